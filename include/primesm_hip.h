@@ -1,0 +1,169 @@
+/*
+ * primesm_hip.h - C ABI of libprimesm_hip.so: the MI355X (gfx950) implementation of the
+ * PRiMEStereoMatch DispEst hot path (CVC cost build -> CVF guided-image-filter aggregation
+ * -> DispSel WTA) that takes the place of the reference's OpenCL side.
+ *
+ * Every entry point names the reference interface it replaces (paths relative to the
+ * reference repository).  Conventions are those of the reference's `_cl` classes:
+ *   - every function returns 0 on success and non-zero on failure (CVC_cl::buildCV,
+ *     src/CVC_cl.cpp:185-210); the message is available from psm_last_error();
+ *   - calls are synchronous on return unless PSM_OPT_ASYNC is set (the reference issues
+ *     clFinish after each launch, src/CVC_cl.cpp:193);
+ *   - the caller owns host memory, the context owns all device memory
+ *     (DispEst owns memoryObjects[12], src/DispEst.cpp:88-128,159-160);
+ *   - a context is used from one thread at a time (the reference calls from a single
+ *     worker thread, src/main.cpp:42,64-73).
+ * Plain pointers and sizes only; no C++/torch types cross this boundary.  The library is
+ * meant to be dlopen()ed by the host program (hipUtil in primestereomatch_amd/host takes
+ * the place of oclUtil) the way the reference defers .cl compilation to run time
+ * (src/oclUtil.cpp:438-496).
+ */
+#ifndef PRIMESM_HIP_H
+#define PRIMESM_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PSM_ABI_VERSION 1
+
+typedef struct psm_ctx psm_ctx;
+
+/* element type of the cost volume ("float mode" / "8-bit char mode") */
+enum { PSM_F32 = 0, PSM_U8 = 1 };
+/* element type of host images handed to psm_upload_pair */
+enum { PSM_IMG_U8 = 0, PSM_IMG_F32 = 1 };
+/* volume side: the reference's buffers CV_LCV / CV_RCV (include/ComFunc.h:65) */
+enum { PSM_LEFT = 0, PSM_RIGHT = 1 };
+/* stages, in the order StereoMatch::compute times them (src/StereoMatch.cpp:225-242) */
+enum { PSM_STAGE_CVC = 0, PSM_STAGE_CVF = 1, PSM_STAGE_DISPSEL = 2, PSM_STAGE_PP = 3,
+       PSM_STAGE_COUNT = 4 };
+/* kernels whose device time can be queried with psm_kernel_time_ms() */
+enum { PSM_K_PREP = 0, PSM_K_CVC = 1, PSM_K_GUIDE = 2, PSM_K_CVF_A = 3, PSM_K_CVF_B = 4,
+       PSM_K_WTA = 5, PSM_K_MERGE = 6, PSM_K_BOX = 7, PSM_K_LRC = 8, PSM_K_COUNT = 9 };
+/* options for psm_set_option */
+enum {
+    PSM_OPT_ASYNC = 0,          /* 1: stage calls only enqueue; use psm_synchronize()        */
+    PSM_OPT_KERNEL_VARIANT = 1, /* 0: marching kernels (default), 1: direct per-voxel kernels */
+    PSM_OPT_PROFILE = 2,        /* 1: bracket every kernel launch with hipEvents              */
+    PSM_OPT_SEG_ROWS = 3,       /* rows per y-segment of the marching kernels (0 = auto)      */
+    PSM_OPT_WAVES = 4           /* waves (disparity slices) per workgroup: 1,2,4,8            */
+};
+
+/* Number of usable HIP devices; 0 if none.  Replaces openCLdevicepoll()
+ * (src/oclUtil.cpp:18-135) whose result StereoMatch receives as gotOCLDev
+ * (src/main.cpp:29,37). */
+int psm_device_count(void);
+
+/* Create a context for W x H images and disparities [0, max_disp): device selection,
+ * stream, the device buffers of enum buff_id (8 image/gradient planes, 2 volumes, 2 maps;
+ * include/ComFunc.h:65, src/DispEst.cpp:88-128) and the CVF intermediates
+ * (src/CVF_cl.cpp:115-159).  Replaces createContext/createCommandQueue/clCreateBuffer and
+ * the three `_cl` constructors (src/DispEst.cpp:57-140).
+ * dtype: PSM_F32 | PSM_U8.  8 <= W,H; 1 <= max_disp <= 256 (maps are 8-bit,
+ * src/DispSel.cpp:105). */
+int psm_create(psm_ctx **out, int width, int height, int max_disp, int dtype, int device);
+
+/* As psm_create, for one rank of a disparity-sharded job: this context holds only the
+ * slices d in [d_begin, d_end) of both volumes.  0 <= d_begin < d_end <=
+ * max_disp. */
+int psm_create_shard(psm_ctx **out, int width, int height, int max_disp, int d_begin, int d_end,
+                     int dtype, int device);
+
+/* Releases everything the context owns (DispEst::~DispEst, src/DispEst.cpp:143-162). */
+void psm_destroy(psm_ctx *ctx);
+
+/* Last error text of this context (ctx == NULL: last creation error).  Replaces
+ * checkSuccess/errorNumberToString (include/oclUtil.h:63-71, src/oclUtil.cpp:582-683). */
+const char *psm_last_error(const psm_ctx *ctx);
+
+int psm_set_option(psm_ctx *ctx, int option, int value);
+/* Run all work of this context on an existing hipStream_t (NULL = the context's own). */
+int psm_set_stream(psm_ctx *ctx, void *hip_stream);
+int psm_synchronize(psm_ctx *ctx);
+
+/* Copy a stereo pair to the device and planarise it.  Replaces the host half of
+ * CVC_cl::buildCV (split + 8x map/memcpy, src/CVC_cl.cpp:95-160) and
+ * DispEst::setInputImages (src/DispEst.cpp:164-170).  l, r: H rows of W interleaved
+ * `channels`(=3, cv::imread order B,G,R) pixels, row pitch stride_bytes.
+ * depth PSM_IMG_U8: values are scaled by 1/255.0f on the device exactly as
+ * convertTo(CV_32F, 1/255.0f) does (src/StereoMatch.cpp:195-196); PSM_IMG_F32: used as is. */
+int psm_upload_pair(psm_ctx *ctx, const void *l, const void *r, int channels, size_t stride_bytes,
+                    int depth);
+
+/* DispEst::CostConst_GPU (src/DispEst.cpp:272-276) == CVC_cl::buildCV: gray + x-gradient
+ * of both images (CVC::preprocess arithmetic, src/CVC.cpp:41-46 - no +0.5) and both cost
+ * volumes (CVC::buildCV_left/right arithmetic, src/CVC.cpp:122-179). */
+int psm_cost_construct(psm_ctx *ctx);
+
+/* DispEst::CostFilter_GPU (src/DispEst.cpp:299-308) == CVF_cl::preprocess + filterCV for
+ * the left then the right volume, with the arithmetic of CVF::preprocess and
+ * GuidedFilter_cv (src/CVF.cpp:44-165).  Filters both volumes in place. */
+int psm_cost_filter(psm_ctx *ctx);
+
+/* DispEst::DispSelect_GPU (src/DispEst.cpp:323-328) == DispSel_cl::CVSelect
+ * (src/DispSel_cl.cpp:69-140) with DispSel::CVSelect arithmetic (src/DispSel.cpp:83-109).
+ * lmap/rmap: H rows of W bytes, row pitch `stride` (cv::Mat lDisMap/rDisMap, CV_8UC1).
+ * Either may be NULL: the maps then stay on the device (psm_download_maps).
+ * Only valid on an unsharded context. */
+int psm_disp_select(psm_ctx *ctx, uint8_t *lmap, uint8_t *rmap, size_t stride);
+
+/* Sharded DispSel, step 1: local argmin over this context's slices with the global
+ * semantics (d = 0 never a candidate, strict '<', lowest d wins ties).  Writes one packed
+ * 64-bit key per pixel and side, keys[side][y][x] = (ordered(cost) << 32 | d) ^ (1<<63), so
+ * that a signed 64-bit minimum over ranks selects (min cost, then lowest d).
+ * dev_keys: DEVICE pointer to 2*H*W int64 (e.g. a torch tensor handed to RCCL), or NULL to
+ * use the context's own buffer (psm_partial_keys). */
+int psm_disp_select_partial(psm_ctx *ctx, void *dev_keys);
+/* Device pointer / size of the context's own key buffer. */
+int psm_partial_keys(psm_ctx *ctx, void **dev_keys, size_t *bytes);
+/* Sharded DispSel, step 2: dev_keys_all = DEVICE pointer to nranks consecutive key buffers
+ * (the all-gather result, rank-major).  Produces the two final maps as psm_disp_select. */
+int psm_disp_merge(psm_ctx *ctx, const void *dev_keys_all, int nranks, uint8_t *lmap,
+                   uint8_t *rmap, size_t stride);
+
+int psm_download_maps(psm_ctx *ctx, uint8_t *lmap, uint8_t *rmap, size_t stride);
+
+/* "next" row: PP lrCheck on the device (src/PP.cpp:17-50) on the maps of the last
+ * psm_disp_select/psm_disp_merge.  lvalid/rvalid: H x W bytes (0/1), pitch `stride`; either
+ * may be NULL (results stay on the device). */
+int psm_lr_check(psm_ctx *ctx, uint8_t *lvalid, uint8_t *rvalid, size_t stride);
+
+/* ---- debug / bench entry points (no counterpart in the reference) ---- */
+
+/* Copy slices [d0,d1) (global disparity numbers) of a volume to/from dense host memory
+ * [d1-d0][H][W]; element type = the context's dtype. */
+int psm_download_volume(psm_ctx *ctx, int side, int d0, int d1, void *host);
+int psm_upload_volume(psm_ctx *ctx, int side, int d0, int d1, const void *host);
+/* After psm_cost_filter: the a0,a1,a2,b intermediates of the LAST filtered side (right) are
+ * still in the scratch buffer; psm_filter_stage_a(side) runs only the first half of the
+ * guided filter for `side` and leaves them there.  host: [d1-d0][H][W][4] floats. */
+int psm_filter_stage_a(psm_ctx *ctx, int side);
+int psm_download_ab(psm_ctx *ctx, int d0, int d1, float *host);
+/* guidance planes of `side` after psm_cost_filter/psm_filter_stage_a: host receives
+ * [14][H][W] floats: I0,I1,I2,grad, mI0,mI1,mI2,invDET, A00,A01,A02,A11,A12,A22. */
+int psm_download_guidance(psm_ctx *ctx, int side, float *host);
+/* The north-star kernel in isolation: cv::boxFilter(Size(8,8)) semantics applied to every
+ * slice of volume `side`, result left in the scratch buffer; host (optional) receives
+ * [Dlocal][H][W] floats. */
+int psm_box8_volume(psm_ctx *ctx, int side, float *host);
+
+/* Wall time of the last call of each stage in microseconds (the reference's
+ * cvc_time/cvf_time/dispsel_time, src/StereoMatch.cpp:227-241). */
+int psm_stage_time_us(psm_ctx *ctx, int stage, double *us);
+/* With PSM_OPT_PROFILE=1: accumulated device time (hipEvent pairs on the launch stream)
+ * and launch count of a kernel class since the last psm_reset_kernel_times(). */
+int psm_kernel_time_ms(psm_ctx *ctx, int kernel, double *total_ms, int *launches);
+int psm_reset_kernel_times(psm_ctx *ctx);
+
+/* geometry queries */
+int psm_get_info(const psm_ctx *ctx, int *width, int *height, int *max_disp, int *d_begin,
+                 int *d_end, int *dtype, int *device);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

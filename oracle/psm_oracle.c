@@ -1,0 +1,776 @@
+/*
+ * psm_oracle.c - CPU restatement of the DispEst hot path (CVC -> CVF -> DispSel).
+ * TEST INFRASTRUCTURE ONLY - see psm_oracle.h.  "parity unpinned" (no reference binary,
+ * tests or golden vectors exist; OpenCV semantics per SURVEY.md Appendix A).
+ *
+ * Build: gcc -O2 -ffp-contract=off -fno-fast-math -fPIC -shared -pthread (oracle/Makefile).
+ */
+#include "psm_oracle.h"
+
+#include <math.h>
+#include <pthread.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+
+/* ------------------------------------------------------------------------------- */
+/* helpers                                                                          */
+/* ------------------------------------------------------------------------------- */
+
+/* cv::BORDER_REFLECT_101 index map (gfedcb|abcdefgh|gfedcba). */
+static inline int r101(int k, int n)
+{
+    if (k < 0) k = -k;
+    if (k >= n) k = 2 * (n - 1) - k;
+    return k;
+}
+
+static double now_ms(void)
+{ /* include/ComFunc.h:67-71 get_rt(), kept in double */
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (double)ts.tv_sec * 1e3 + (double)ts.tv_nsec * 1e-6;
+}
+
+#define T8(t0, t1, t2, t3, t4, t5, t6, t7) \
+    ((((t0) + (t1)) + ((t2) + (t3))) + (((t4) + (t5)) + ((t6) + (t7))))
+
+/* ------------------------------------------------------------------------------- */
+/* input conditioning                                                               */
+/* ------------------------------------------------------------------------------- */
+
+void psmo_u8_to_f32(const uint8_t *src, size_t n, float *dst)
+{
+    /* src/StereoMatch.cpp:195: convertTo(CV_32F, 1/255.0f) -> (float)u8 * alpha, fp32 */
+    const float alpha = 1 / 255.0f;
+    for (size_t i = 0; i < n; ++i) dst[i] = (float)src[i] * alpha;
+}
+
+/* ------------------------------------------------------------------------------- */
+/* CVC (float)                                                                      */
+/* ------------------------------------------------------------------------------- */
+
+#define BC_32F 1.0     /* include/CVC.h:12  (a double literal) */
+#define ALPHA_32F 0.9f /* include/CVC.h:23 */
+
+/* src/CVC.cpp:18-27 */
+static inline float myCostGrd2(const float *lC, const float *rC, const float *lG, const float *rG)
+{
+    float clrDiff = fabsf(lC[0] - rC[0]) + fabsf(lC[1] - rC[1]) + fabsf(lC[2] - rC[2]);
+    float grdDiff = fabsf(*lG - *rG);
+    return ALPHA_32F * clrDiff + (1 - ALPHA_32F) * grdDiff;
+}
+
+/* src/CVC.cpp:30-39: BC_32F is a double, so the differences and their sum are double and
+ * are rounded once when assigned to the float locals. */
+static inline float myCostGrd1(const float *lC, const float *lG)
+{
+    float clrDiff = (float)(fabs(lC[0] - BC_32F) + fabs(lC[1] - BC_32F) + fabs(lC[2] - BC_32F));
+    float grdDiff = (float)fabs(*lG - BC_32F);
+    return ALPHA_32F * clrDiff + (1 - ALPHA_32F) * grdDiff;
+}
+
+void psmo_cvc_preprocess(const float *img, int H, int W, float *grdx)
+{
+    /* src/CVC.cpp:43: cvtColor(Img, GrdX, CV_RGB2GRAY) on BGR data: 0.299 multiplies c0.
+     * src/CVC.cpp:44: Sobel(GrdX, GrdX, CV_32F, 1, 0, 1): [-1 0 1], REFLECT_101. */
+    float *gray = (float *)malloc((size_t)H * W * sizeof(float));
+    for (int y = 0; y < H; ++y)
+        for (int x = 0; x < W; ++x) {
+            const float *c = img + ((size_t)y * W + x) * 3;
+            gray[(size_t)y * W + x] = (c[0] * 0.299f + c[1] * 0.587f) + c[2] * 0.114f;
+        }
+    for (int y = 0; y < H; ++y) {
+        const float *g = gray + (size_t)y * W;
+        for (int x = 0; x < W; ++x) grdx[(size_t)y * W + x] = g[r101(x + 1, W)] - g[r101(x - 1, W)];
+    }
+    free(gray);
+}
+
+void psmo_cvc_build_left(const float *lImg, const float *rImg, const float *lGrdX,
+                         const float *rGrdX, int H, int W, int d, float *cost)
+{
+    /* src/CVC.cpp:127-147 */
+    for (int y = 0; y < H; ++y) {
+        const float *lData = lImg + (size_t)y * W * 3;
+        const float *rData = rImg + (size_t)y * W * 3;
+        const float *lGData = lGrdX + (size_t)y * W;
+        const float *rGData = rGrdX + (size_t)y * W;
+        float *c = cost + (size_t)y * W;
+        for (int x = d; x < W; ++x)
+            c[x] = myCostGrd2(lData + 3 * x, rData + 3 * (x - d), lGData + x, rGData + x - d);
+        for (int x = 0; x < d && x < W; ++x) c[x] = myCostGrd1(lData + 3 * x, lGData + x);
+    }
+}
+
+void psmo_cvc_build_right(const float *lImg, const float *rImg, const float *lGrdX,
+                          const float *rGrdX, int H, int W, int d, float *cost)
+{
+    /* src/CVC.cpp:157-177 */
+    int border = W - d;
+    if (border < 0) border = 0;
+    for (int y = 0; y < H; ++y) {
+        const float *lData = lImg + (size_t)y * W * 3;
+        const float *rData = rImg + (size_t)y * W * 3;
+        const float *lGData = lGrdX + (size_t)y * W;
+        const float *rGData = rGrdX + (size_t)y * W;
+        float *c = cost + (size_t)y * W;
+        for (int x = 0; x < border; ++x)
+            c[x] = myCostGrd2(lData + 3 * x, rData + 3 * (x + d), lGData + x, rGData + x + d);
+        for (int x = border; x < W; ++x) c[x] = myCostGrd1(lData + 3 * x, lGData + x);
+    }
+}
+
+/* ------------------------------------------------------------------------------- */
+/* CVF                                                                              */
+/* ------------------------------------------------------------------------------- */
+
+/* box with caller-provided double scratch (H*W) so threads do not malloc per call */
+static void box8_ws(const float *src, int H, int W, float *dst, double *hs)
+{
+    for (int y = 0; y < H; ++y) {
+        const float *s = src + (size_t)y * W;
+        double *h = hs + (size_t)y * W;
+        for (int x = 0; x < W; ++x) {
+            double t0 = s[r101(x - 4, W)], t1 = s[r101(x - 3, W)], t2 = s[r101(x - 2, W)],
+                   t3 = s[r101(x - 1, W)], t4 = s[x], t5 = s[r101(x + 1, W)],
+                   t6 = s[r101(x + 2, W)], t7 = s[r101(x + 3, W)];
+            h[x] = T8(t0, t1, t2, t3, t4, t5, t6, t7);
+        }
+    }
+    for (int y = 0; y < H; ++y) {
+        const double *r0 = hs + (size_t)r101(y - 4, H) * W, *r1 = hs + (size_t)r101(y - 3, H) * W,
+                     *r2 = hs + (size_t)r101(y - 2, H) * W, *r3 = hs + (size_t)r101(y - 1, H) * W,
+                     *r4 = hs + (size_t)y * W, *r5 = hs + (size_t)r101(y + 1, H) * W,
+                     *r6 = hs + (size_t)r101(y + 2, H) * W, *r7 = hs + (size_t)r101(y + 3, H) * W;
+        float *o = dst + (size_t)y * W;
+        for (int x = 0; x < W; ++x)
+            o[x] = (float)(T8(r0[x], r1[x], r2[x], r3[x], r4[x], r5[x], r6[x], r7[x]) * (1.0 / 64));
+    }
+}
+
+void psmo_box8(const float *src, int H, int W, float *dst)
+{
+    double *hs = (double *)malloc((size_t)H * W * sizeof(double));
+    box8_ws(src, H, W, dst, hs);
+    free(hs);
+}
+
+void psmo_cvf_preprocess(const float *img, int H, int W, float *rgb, float *mean, float *var)
+{
+    const size_t N = (size_t)H * W;
+    float *tmp = (float *)malloc(N * sizeof(float));
+    double *hs = (double *)malloc(N * sizeof(double));
+    /* src/CVF.cpp:47 split */
+    for (size_t i = 0; i < N; ++i)
+        for (int c = 0; c < 3; ++c) rgb[c * N + i] = img[i * 3 + c];
+    /* src/CVF.cpp:49-51 */
+    for (int c = 0; c < 3; ++c) box8_ws(rgb + c * N, H, W, mean + c * N, hs);
+    /* src/CVF.cpp:58-68 */
+    int varIdx = 0;
+    for (int c = 0; c < 3; ++c)
+        for (int cp = c; cp < 3; ++cp) {
+            float *v = var + (size_t)varIdx * N;
+            for (size_t i = 0; i < N; ++i) tmp[i] = rgb[c * N + i] * rgb[cp * N + i];
+            box8_ws(tmp, H, W, v, hs);
+            for (size_t i = 0; i < N; ++i) {
+                float m = mean[c * N + i] * mean[cp * N + i];
+                v[i] = v[i] - m;
+            }
+            ++varIdx;
+        }
+    free(tmp);
+    free(hs);
+}
+
+/* workspace-taking core of GuidedFilter_cv; ws: 9*N floats, hs: N doubles */
+static void guided_filter_ws(const float *rgb, const float *mean_I, const float *var_I, int H,
+                             int W, float *p, float *ab_out, float *ws, double *hs)
+{
+    const size_t N = (size_t)H * W;
+    float *mean_p = ws;             /* N */
+    float *tmp = ws + N;            /* N */
+    float *mean_Ip = ws + 2 * N;    /* 3N, becomes cov_Ip */
+    float *a = ws + 5 * N;          /* 3N */
+    float *q = ws + 8 * N;          /* N */
+
+    /* src/CVF.cpp:81-82 */
+    box8_ws(p, H, W, mean_p, hs);
+    /* src/CVF.cpp:86-89 */
+    for (int c = 0; c < 3; ++c) {
+        for (size_t i = 0; i < N; ++i) tmp[i] = rgb[c * N + i] * p[i];
+        box8_ws(tmp, H, W, mean_Ip + c * N, hs);
+    }
+    /* src/CVF.cpp:91-95: cov_Ip = mean_Ip - mean_I*mean_p */
+    for (int c = 0; c < 3; ++c)
+        for (size_t i = 0; i < N; ++i) {
+            float t = mean_I[c * N + i] * mean_p[i];
+            mean_Ip[c * N + i] = mean_Ip[c * N + i] - t;
+        }
+    /* src/CVF.cpp:102-149 */
+    for (size_t i = 0; i < N; ++i) {
+        float c0 = mean_Ip[0 * N + i];
+        float c1 = mean_Ip[1 * N + i];
+        float c2 = mean_Ip[2 * N + i];
+        float a11 = var_I[0 * N + i] + PSMO_GIF_EPS;
+        float a12 = var_I[1 * N + i];
+        float a13 = var_I[2 * N + i];
+        float a21 = var_I[1 * N + i];
+        float a22 = var_I[3 * N + i] + PSMO_GIF_EPS;
+        float a23 = var_I[4 * N + i];
+        float a31 = var_I[2 * N + i];
+        float a32 = var_I[4 * N + i];
+        float a33 = var_I[5 * N + i] + PSMO_GIF_EPS;
+        float DET = a11 * (a33 * a22 - a32 * a23) - a21 * (a33 * a12 - a32 * a13) +
+                    a31 * (a23 * a12 - a22 * a13);
+        DET = 1 / DET;
+        a[0 * N + i] = DET * (c0 * (a33 * a22 - a32 * a23) + c1 * (a31 * a23 - a33 * a21) +
+                              c2 * (a32 * a21 - a31 * a22));
+        a[1 * N + i] = DET * (c0 * (a32 * a13 - a33 * a12) + c1 * (a33 * a11 - a31 * a13) +
+                              c2 * (a31 * a12 - a32 * a11));
+        a[2 * N + i] = DET * (c0 * (a23 * a12 - a22 * a13) + c1 * (a21 * a13 - a23 * a11) +
+                              c2 * (a22 * a11 - a21 * a12));
+    }
+    /* src/CVF.cpp:152-155: mean_p -= a[c]*mean_I[c], sequentially */
+    for (int c = 0; c < 3; ++c)
+        for (size_t i = 0; i < N; ++i) {
+            float t = a[c * N + i] * mean_I[c * N + i];
+            mean_p[i] = mean_p[i] - t;
+        }
+    if (ab_out) {
+        memcpy(ab_out, a, 3 * N * sizeof(float));
+        memcpy(ab_out + 3 * N, mean_p, N * sizeof(float));
+    }
+    /* src/CVF.cpp:157-163 */
+    box8_ws(mean_p, H, W, q, hs);
+    for (int c = 0; c < 3; ++c) {
+        box8_ws(a + c * N, H, W, tmp, hs);
+        for (size_t i = 0; i < N; ++i) {
+            float t = tmp[i] * rgb[c * N + i];
+            q[i] = q[i] + t;
+        }
+    }
+    memcpy(p, q, N * sizeof(float));
+}
+
+void psmo_guided_filter(const float *rgb, const float *mean, const float *var, int H, int W,
+                        float *p, float *ab)
+{
+    const size_t N = (size_t)H * W;
+    float *ws = (float *)malloc(9 * N * sizeof(float));
+    double *hs = (double *)malloc(N * sizeof(double));
+    guided_filter_ws(rgb, mean, var, H, W, p, ab, ws, hs);
+    free(ws);
+    free(hs);
+}
+
+/* ------------------------------------------------------------------------------- */
+/* DispSel                                                                          */
+/* ------------------------------------------------------------------------------- */
+
+void psmo_wta(const float *vol, int D, int H, int W, uint8_t *disp)
+{
+    /* src/DispSel.cpp:88-107.  "float minCost = DBL_MAX" converts to +inf. */
+    const size_t N = (size_t)H * W;
+    for (int y = 0; y < H; ++y)
+        for (int x = 0; x < W; ++x) {
+            float minCost = INFINITY;
+            int minDis = 0;
+            for (int d = 1; d < D; ++d) {
+                float c = vol[(size_t)d * N + (size_t)y * W + x];
+                if (c < minCost) {
+                    minCost = c;
+                    minDis = d;
+                }
+            }
+            disp[(size_t)y * W + x] = (uint8_t)minDis;
+        }
+}
+
+void psmo_wta_partial(const float *vol, int d_begin, int d_end, int H, int W, float *min_cost,
+                      int32_t *min_disp)
+{
+    const size_t N = (size_t)H * W;
+    for (size_t i = 0; i < N; ++i) {
+        float minCost = INFINITY;
+        int minDis = 0;
+        for (int d = (d_begin < 1 ? 1 : d_begin); d < d_end; ++d) {
+            float c = vol[(size_t)(d - d_begin) * N + i];
+            if (c < minCost) {
+                minCost = c;
+                minDis = d;
+            }
+        }
+        min_cost[i] = minCost;
+        min_disp[i] = minDis;
+    }
+}
+
+/* ------------------------------------------------------------------------------- */
+/* pthreads driver: one joinable thread per disparity, in blocks of `threads`       */
+/* (src/DispEst.cpp:235-268)                                                        */
+/* ------------------------------------------------------------------------------- */
+
+typedef struct {
+    /* buildCV_TD, include/CVC.h:46-53 */
+    const float *lImg, *rImg, *lGrdX, *rGrdX;
+    int H, W, d, right;
+    float *costVol;
+} buildCV_TD;
+
+static void *buildCV_thread(void *arg)
+{
+    buildCV_TD *t = (buildCV_TD *)arg;
+    if (t->right)
+        psmo_cvc_build_right(t->lImg, t->rImg, t->lGrdX, t->rGrdX, t->H, t->W, t->d, t->costVol);
+    else
+        psmo_cvc_build_left(t->lImg, t->rImg, t->lGrdX, t->rGrdX, t->H, t->W, t->d, t->costVol);
+    return NULL;
+}
+
+typedef struct {
+    /* filterCV_TD, include/CVF.h:28 */
+    const float *Img_rgb, *mean_Img, *var_Img;
+    int H, W;
+    float *costVol;
+    float *ws;
+    double *hs;
+} filterCV_TD;
+
+static void *filterCV_thread(void *arg)
+{ /* src/CVF.cpp:28-41 */
+    filterCV_TD *t = (filterCV_TD *)arg;
+    guided_filter_ws(t->Img_rgb, t->mean_Img, t->var_Img, t->H, t->W, t->costVol, NULL, t->ws,
+                     t->hs);
+    return NULL;
+}
+
+typedef struct {
+    void *(*fn)(void *);
+    void *arg;
+} job;
+
+/* the level/block_size pattern of src/DispEst.cpp:235-251 */
+static void run_blocked(job *jobs, int n, int threads)
+{
+    pthread_t *tid = (pthread_t *)malloc((size_t)(n > 0 ? n : 1) * sizeof(pthread_t));
+    pthread_attr_t attr;
+    pthread_attr_init(&attr);
+    pthread_attr_setdetachstate(&attr, PTHREAD_CREATE_JOINABLE);
+    for (int level = 0; level <= n / threads; ++level) {
+        int block_size = (level < n / threads) ? threads : (n % threads);
+        for (int iter = 0; iter < block_size; ++iter) {
+            int d = level * threads + iter;
+            pthread_create(&tid[d], &attr, jobs[d].fn, jobs[d].arg);
+        }
+        for (int iter = 0; iter < block_size; ++iter) {
+            int d = level * threads + iter;
+            pthread_join(tid[d], NULL);
+        }
+    }
+    pthread_attr_destroy(&attr);
+    free(tid);
+}
+
+typedef struct {
+    const float *vol;
+    int D, H, W, y0, y1;
+    uint8_t *disp;
+} wta_TD;
+
+static void *wta_rows_thread(void *arg)
+{
+    wta_TD *t = (wta_TD *)arg;
+    const size_t N = (size_t)t->H * t->W;
+    for (int y = t->y0; y < t->y1; ++y)
+        for (int x = 0; x < t->W; ++x) {
+            float minCost = INFINITY;
+            int minDis = 0;
+            for (int d = 1; d < t->D; ++d) {
+                float c = t->vol[(size_t)d * N + (size_t)y * t->W + x];
+                if (c < minCost) {
+                    minCost = c;
+                    minDis = d;
+                }
+            }
+            t->disp[(size_t)y * t->W + x] = (uint8_t)minDis;
+        }
+    return NULL;
+}
+
+/* DispSel::CVSelect is "#pragma omp parallel for" over rows (src/DispSel.cpp:88); here the
+ * rows are split statically over `threads` pthreads - same arithmetic, same result. */
+static void wta_parallel(const float *vol, int D, int H, int W, uint8_t *disp, int threads)
+{
+    pthread_t tid[PSMO_MAX_CPU_THREADS * 32];
+    wta_TD td[PSMO_MAX_CPU_THREADS * 32];
+    if (threads > PSMO_MAX_CPU_THREADS * 32) threads = PSMO_MAX_CPU_THREADS * 32;
+    for (int t = 0; t < threads; ++t) {
+        td[t] = (wta_TD){vol, D, H, W, (int)((long)H * t / threads), (int)((long)H * (t + 1) / threads), disp};
+        pthread_create(&tid[t], NULL, wta_rows_thread, &td[t]);
+    }
+    for (int t = 0; t < threads; ++t) pthread_join(tid[t], NULL);
+}
+
+int psmo_pipeline_f32(const uint8_t *l_bgr, const uint8_t *r_bgr, int H, int W, int D, int threads,
+                      uint8_t *ldisp, uint8_t *rdisp, float *lvol, float *rvol, float *raw_l,
+                      float *raw_r, psmo_times *times)
+{
+    if (!l_bgr || !r_bgr || H < 8 || W < 8 || D < 1 || D > 256 || threads < 1) return -1;
+    const size_t N = (size_t)H * W;
+    int rc = -1;
+    float *lImg = (float *)malloc(N * 3 * sizeof(float)), *rImg = (float *)malloc(N * 3 * sizeof(float));
+    float *lG = (float *)malloc(N * sizeof(float)), *rG = (float *)malloc(N * sizeof(float));
+    float *lv = lvol ? lvol : (float *)malloc(N * D * sizeof(float));
+    float *rv = rvol ? rvol : (float *)malloc(N * D * sizeof(float));
+    float *guide = (float *)malloc(12 * N * sizeof(float));
+    float *ws = (float *)malloc((size_t)threads * 9 * N * sizeof(float));
+    double *hs = (double *)malloc((size_t)threads * N * sizeof(double));
+    job *jobs = (job *)malloc((size_t)D * sizeof(job));
+    buildCV_TD *btd = (buildCV_TD *)malloc((size_t)D * sizeof(buildCV_TD));
+    filterCV_TD *ftd = (filterCV_TD *)malloc((size_t)D * sizeof(filterCV_TD));
+    if (!lImg || !rImg || !lG || !rG || !lv || !rv || !guide || !ws || !hs || !jobs || !btd || !ftd)
+        goto done;
+
+    /* src/StereoMatch.cpp:193-198 */
+    psmo_u8_to_f32(l_bgr, N * 3, lImg);
+    psmo_u8_to_f32(r_bgr, N * 3, rImg);
+
+    /* ---- CostConst_CPU, src/DispEst.cpp:222-270 ---- */
+    double t0 = now_ms();
+    psmo_cvc_preprocess(lImg, H, W, lG);
+    psmo_cvc_preprocess(rImg, H, W, rG);
+    for (int d = 0; d < D; ++d) {
+        btd[d] = (buildCV_TD){lImg, rImg, lG, rG, H, W, d, 0, lv + (size_t)d * N};
+        jobs[d] = (job){buildCV_thread, &btd[d]};
+    }
+    run_blocked(jobs, D, threads);
+    for (int d = 0; d < D; ++d) {
+        btd[d] = (buildCV_TD){rImg, lImg, rG, lG, H, W, d, 1, rv + (size_t)d * N};
+        jobs[d] = (job){buildCV_thread, &btd[d]};
+    }
+    run_blocked(jobs, D, threads);
+    double t1 = now_ms();
+    if (raw_l) memcpy(raw_l, lv, N * D * sizeof(float));
+    if (raw_r) memcpy(raw_r, rv, N * D * sizeof(float));
+
+    /* ---- cost filter: CVF::preprocess once per side + one filterCV_thread per d in the
+     * same level/block pattern (driver absent from the snapshot; order
+     * L-preprocess, L-filter, R-preprocess, R-filter as src/DispEst.cpp:302-305) ---- */
+    double t2 = now_ms();
+    for (int side = 0; side < 2; ++side) {
+        float *vol = side ? rv : lv;
+        psmo_cvf_preprocess(side ? rImg : lImg, H, W, guide, guide + 3 * N, guide + 6 * N);
+        for (int d = 0; d < D; ++d) {
+            int slot = d % threads; /* threads of one block run concurrently: distinct slots */
+            ftd[d] = (filterCV_TD){guide, guide + 3 * N, guide + 6 * N, H, W, vol + (size_t)d * N,
+                                   ws + (size_t)slot * 9 * N, hs + (size_t)slot * N};
+            jobs[d] = (job){filterCV_thread, &ftd[d]};
+        }
+        run_blocked(jobs, D, threads);
+    }
+    double t3 = now_ms();
+
+    /* ---- DispSelect_CPU, src/DispEst.cpp:311-321 ---- */
+    wta_parallel(lv, D, H, W, ldisp, threads);
+    wta_parallel(rv, D, H, W, rdisp, threads);
+    double t4 = now_ms();
+
+    if (times) {
+        times->cvc_ms = t1 - t0;
+        times->cvf_ms = t3 - t2;
+        times->dispsel_ms = t4 - t3;
+    }
+    rc = 0;
+done:
+    free(lImg); free(rImg); free(lG); free(rG);
+    if (!lvol) free(lv);
+    if (!rvol) free(rv);
+    free(guide); free(ws); free(hs); free(jobs); free(btd); free(ftd);
+    return rc;
+}
+
+/* ------------------------------------------------------------------------------- */
+/* 8-bit char mode (build-defined, see header)                                      */
+/* ------------------------------------------------------------------------------- */
+
+void psmo_gray_grad_u8(const uint8_t *img, int H, int W, uint8_t *gray, uint8_t *grdx)
+{
+    /* OpenCV 8-bit RGB2GRAY fixed point (14 fractional bits): R2Y=4899 G2Y=9617 B2Y=1868,
+     * applied in memory order (so 4899 multiplies c0, as in the float path). */
+    for (size_t i = 0; i < (size_t)H * W; ++i) {
+        const uint8_t *c = img + i * 3;
+        gray[i] = (uint8_t)((c[0] * 4899 + c[1] * 9617 + c[2] * 1868 + (1 << 13)) >> 14);
+    }
+    /* Sobel(gray, grd, CV_8U, 1, 0, 1) (commented host code src/CVC_cl.cpp:127-128):
+     * saturate_cast<uchar>(g[x+1]-g[x-1]), REFLECT_101. */
+    for (int y = 0; y < H; ++y) {
+        const uint8_t *g = gray + (size_t)y * W;
+        for (int x = 0; x < W; ++x) {
+            int v = (int)g[r101(x + 1, W)] - (int)g[r101(x - 1, W)];
+            grdx[(size_t)y * W + x] = (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v));
+        }
+    }
+}
+
+/* assets/cvc.cl:279-301: integer colour term /3; TAU_1_US/TAU_2_US (1835/524) can never
+ * clip an 8-bit value; (uchar)(ALPHA*clr + (1-ALPHA)*grd) in fp32, truncating cast. */
+static inline uint8_t cost_u8(int clr3, int grd)
+{
+    unsigned short clrDiff = (unsigned short)(clr3 / 3);
+    unsigned short grdDiff = (unsigned short)grd;
+    float f = 0.9f * (float)clrDiff + (1 - 0.9f) * (float)grdDiff;
+    return (uint8_t)f;
+}
+
+void psmo_cvc_build_left_u8(const uint8_t *lImg, const uint8_t *rImg, const uint8_t *lGrdX,
+                            const uint8_t *rGrdX, int H, int W, int d, uint8_t *cost)
+{
+    for (int y = 0; y < H; ++y)
+        for (int x = 0; x < W; ++x) {
+            const uint8_t *lC = lImg + ((size_t)y * W + x) * 3;
+            int lG = lGrdX[(size_t)y * W + x];
+            int clr, grd;
+            if (x >= d) {
+                const uint8_t *rC = rImg + ((size_t)y * W + x - d) * 3;
+                clr = abs(lC[0] - rC[0]) + abs(lC[1] - rC[1]) + abs(lC[2] - rC[2]);
+                grd = abs(lG - rGrdX[(size_t)y * W + x - d]);
+            } else {
+                clr = abs(lC[0] - 255) + abs(lC[1] - 255) + abs(lC[2] - 255);
+                grd = abs(lG - 255);
+            }
+            cost[(size_t)y * W + x] = cost_u8(clr, grd);
+        }
+}
+
+void psmo_cvc_build_right_u8(const uint8_t *lImg, const uint8_t *rImg, const uint8_t *lGrdX,
+                             const uint8_t *rGrdX, int H, int W, int d, uint8_t *cost)
+{
+    /* predicate corrected to x < W-d (assets/cvc.cl:400-408 uses x>=d with +d reads and runs
+     * off the row - SURVEY.md Appendix B); argument order as buildCV_right. */
+    for (int y = 0; y < H; ++y)
+        for (int x = 0; x < W; ++x) {
+            const uint8_t *lC = lImg + ((size_t)y * W + x) * 3;
+            int lG = lGrdX[(size_t)y * W + x];
+            int clr, grd;
+            if (x < W - d) {
+                const uint8_t *rC = rImg + ((size_t)y * W + x + d) * 3;
+                clr = abs(lC[0] - rC[0]) + abs(lC[1] - rC[1]) + abs(lC[2] - rC[2]);
+                grd = abs(lG - rGrdX[(size_t)y * W + x + d]);
+            } else {
+                clr = abs(lC[0] - 255) + abs(lC[1] - 255) + abs(lC[2] - 255);
+                grd = abs(lG - 255);
+            }
+            cost[(size_t)y * W + x] = cost_u8(clr, grd);
+        }
+}
+
+void psmo_wta_u8(const uint8_t *vol, int D, int H, int W, uint8_t *disp)
+{
+    /* assets/dispsel.cl:41-62 with minCost initialised to 256 instead of UCHAR_MAX */
+    const size_t N = (size_t)H * W;
+    for (size_t i = 0; i < N; ++i) {
+        int minCost = 256, minDis = 0;
+        for (int d = 1; d < D; ++d) {
+            int c = vol[(size_t)d * N + i];
+            if (c < minCost) {
+                minCost = c;
+                minDis = d;
+            }
+        }
+        disp[i] = (uint8_t)minDis;
+    }
+}
+
+static inline uint8_t quant_u8(float q)
+{
+    float r = rintf(q * 255.0f); /* round-half-even; NaN -> 0 */
+    if (!(r > 0.0f)) return 0;
+    if (r > 255.0f) return 255;
+    return (uint8_t)r;
+}
+
+typedef struct {
+    const float *Img_rgb, *mean_Img, *var_Img;
+    int H, W;
+    uint8_t *costVol;
+    float *ws;
+    double *hs;
+} filterCV8_TD;
+
+static void *filterCV8_thread(void *arg)
+{
+    filterCV8_TD *t = (filterCV8_TD *)arg;
+    const size_t N = (size_t)t->H * t->W;
+    float *p = t->ws + 9 * N;
+    psmo_u8_to_f32(t->costVol, N, p);
+    guided_filter_ws(t->Img_rgb, t->mean_Img, t->var_Img, t->H, t->W, p, NULL, t->ws, t->hs);
+    for (size_t i = 0; i < N; ++i) t->costVol[i] = quant_u8(p[i]);
+    return NULL;
+}
+
+typedef struct {
+    const uint8_t *lImg, *rImg, *lGrdX, *rGrdX;
+    int H, W, d, right;
+    uint8_t *costVol;
+} buildCV8_TD;
+
+static void *buildCV8_thread(void *arg)
+{
+    buildCV8_TD *t = (buildCV8_TD *)arg;
+    if (t->right)
+        psmo_cvc_build_right_u8(t->lImg, t->rImg, t->lGrdX, t->rGrdX, t->H, t->W, t->d, t->costVol);
+    else
+        psmo_cvc_build_left_u8(t->lImg, t->rImg, t->lGrdX, t->rGrdX, t->H, t->W, t->d, t->costVol);
+    return NULL;
+}
+
+int psmo_pipeline_u8(const uint8_t *l_bgr, const uint8_t *r_bgr, int H, int W, int D, int threads,
+                     uint8_t *ldisp, uint8_t *rdisp, uint8_t *lvol, uint8_t *rvol, uint8_t *raw_l,
+                     uint8_t *raw_r, psmo_times *times)
+{
+    if (!l_bgr || !r_bgr || H < 8 || W < 8 || D < 1 || D > 256 || threads < 1) return -1;
+    const size_t N = (size_t)H * W;
+    int rc = -1;
+    uint8_t *gray = (uint8_t *)malloc(N), *lG = (uint8_t *)malloc(N), *rG = (uint8_t *)malloc(N);
+    uint8_t *lv = lvol ? lvol : (uint8_t *)malloc(N * D), *rv = rvol ? rvol : (uint8_t *)malloc(N * D);
+    float *img = (float *)malloc(N * 3 * sizeof(float));
+    float *guide = (float *)malloc(12 * N * sizeof(float));
+    float *ws = (float *)malloc((size_t)threads * 10 * N * sizeof(float));
+    double *hs = (double *)malloc((size_t)threads * N * sizeof(double));
+    job *jobs = (job *)malloc((size_t)D * sizeof(job));
+    buildCV8_TD *btd = (buildCV8_TD *)malloc((size_t)D * sizeof(buildCV8_TD));
+    filterCV8_TD *ftd = (filterCV8_TD *)malloc((size_t)D * sizeof(filterCV8_TD));
+    if (!gray || !lG || !rG || !lv || !rv || !img || !guide || !ws || !hs || !jobs || !btd || !ftd)
+        goto done;
+
+    double t0 = now_ms();
+    psmo_gray_grad_u8(l_bgr, H, W, gray, lG);
+    psmo_gray_grad_u8(r_bgr, H, W, gray, rG);
+    for (int d = 0; d < D; ++d) {
+        btd[d] = (buildCV8_TD){l_bgr, r_bgr, lG, rG, H, W, d, 0, lv + (size_t)d * N};
+        jobs[d] = (job){buildCV8_thread, &btd[d]};
+    }
+    run_blocked(jobs, D, threads);
+    for (int d = 0; d < D; ++d) {
+        btd[d] = (buildCV8_TD){r_bgr, l_bgr, rG, lG, H, W, d, 1, rv + (size_t)d * N};
+        jobs[d] = (job){buildCV8_thread, &btd[d]};
+    }
+    run_blocked(jobs, D, threads);
+    double t1 = now_ms();
+    if (raw_l) memcpy(raw_l, lv, N * D);
+    if (raw_r) memcpy(raw_r, rv, N * D);
+
+    for (int side = 0; side < 2; ++side) {
+        uint8_t *vol = side ? rv : lv;
+        psmo_u8_to_f32(side ? r_bgr : l_bgr, N * 3, img);
+        psmo_cvf_preprocess(img, H, W, guide, guide + 3 * N, guide + 6 * N);
+        for (int d = 0; d < D; ++d) {
+            int slot = d % threads;
+            ftd[d] = (filterCV8_TD){guide, guide + 3 * N, guide + 6 * N, H, W, vol + (size_t)d * N,
+                                    ws + (size_t)slot * 10 * N, hs + (size_t)slot * N};
+            jobs[d] = (job){filterCV8_thread, &ftd[d]};
+        }
+        run_blocked(jobs, D, threads);
+    }
+    double t2 = now_ms();
+    psmo_wta_u8(lv, D, H, W, ldisp);
+    psmo_wta_u8(rv, D, H, W, rdisp);
+    double t3 = now_ms();
+    if (times) {
+        times->cvc_ms = t1 - t0;
+        times->cvf_ms = t2 - t1;
+        times->dispsel_ms = t3 - t2;
+    }
+    rc = 0;
+done:
+    free(gray); free(lG); free(rG);
+    if (!lvol) free(lv);
+    if (!rvol) free(rv);
+    free(img); free(guide); free(ws); free(hs); free(jobs); free(btd); free(ftd);
+    return rc;
+}
+
+/* ------------------------------------------------------------------------------- */
+/* left-right check + invalid fill ("next" row)                                     */
+/* ------------------------------------------------------------------------------- */
+
+void psmo_lr_check(const uint8_t *ldis, const uint8_t *rdis, int H, int W, uint8_t *lvalid,
+                   uint8_t *rvalid)
+{
+    /* src/PP.cpp:17-50 */
+    memset(lvalid, 0, (size_t)H * W);
+    memset(rvalid, 0, (size_t)H * W);
+    for (int y = 0; y < H; ++y) {
+        const uint8_t *l = ldis + (size_t)y * W, *r = rdis + (size_t)y * W;
+        uint8_t *lv = lvalid + (size_t)y * W, *rv = rvalid + (size_t)y * W;
+        for (int x = 0; x < W; ++x) {
+            int lDep = l[x];
+            int rLoc = (x - lDep + W) % W;
+            int rDep = r[rLoc];
+            if (lDep == rDep && lDep >= 2) lv[x] = 1;
+            rDep = r[x];
+            int lLoc = (x + rDep + W) % W;
+            lDep = l[lLoc];
+            if (rDep == lDep && rDep >= 2) rv[x] = 1;
+        }
+    }
+}
+
+void psmo_fill_inv(uint8_t *dis, const uint8_t *valid, int H, int W)
+{
+    /* src/PP.cpp:58-98 (left) / 100-141 (right): identical logic per map.  The scan reads
+     * dis[] values of *valid* pixels only, which the fill never modifies, so the in-place
+     * update is order independent. */
+    for (int y = 0; y < H; ++y) {
+        uint8_t *d = dis + (size_t)y * W;
+        const uint8_t *v = valid + (size_t)y * W;
+        for (int x = 0; x < W; ++x) {
+            if (v[x] != 0) continue;
+            int lFirst = x, lFind = 0;
+            while (lFirst >= 0) {
+                if (v[lFirst]) { lFind = 1; break; }
+                lFirst--;
+            }
+            int rFirst = x, rFind = 0;
+            while (rFirst < W) {
+                if (v[rFirst]) { rFind = 1; break; }
+                rFirst++;
+            }
+            if (lFind && rFind)
+                d[x] = (d[lFirst] <= d[rFirst]) ? d[lFirst] : d[rFirst];
+            else if (lFind)
+                d[x] = d[lFirst];
+            else if (rFind)
+                d[x] = d[rFirst];
+        }
+    }
+}
+
+/* ------------------------------------------------------------------------------- */
+/* harness evaluation (src/StereoMatch.cpp:248-249,275-311)                         */
+/* ------------------------------------------------------------------------------- */
+
+unsigned psmo_eval_bad_pixels(const uint8_t *disp, const uint8_t *gt, const uint8_t *mask, int H,
+                              int W, int maxDis, int scale_factor, int error_threshold,
+                              float *avg_err)
+{
+    const int unit = 127 / maxDis; /* CHAR_MAX/maxDis, integer division */
+    const int thresh = error_threshold * unit;
+    unsigned bad = 0;
+    double sum = 0.0;
+    for (int y = 0; y < H; ++y)
+        for (int x = 0; x < W; ++x) {
+            size_t i = (size_t)y * W + x;
+            int s = disp[i] * scale_factor; /* convertTo(CV_8U, scale_factor) */
+            if (s > 255) s = 255;
+            int e = abs(s - (int)gt[i]);       /* absdiff */
+            if (x <= maxDis) e = 0;            /* Rect(0,0,maxDis+1,rows) -> 0 */
+            if (e <= thresh) e = 0;            /* THRESH_TOZERO */
+            if (mask) e = mask[i] ? (mask[i] == 255 ? e : (int)lrint(e * (mask[i] / 255.0))) : 0;
+            if (e) ++bad;
+            sum += e;
+        }
+    if (avg_err) *avg_err = unit ? (float)(sum / ((double)H * W) / unit) : 0.0f;
+    return bad;
+}

@@ -1,0 +1,630 @@
+// psm_api.cpp - the C ABI of libprimesm_hip.so (include/primesm_hip.h): context, device memory,
+// stage sequencing, timing.  Takes the place of the reference's oclUtil + CVC_cl/CVF_cl/DispSel_cl
+// host wrappers (src/oclUtil.cpp, src/CVC_cl.cpp, src/CVF_cl.cpp, src/DispSel_cl.cpp).
+#include "../../include/primesm_hip.h"
+#include "psm_kernels.h"
+
+#include <chrono>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+using namespace psm;
+
+namespace {
+
+std::string g_create_error;
+
+struct KernelTimer {
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
+    double total_ms = 0.0;
+    int launches = 0;
+};
+
+double now_us()
+{
+    using namespace std::chrono;
+    return duration_cast<duration<double, std::micro>>(steady_clock::now().time_since_epoch()).count();
+}
+
+}  // namespace
+
+struct psm_ctx {
+    int W = 0, H = 0, D = 0, d0 = 0, d1 = 0, Dloc = 0, dtype = PSM_F32, device = 0;
+    hipStream_t own_stream = nullptr, stream = nullptr;
+
+    // device memory (DESIGN.md "HBM layout")
+    void *raw[2] = {nullptr, nullptr};  // staged copy of the interleaved host images
+    size_t raw_bytes = 0;
+    int raw_depth = -1;                 // PSM_IMG_* of the staged pair, -1 = nothing uploaded
+    Guidance g[2] = {};
+    double *hs9 = nullptr;
+    void *vol[2] = {nullptr, nullptr};  // [Dloc][H][W] float (PSM_F32) or uint8 (PSM_U8)
+    float *fvol = nullptr;              // PSM_U8 only: float work volume of one side
+    float4 *ab = nullptr;               // [Dloc][H][W] {a0,a1,a2,b}; also box8 output
+    long long *keys = nullptr;          // [2][H][W]
+    uint8_t *maps = nullptr;            // [2][H][W]
+    uint8_t *valid = nullptr;           // [2][H][W]
+    uint8_t *p4[2] = {nullptr, nullptr};  // PSM_U8 only: {c0,c1,c2,grad} words
+
+    bool have_images = false, have_cost = false, have_maps = false;
+
+    // options
+    int opt_async = 0, opt_variant = 0, opt_profile = 0;
+    March march = {0, 4};
+
+    double stage_us[PSM_STAGE_COUNT] = {0, 0, 0, 0};
+    KernelTimer timers[PSM_K_COUNT];
+    std::vector<hipEvent_t> event_pool;
+    std::string err;
+};
+
+namespace {
+
+int fail(psm_ctx *c, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (c) c->err = buf; else g_create_error = buf;
+    fprintf(stderr, "primesm_hip: %s\n", buf);  // the _cl wrappers print to stderr too (src/CVC_cl.cpp:185-210)
+    return 1;
+}
+
+#define PSM_HIP(c, call)                                                                         \
+    do {                                                                                         \
+        hipError_t e_ = (call);                                                                  \
+        if (e_ != hipSuccess) return fail((c), "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+size_t velem(const psm_ctx *c) { return c->dtype == PSM_U8 ? 1 : 4; }
+
+hipEvent_t get_event(psm_ctx *c)
+{
+    if (!c->event_pool.empty()) {
+        hipEvent_t e = c->event_pool.back();
+        c->event_pool.pop_back();
+        return e;
+    }
+    hipEvent_t e = nullptr;
+    (void)hipEventCreate(&e);
+    return e;
+}
+
+// RAII bracket of one kernel launch with hipEvents on the launch stream (PSM_OPT_PROFILE)
+struct Prof {
+    psm_ctx *c;
+    int k;
+    hipEvent_t a = nullptr, b = nullptr;
+    Prof(psm_ctx *c_, int k_) : c(c_), k(k_)
+    {
+        if (c->opt_profile) {
+            a = get_event(c);
+            b = get_event(c);
+            (void)hipEventRecord(a, c->stream);
+        }
+    }
+    ~Prof()
+    {
+        if (a) {
+            (void)hipEventRecord(b, c->stream);
+            c->timers[k].pending.emplace_back(a, b);
+        }
+    }
+};
+
+int check_launch(psm_ctx *c, const char *what)
+{
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(c, "launch of %s failed: %s", what, hipGetErrorString(e));
+    return 0;
+}
+
+int end_stage(psm_ctx *c, int stage, double t0)
+{
+    if (!c->opt_async) PSM_HIP(c, hipStreamSynchronize(c->stream));
+    c->stage_us[stage] = now_us() - t0;
+    return 0;
+}
+
+int bind(psm_ctx *c)
+{
+    PSM_HIP(c, hipSetDevice(c->device));
+    return 0;
+}
+
+void free_all(psm_ctx *c)
+{
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    for (int s = 0; s < 2; ++s) {
+        (void)hipFree(c->raw[s]);
+        (void)hipFree(c->g[s].g1);
+        (void)hipFree(c->g[s].g2);
+        (void)hipFree(c->g[s].g3);
+        (void)hipFree(c->g[s].g4);
+        (void)hipFree(c->vol[s]);
+        (void)hipFree(c->p4[s]);
+    }
+    (void)hipFree(c->hs9);
+    (void)hipFree(c->fvol);
+    (void)hipFree(c->ab);
+    (void)hipFree(c->keys);
+    (void)hipFree(c->maps);
+    (void)hipFree(c->valid);
+    for (auto &t : c->timers)
+        for (auto &p : t.pending) {
+            (void)hipEventDestroy(p.first);
+            (void)hipEventDestroy(p.second);
+        }
+    for (auto e : c->event_pool) (void)hipEventDestroy(e);
+    if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+}
+
+int flush_timers(psm_ctx *c)
+{
+    PSM_HIP(c, hipStreamSynchronize(c->stream));
+    for (auto &t : c->timers) {
+        for (auto &p : t.pending) {
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, p.first, p.second) == hipSuccess) {
+                t.total_ms += ms;
+                t.launches += 1;
+            }
+            c->event_pool.push_back(p.first);
+            c->event_pool.push_back(p.second);
+        }
+        t.pending.clear();
+    }
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int psm_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    return n;
+}
+
+int psm_create_shard(psm_ctx **out, int width, int height, int max_disp, int d_begin, int d_end, int dtype, int device)
+{
+    if (!out) return fail(nullptr, "psm_create: out is NULL");
+    *out = nullptr;
+    if (width < 8 || height < 8) return fail(nullptr, "psm_create: image %dx%d smaller than the 8x8 filter window", width, height);
+    if ((long long)width * height > 0x3fffffffLL) return fail(nullptr, "psm_create: image too large");
+    if (max_disp < 1 || max_disp > 256) return fail(nullptr, "psm_create: max_disp %d outside [1,256] (maps are 8-bit)", max_disp);
+    if (d_begin < 0 || d_end > max_disp || d_begin >= d_end) return fail(nullptr, "psm_create: bad slice range [%d,%d) of %d", d_begin, d_end, max_disp);
+    if (dtype != PSM_F32 && dtype != PSM_U8) return fail(nullptr, "psm_create: unknown dtype %d", dtype);
+    int ndev = psm_device_count();
+    if (ndev <= 0) return fail(nullptr, "psm_create: no HIP device available");
+    if (device < 0 || device >= ndev) return fail(nullptr, "psm_create: device %d not in [0,%d)", device, ndev);
+
+    psm_ctx *c = new psm_ctx();
+    c->W = width; c->H = height; c->D = max_disp; c->d0 = d_begin; c->d1 = d_end; c->Dloc = d_end - d_begin;
+    c->dtype = dtype; c->device = device;
+    const size_t HW = (size_t)width * height;
+    const size_t V = HW * (size_t)c->Dloc;
+    hipError_t e = hipSetDevice(device);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking);
+    c->stream = c->own_stream;
+    c->raw_bytes = HW * 3 * sizeof(float);
+    for (int s = 0; s < 2 && e == hipSuccess; ++s) {
+        e = hipMalloc(&c->raw[s], c->raw_bytes);
+        if (e == hipSuccess) e = hipMalloc((void **)&c->g[s].g1, HW * sizeof(float4));
+        if (e == hipSuccess) e = hipMalloc((void **)&c->g[s].g2, HW * sizeof(float4));
+        if (e == hipSuccess) e = hipMalloc((void **)&c->g[s].g3, HW * sizeof(float4));
+        if (e == hipSuccess) e = hipMalloc((void **)&c->g[s].g4, HW * sizeof(float2));
+        if (e == hipSuccess) e = hipMalloc(&c->vol[s], V * velem(c));
+        if (e == hipSuccess && dtype == PSM_U8) e = hipMalloc((void **)&c->p4[s], HW * 4);
+    }
+    if (e == hipSuccess) e = hipMalloc((void **)&c->hs9, 9 * HW * sizeof(double));
+    if (e == hipSuccess) e = hipMalloc((void **)&c->ab, V * sizeof(float4));
+    if (e == hipSuccess && dtype == PSM_U8) e = hipMalloc((void **)&c->fvol, V * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc((void **)&c->keys, 2 * HW * sizeof(long long));
+    if (e == hipSuccess) e = hipMalloc((void **)&c->maps, 2 * HW);
+    if (e == hipSuccess) e = hipMalloc((void **)&c->valid, 2 * HW);
+    if (e != hipSuccess) {
+        fail(nullptr, "psm_create: device setup failed: %s", hipGetErrorString(e));
+        free_all(c);
+        delete c;
+        return 1;
+    }
+    *out = c;
+    return 0;
+}
+
+int psm_create(psm_ctx **out, int width, int height, int max_disp, int dtype, int device)
+{
+    return psm_create_shard(out, width, height, max_disp, 0, max_disp, dtype, device);
+}
+
+void psm_destroy(psm_ctx *ctx)
+{
+    if (!ctx) return;
+    free_all(ctx);
+    delete ctx;
+}
+
+const char *psm_last_error(const psm_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+int psm_get_info(const psm_ctx *c, int *width, int *height, int *max_disp, int *d_begin, int *d_end, int *dtype, int *device)
+{
+    if (!c) return 1;
+    if (width) *width = c->W;
+    if (height) *height = c->H;
+    if (max_disp) *max_disp = c->D;
+    if (d_begin) *d_begin = c->d0;
+    if (d_end) *d_end = c->d1;
+    if (dtype) *dtype = c->dtype;
+    if (device) *device = c->device;
+    return 0;
+}
+
+int psm_set_option(psm_ctx *c, int option, int value)
+{
+    if (!c) return 1;
+    switch (option) {
+    case PSM_OPT_ASYNC: c->opt_async = value != 0; return 0;
+    case PSM_OPT_KERNEL_VARIANT:
+        if (value != 0 && value != 1) return fail(c, "psm_set_option: kernel variant %d unknown", value);
+        c->opt_variant = value; return 0;
+    case PSM_OPT_PROFILE: c->opt_profile = value != 0; return 0;
+    case PSM_OPT_SEG_ROWS:
+        if (value < 0) return fail(c, "psm_set_option: seg_rows %d < 0", value);
+        c->march.seg_rows = value; return 0;
+    case PSM_OPT_WAVES:
+        if (value != 1 && value != 2 && value != 4 && value != 8) return fail(c, "psm_set_option: waves %d not in {1,2,4,8}", value);
+        c->march.waves = value; return 0;
+    default: return fail(c, "psm_set_option: unknown option %d", option);
+    }
+}
+
+int psm_set_stream(psm_ctx *c, void *hip_stream)
+{
+    if (!c) return 1;
+    if (bind(c)) return 1;
+    PSM_HIP(c, hipStreamSynchronize(c->stream));
+    c->stream = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
+    return 0;
+}
+
+int psm_synchronize(psm_ctx *c)
+{
+    if (!c) return 1;
+    if (bind(c)) return 1;
+    PSM_HIP(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int psm_upload_pair(psm_ctx *c, const void *l, const void *r, int channels, size_t stride_bytes, int depth)
+{
+    if (!c) return 1;
+    if (!l || !r) return fail(c, "psm_upload_pair: NULL image");
+    if (channels != 3) return fail(c, "psm_upload_pair: %d channels (3 required, B,G,R interleaved)", channels);
+    if (depth != PSM_IMG_U8 && depth != PSM_IMG_F32) return fail(c, "psm_upload_pair: unknown depth %d", depth);
+    if (c->dtype == PSM_U8 && depth != PSM_IMG_U8) return fail(c, "psm_upload_pair: 8-bit mode needs 8-bit images");
+    const size_t row = (size_t)c->W * 3 * (depth == PSM_IMG_F32 ? 4 : 1);
+    if (stride_bytes == 0) stride_bytes = row;
+    if (stride_bytes < row) return fail(c, "psm_upload_pair: stride %zu < row size %zu", stride_bytes, row);
+    if (bind(c)) return 1;
+    const void *src[2] = {l, r};
+    for (int s = 0; s < 2; ++s)
+        PSM_HIP(c, hipMemcpy2DAsync(c->raw[s], row, src[s], stride_bytes, row, c->H, hipMemcpyHostToDevice, c->stream));
+    // the copy reads caller memory: always complete it before returning (CVC_cl::buildCV copies
+    // out of the cv::Mats synchronously, src/CVC_cl.cpp:113-160)
+    PSM_HIP(c, hipStreamSynchronize(c->stream));
+    c->raw_depth = depth;
+    c->have_images = true;
+    c->have_cost = false;
+    c->have_maps = false;
+    return 0;
+}
+
+int psm_cost_construct(psm_ctx *c)
+{
+    if (!c) return 1;
+    if (!c->have_images) return fail(c, "psm_cost_construct: no image pair uploaded");
+    if (bind(c)) return 1;
+    const double t0 = now_us();
+    const size_t row = (size_t)c->W * 3 * (c->raw_depth == PSM_IMG_F32 ? 4 : 1);
+    for (int s = 0; s < 2; ++s) {
+        Prof p(c, PSM_K_PREP);
+        launch_prep(c->stream, c->raw[s], row, c->raw_depth == PSM_IMG_F32, c->W, c->H, c->g[s].g1);
+        if (c->dtype == PSM_U8) launch_prep_u8(c->stream, (const uint8_t *)c->raw[s], row, c->W, c->H, c->p4[s]);
+    }
+    if (check_launch(c, "prep")) return 1;
+    for (int s = 0; s < 2; ++s) {
+        Prof p(c, PSM_K_CVC);
+        // buildCV_right is called with the images swapped (src/DispEst.cpp:217,260)
+        if (c->dtype == PSM_U8)
+            launch_cvc_u8(c->stream, c->p4[s], c->p4[1 - s], (uint8_t *)c->vol[s], c->W, c->H, c->d0, c->Dloc, s);
+        else
+            launch_cvc(c->stream, c->g[s].g1, c->g[1 - s].g1, (float *)c->vol[s], c->W, c->H, c->d0, c->Dloc, s);
+    }
+    if (check_launch(c, "cvc")) return 1;
+    c->have_cost = true;
+    c->have_maps = false;
+    return end_stage(c, PSM_STAGE_CVC, t0);
+}
+
+static int filter_side(psm_ctx *c, int side, bool stage_b)
+{
+    const size_t V = (size_t)c->W * c->H * c->Dloc;
+    {
+        Prof p(c, PSM_K_GUIDE);
+        launch_guidance(c->stream, c->g[side], c->hs9, c->W, c->H);
+    }
+    float *fv = (float *)c->vol[side];
+    if (c->dtype == PSM_U8) {
+        fv = c->fvol;
+        launch_u8_to_f32(c->stream, (const uint8_t *)c->vol[side], fv, V);
+    }
+    {
+        Prof p(c, PSM_K_CVF_A);
+        launch_cvf_a(c->stream, c->opt_variant, c->march, fv, c->ab, c->g[side], c->W, c->H, c->Dloc);
+    }
+    if (stage_b) {
+        {
+            Prof p(c, PSM_K_CVF_B);
+            launch_cvf_b(c->stream, c->opt_variant, c->march, c->ab, fv, c->g[side], c->W, c->H, c->Dloc);
+        }
+        if (c->dtype == PSM_U8) launch_f32_to_u8(c->stream, fv, (uint8_t *)c->vol[side], V);
+    }
+    return check_launch(c, "cvf");
+}
+
+int psm_cost_filter(psm_ctx *c)
+{
+    if (!c) return 1;
+    if (!c->have_cost) return fail(c, "psm_cost_filter: no cost volume (call psm_cost_construct or psm_upload_volume)");
+    if (!c->have_images) return fail(c, "psm_cost_filter: no image pair uploaded (guidance)");
+    if (bind(c)) return 1;
+    const double t0 = now_us();
+    // preprocess L, filter L, preprocess R, filter R (src/DispEst.cpp:302-305)
+    for (int s = 0; s < 2; ++s)
+        if (filter_side(c, s, true)) return 1;
+    c->have_maps = false;
+    return end_stage(c, PSM_STAGE_CVF, t0);
+}
+
+int psm_filter_stage_a(psm_ctx *c, int side)
+{
+    if (!c) return 1;
+    if (side != PSM_LEFT && side != PSM_RIGHT) return fail(c, "psm_filter_stage_a: bad side %d", side);
+    if (!c->have_cost || !c->have_images) return fail(c, "psm_filter_stage_a: needs images and a cost volume");
+    if (bind(c)) return 1;
+    if (c->raw_depth >= 0) {
+        // guidance needs g1; make sure it exists even if psm_cost_construct was skipped
+        const size_t row = (size_t)c->W * 3 * (c->raw_depth == PSM_IMG_F32 ? 4 : 1);
+        launch_prep(c->stream, c->raw[side], row, c->raw_depth == PSM_IMG_F32, c->W, c->H, c->g[side].g1);
+    }
+    if (filter_side(c, side, false)) return 1;
+    PSM_HIP(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+static int copy_maps_out(psm_ctx *c, const uint8_t *dev, uint8_t *lmap, uint8_t *rmap, size_t stride)
+{
+    const size_t HW = (size_t)c->W * c->H;
+    if (stride == 0) stride = c->W;
+    if (stride < (size_t)c->W) return fail(c, "map stride %zu < width %d", stride, c->W);
+    if (lmap) PSM_HIP(c, hipMemcpy2DAsync(lmap, stride, dev, c->W, c->W, c->H, hipMemcpyDeviceToHost, c->stream));
+    if (rmap) PSM_HIP(c, hipMemcpy2DAsync(rmap, stride, dev + HW, c->W, c->W, c->H, hipMemcpyDeviceToHost, c->stream));
+    if (lmap || rmap) PSM_HIP(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+static int wta_launch(psm_ctx *c, long long *keys, uint8_t *maps)
+{
+    const size_t HW = (size_t)c->W * c->H;
+    for (int s = 0; s < 2; ++s) {
+        Prof p(c, PSM_K_WTA);
+        if (c->dtype == PSM_U8)
+            launch_wta_u8(c->stream, (const uint8_t *)c->vol[s], c->W, c->H, c->d0, c->Dloc, keys ? keys + s * HW : nullptr,
+                          maps ? maps + s * HW : nullptr);
+        else
+            launch_wta(c->stream, (const float *)c->vol[s], c->W, c->H, c->d0, c->Dloc, keys ? keys + s * HW : nullptr,
+                       maps ? maps + s * HW : nullptr);
+    }
+    return check_launch(c, "wta");
+}
+
+int psm_disp_select(psm_ctx *c, uint8_t *lmap, uint8_t *rmap, size_t stride)
+{
+    if (!c) return 1;
+    if (c->Dloc != c->D) return fail(c, "psm_disp_select: context holds slices [%d,%d) of %d; use psm_disp_select_partial + psm_disp_merge", c->d0, c->d1, c->D);
+    if (!c->have_cost) return fail(c, "psm_disp_select: no cost volume");
+    if (bind(c)) return 1;
+    const double t0 = now_us();
+    if (wta_launch(c, nullptr, c->maps)) return 1;
+    c->have_maps = true;
+    if (copy_maps_out(c, c->maps, lmap, rmap, stride)) return 1;
+    return end_stage(c, PSM_STAGE_DISPSEL, t0);
+}
+
+int psm_disp_select_partial(psm_ctx *c, void *dev_keys)
+{
+    if (!c) return 1;
+    if (!c->have_cost) return fail(c, "psm_disp_select_partial: no cost volume");
+    if (bind(c)) return 1;
+    const double t0 = now_us();
+    if (wta_launch(c, dev_keys ? (long long *)dev_keys : c->keys, nullptr)) return 1;
+    return end_stage(c, PSM_STAGE_DISPSEL, t0);
+}
+
+int psm_partial_keys(psm_ctx *c, void **dev_keys, size_t *bytes)
+{
+    if (!c) return 1;
+    if (dev_keys) *dev_keys = c->keys;
+    if (bytes) *bytes = 2 * (size_t)c->W * c->H * sizeof(long long);
+    return 0;
+}
+
+int psm_disp_merge(psm_ctx *c, const void *dev_keys_all, int nranks, uint8_t *lmap, uint8_t *rmap, size_t stride)
+{
+    if (!c) return 1;
+    if (!dev_keys_all || nranks < 1) return fail(c, "psm_disp_merge: bad arguments");
+    if (bind(c)) return 1;
+    const double t0 = now_us();
+    const size_t n = 2 * (size_t)c->W * c->H;
+    {
+        Prof p(c, PSM_K_MERGE);
+        launch_merge(c->stream, (const long long *)dev_keys_all, n, nranks, (int)n, c->maps);
+    }
+    if (check_launch(c, "merge")) return 1;
+    c->have_maps = true;
+    if (copy_maps_out(c, c->maps, lmap, rmap, stride)) return 1;
+    if (!c->opt_async) PSM_HIP(c, hipStreamSynchronize(c->stream));
+    c->stage_us[PSM_STAGE_DISPSEL] += now_us() - t0;
+    return 0;
+}
+
+int psm_download_maps(psm_ctx *c, uint8_t *lmap, uint8_t *rmap, size_t stride)
+{
+    if (!c) return 1;
+    if (!c->have_maps) return fail(c, "psm_download_maps: no disparity maps computed");
+    if (bind(c)) return 1;
+    return copy_maps_out(c, c->maps, lmap, rmap, stride);
+}
+
+int psm_lr_check(psm_ctx *c, uint8_t *lvalid, uint8_t *rvalid, size_t stride)
+{
+    if (!c) return 1;
+    if (!c->have_maps) return fail(c, "psm_lr_check: no disparity maps computed");
+    if (bind(c)) return 1;
+    const double t0 = now_us();
+    const size_t HW = (size_t)c->W * c->H;
+    {
+        Prof p(c, PSM_K_LRC);
+        launch_lr_check(c->stream, c->maps, c->maps + HW, c->W, c->H, c->valid, c->valid + HW);
+    }
+    if (check_launch(c, "lr_check")) return 1;
+    if (copy_maps_out(c, c->valid, lvalid, rvalid, stride)) return 1;
+    return end_stage(c, PSM_STAGE_PP, t0);
+}
+
+static int check_slices(psm_ctx *c, const char *who, int side, int d0, int d1)
+{
+    if (side != PSM_LEFT && side != PSM_RIGHT) return fail(c, "%s: bad side %d", who, side);
+    if (d0 < c->d0 || d1 > c->d1 || d0 >= d1) return fail(c, "%s: slices [%d,%d) not inside this context's [%d,%d)", who, d0, d1, c->d0, c->d1);
+    return 0;
+}
+
+int psm_download_volume(psm_ctx *c, int side, int d0, int d1, void *host)
+{
+    if (!c || !host) return 1;
+    if (check_slices(c, "psm_download_volume", side, d0, d1)) return 1;
+    if (bind(c)) return 1;
+    const size_t S = (size_t)c->W * c->H * velem(c);
+    PSM_HIP(c, hipMemcpyAsync(host, (const char *)c->vol[side] + (size_t)(d0 - c->d0) * S, (size_t)(d1 - d0) * S, hipMemcpyDeviceToHost, c->stream));
+    PSM_HIP(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int psm_upload_volume(psm_ctx *c, int side, int d0, int d1, const void *host)
+{
+    if (!c || !host) return 1;
+    if (check_slices(c, "psm_upload_volume", side, d0, d1)) return 1;
+    if (bind(c)) return 1;
+    const size_t S = (size_t)c->W * c->H * velem(c);
+    PSM_HIP(c, hipMemcpyAsync((char *)c->vol[side] + (size_t)(d0 - c->d0) * S, host, (size_t)(d1 - d0) * S, hipMemcpyHostToDevice, c->stream));
+    PSM_HIP(c, hipStreamSynchronize(c->stream));
+    c->have_cost = true;
+    c->have_maps = false;
+    return 0;
+}
+
+int psm_download_ab(psm_ctx *c, int d0, int d1, float *host)
+{
+    if (!c || !host) return 1;
+    if (check_slices(c, "psm_download_ab", 0, d0, d1)) return 1;
+    if (bind(c)) return 1;
+    const size_t S = (size_t)c->W * c->H * sizeof(float4);
+    PSM_HIP(c, hipMemcpyAsync(host, (const char *)c->ab + (size_t)(d0 - c->d0) * S, (size_t)(d1 - d0) * S, hipMemcpyDeviceToHost, c->stream));
+    PSM_HIP(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int psm_download_guidance(psm_ctx *c, int side, float *host)
+{
+    if (!c || !host) return 1;
+    if (side != PSM_LEFT && side != PSM_RIGHT) return fail(c, "psm_download_guidance: bad side %d", side);
+    if (bind(c)) return 1;
+    const size_t HW = (size_t)c->W * c->H;
+    std::vector<float4> b1(HW), b2(HW), b3(HW);
+    std::vector<float2> b4(HW);
+    PSM_HIP(c, hipStreamSynchronize(c->stream));
+    PSM_HIP(c, hipMemcpy(b1.data(), c->g[side].g1, HW * sizeof(float4), hipMemcpyDeviceToHost));
+    PSM_HIP(c, hipMemcpy(b2.data(), c->g[side].g2, HW * sizeof(float4), hipMemcpyDeviceToHost));
+    PSM_HIP(c, hipMemcpy(b3.data(), c->g[side].g3, HW * sizeof(float4), hipMemcpyDeviceToHost));
+    PSM_HIP(c, hipMemcpy(b4.data(), c->g[side].g4, HW * sizeof(float2), hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < HW; ++i) {
+        host[0 * HW + i] = b1[i].x; host[1 * HW + i] = b1[i].y; host[2 * HW + i] = b1[i].z; host[3 * HW + i] = b1[i].w;
+        host[4 * HW + i] = b2[i].x; host[5 * HW + i] = b2[i].y; host[6 * HW + i] = b2[i].z; host[7 * HW + i] = b2[i].w;
+        host[8 * HW + i] = b3[i].x; host[9 * HW + i] = b3[i].y; host[10 * HW + i] = b3[i].z; host[11 * HW + i] = b3[i].w;
+        host[12 * HW + i] = b4[i].x; host[13 * HW + i] = b4[i].y;
+    }
+    return 0;
+}
+
+int psm_box8_volume(psm_ctx *c, int side, float *host)
+{
+    if (!c) return 1;
+    if (side != PSM_LEFT && side != PSM_RIGHT) return fail(c, "psm_box8_volume: bad side %d", side);
+    if (c->dtype != PSM_F32) return fail(c, "psm_box8_volume: float mode only");
+    if (!c->have_cost) return fail(c, "psm_box8_volume: no cost volume");
+    if (bind(c)) return 1;
+    {
+        Prof p(c, PSM_K_BOX);
+        launch_box8(c->stream, c->opt_variant, c->march, (const float *)c->vol[side], (float *)c->ab, c->W, c->H, c->Dloc);
+    }
+    if (check_launch(c, "box8")) return 1;
+    if (host) {
+        const size_t V = (size_t)c->W * c->H * c->Dloc;
+        PSM_HIP(c, hipMemcpyAsync(host, c->ab, V * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    }
+    if (host || !c->opt_async) PSM_HIP(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int psm_stage_time_us(psm_ctx *c, int stage, double *us)
+{
+    if (!c || !us || stage < 0 || stage >= PSM_STAGE_COUNT) return 1;
+    *us = c->stage_us[stage];
+    return 0;
+}
+
+int psm_kernel_time_ms(psm_ctx *c, int kernel, double *total_ms, int *launches)
+{
+    if (!c || kernel < 0 || kernel >= PSM_K_COUNT) return 1;
+    if (bind(c)) return 1;
+    if (flush_timers(c)) return 1;
+    if (total_ms) *total_ms = c->timers[kernel].total_ms;
+    if (launches) *launches = c->timers[kernel].launches;
+    return 0;
+}
+
+int psm_reset_kernel_times(psm_ctx *c)
+{
+    if (!c) return 1;
+    if (bind(c)) return 1;
+    if (flush_timers(c)) return 1;
+    for (auto &t : c->timers) {
+        t.total_ms = 0.0;
+        t.launches = 0;
+    }
+    return 0;
+}
+
+}  // extern "C"

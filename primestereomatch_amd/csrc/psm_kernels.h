@@ -1,0 +1,59 @@
+// psm_kernels.h - launcher interface between the C-ABI layer (psm_api.cpp) and the gfx950
+// kernels (psm_kernels.hip).  Internal to libprimesm_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace psm {
+
+// Per-pixel guidance of one side, packed for 16-byte lane loads (DESIGN.md "HBM layout").
+//   g1[y][x] = { I0, I1, I2, GrdX }            I_c = image channel c (c0=B), GrdX = x-gradient of gray
+//   g2[y][x] = { mI0, mI1, mI2, 1/DET }        mI_c = box(I_c)
+//   g3[y][x] = { A00, A01, A02, A11 }          A_rc = the distinct adjugate entries of Sigma+eps*I
+//   g4[y][x] = { A12, A22 }
+struct Guidance {
+    float4 *g1;
+    float4 *g2;
+    float4 *g3;
+    float2 *g4;
+};
+
+struct March {       // geometry of the marching kernels
+    int seg_rows;    // output rows per y-segment
+    int waves;       // waves (= disparity slices) per workgroup: 1,2,4,8
+};
+
+// image -> g1 (planarise, scale, gray, x-gradient).  src: device copy of the interleaved image.
+void launch_prep(hipStream_t s, const void *src, size_t pitch, int depth_f32, int W, int H, float4 *g1);
+// g1 -> g2,g3,g4.  hs9: scratch, 9*H*W doubles.
+void launch_guidance(hipStream_t s, Guidance g, double *hs9, int W, int H);
+// cost volume slices [d_begin, d_begin+Dloc) of one side.  base: g1 of the side's own image.
+void launch_cvc(hipStream_t s, const float4 *g1_base, const float4 *g1_other, float *vol, int W, int H,
+                int d_begin, int Dloc, int right);
+// guided filter halves.  variant 0 = marching, 1 = direct per-voxel.
+void launch_cvf_a(hipStream_t s, int variant, March m, const float *vol, float4 *ab, Guidance g, int W,
+                  int H, int Dloc);
+void launch_cvf_b(hipStream_t s, int variant, March m, const float4 *ab, float *vol, Guidance g, int W,
+                  int H, int Dloc);
+// plain 8x8 box filter of every slice (the north-star kernel in isolation)
+void launch_box8(hipStream_t s, int variant, March m, const float *vol, float *out, int W, int H, int Dloc);
+// WTA over local slices -> packed keys (keys != NULL) and/or final map (map != NULL)
+void launch_wta(hipStream_t s, const float *vol, int W, int H, int d_begin, int Dloc, long long *keys,
+                uint8_t *map);
+// min over nranks key planes -> map
+void launch_merge(hipStream_t s, const long long *keys_all, size_t rank_stride, int nranks, int n,
+                  uint8_t *map);
+// left-right check on two maps
+void launch_lr_check(hipStream_t s, const uint8_t *l, const uint8_t *r, int W, int H, uint8_t *lv,
+                     uint8_t *rv);
+
+// ---- 8-bit char mode ----
+void launch_prep_u8(hipStream_t s, const uint8_t *src, size_t pitch, int W, int H, uint8_t *planes4);
+void launch_cvc_u8(hipStream_t s, const uint8_t *base4, const uint8_t *other4, uint8_t *vol, int W, int H,
+                   int d_begin, int Dloc, int right);
+void launch_u8_to_f32(hipStream_t s, const uint8_t *src, float *dst, size_t n);
+void launch_f32_to_u8(hipStream_t s, const float *src, uint8_t *dst, size_t n);
+void launch_wta_u8(hipStream_t s, const uint8_t *vol, int W, int H, int d_begin, int Dloc, long long *keys,
+                   uint8_t *map);
+
+}  // namespace psm

@@ -1,0 +1,826 @@
+// psm_kernels.hip - hand-written gfx950 (CDNA4, wave64) kernels of the DispEst hot path.
+//
+// Arithmetic contract (order fixed in oracle/psm_oracle.h):
+//   * every fp32 expression is evaluated op-for-op (no FMA contraction: the file is built with
+//     -ffp-contract=off AND the expressions use __fmul_rn/__fadd_rn/__fsub_rn), IEEE division;
+//   * cv::boxFilter(Size(8,8)) = fp64 window sums, horizontal then vertical, each 8-tap sum
+//     evaluated as the balanced tree ((t0+t1)+(t2+t3))+((t4+t5)+(t6+t7)), x(1/64), round to fp32;
+//     taps at offsets -4..+3, BORDER_REFLECT_101.
+// Reference arithmetic followed: src/CVC.cpp:18-46,122-179, src/CVF.cpp:44-165,
+// src/DispSel.cpp:83-109, src/PP.cpp:17-50 (paths in the reference repository).
+//
+// Kernel design (DESIGN.md "Kernels"): the guided filter's two box-filter rounds are "marching"
+// kernels: one wave owns 64 adjacent columns of one disparity slice (57 outputs + 7 halo) and
+// walks down the rows.  Horizontal 8-tap sums are built with three cross-lane exchanges
+// (distance 1, 2, 4: a sliding balanced tree, 3 fp64 adds per output), vertical sums with a
+// register-resident sliding tree (7 doubles of state per channel, 3 fp64 adds per output).
+// Every voxel is loaded from HBM once per stage with coalesced row reads; the waves of a
+// workgroup process different slices of the same pixels so the d-invariant guidance is served
+// from L1/L2.  MFMA is not used: nothing here is a dense contraction.
+#include "psm_kernels.h"
+
+namespace psm {
+
+// ------------------------------------------------------------------------------------------
+// small device helpers
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ int r101(int k, int n)
+{
+    k = k < 0 ? -k : k;
+    k = k >= n ? 2 * (n - 1) - k : k;
+    return k;
+}
+__device__ __forceinline__ int r101c(int k, int n)
+{  // reflect, then clamp (only matters for the unused overshoot rows/lanes)
+    k = r101(k, n);
+    return k < 0 ? 0 : (k > n - 1 ? n - 1 : k);
+}
+
+__device__ __forceinline__ double t8(double t0, double t1, double t2, double t3, double t4, double t5,
+                                     double t6, double t7)
+{
+    return __dadd_rn(__dadd_rn(__dadd_rn(t0, t1), __dadd_rn(t2, t3)),
+                     __dadd_rn(__dadd_rn(t4, t5), __dadd_rn(t6, t7)));
+}
+__device__ __forceinline__ float box_out(double s) { return (float)(s * 0.015625); }
+
+// gray of CVC::preprocess: cvtColor(CV_RGB2GRAY) on B,G,R data -> 0.299 multiplies c0
+__device__ __forceinline__ float gray_of(float c0, float c1, float c2)
+{
+    return __fadd_rn(__fadd_rn(__fmul_rn(c0, 0.299f), __fmul_rn(c1, 0.587f)), __fmul_rn(c2, 0.114f));
+}
+
+// cross-lane gather: lane l receives the value of lane (byte_idx/4)
+__device__ __forceinline__ float lane_get(float v, int byte_idx)
+{
+    return __int_as_float(__builtin_amdgcn_ds_bpermute(byte_idx, __float_as_int(v)));
+}
+__device__ __forceinline__ double lane_get(double v, int byte_idx)
+{
+    int lo = __builtin_amdgcn_ds_bpermute(byte_idx, __double2loint(v));
+    int hi = __builtin_amdgcn_ds_bpermute(byte_idx, __double2hiint(v));
+    return __hiloint2double(hi, lo);
+}
+
+// Horizontal 8-tap window sum over lanes l..l+7 (sliding balanced tree).
+__device__ __forceinline__ double hsum8(float v, int i1, int i2, int i4)
+{
+    double s2 = __dadd_rn((double)v, (double)lane_get(v, i1));
+    double s4 = __dadd_rn(s2, lane_get(s2, i2));
+    return __dadd_rn(s4, lane_get(s4, i4));
+}
+
+// Vertical 8-tap sliding tree.  After feeding row yy, returns the window sum of rows yy-7..yy.
+struct VTree {
+    double hp;
+    double s2[2];
+    double s4[4];
+};
+template <int K>
+__device__ __forceinline__ double vstep(VTree &t, double hs)
+{
+    double n2 = __dadd_rn(t.hp, hs);         // hs[yy-1] + hs[yy]
+    double n4 = __dadd_rn(t.s2[K & 1], n2);  // s2[yy-3] + s2[yy-1]
+    double n8 = __dadd_rn(t.s4[K & 3], n4);  // s4[yy-7] + s4[yy-3]
+    t.s2[K & 1] = n2;
+    t.s4[K & 3] = n4;
+    t.hp = hs;
+    return n8;
+}
+
+// The per-voxel linear-model solve of GuidedFilter_cv (src/CVF.cpp:91-155) with the d-invariant
+// adjugate entries and 1/DET taken from the guidance planes.
+__device__ __forceinline__ float4 solve_ab(float mp, float mIp0, float mIp1, float mIp2, float4 g2,
+                                           float4 g3, float2 g4)
+{
+    const float mI0 = g2.x, mI1 = g2.y, mI2 = g2.z, inv = g2.w;
+    const float A00 = g3.x, A01 = g3.y, A02 = g3.z, A11 = g3.w, A12 = g4.x, A22 = g4.y;
+    float c0 = __fsub_rn(mIp0, __fmul_rn(mI0, mp));
+    float c1 = __fsub_rn(mIp1, __fmul_rn(mI1, mp));
+    float c2 = __fsub_rn(mIp2, __fmul_rn(mI2, mp));
+    float a0 = __fmul_rn(inv, __fadd_rn(__fadd_rn(__fmul_rn(c0, A00), __fmul_rn(c1, A01)), __fmul_rn(c2, A02)));
+    float a1 = __fmul_rn(inv, __fadd_rn(__fadd_rn(__fmul_rn(c0, A01), __fmul_rn(c1, A11)), __fmul_rn(c2, A12)));
+    float a2 = __fmul_rn(inv, __fadd_rn(__fadd_rn(__fmul_rn(c0, A02), __fmul_rn(c1, A12)), __fmul_rn(c2, A22)));
+    float b = __fsub_rn(__fsub_rn(__fsub_rn(mp, __fmul_rn(a0, mI0)), __fmul_rn(a1, mI1)), __fmul_rn(a2, mI2));
+    return make_float4(a0, a1, a2, b);
+}
+// q = ((box(b) + box(a0)*I0) + box(a1)*I1) + box(a2)*I2   (src/CVF.cpp:157-163)
+__device__ __forceinline__ float recombine(float ma0, float ma1, float ma2, float mb, float4 g1)
+{
+    return __fadd_rn(__fadd_rn(__fadd_rn(mb, __fmul_rn(ma0, g1.x)), __fmul_rn(ma1, g1.y)), __fmul_rn(ma2, g1.z));
+}
+
+// ------------------------------------------------------------------------------------------
+// image preparation: planarise + scale + gray + x-gradient  -> g1 = {I0,I1,I2,GrdX}
+// (src/StereoMatch.cpp:195-196 convertTo; src/CVC.cpp:41-46 CVC::preprocess)
+// ------------------------------------------------------------------------------------------
+template <bool F32>
+__device__ __forceinline__ void load_px(const void *src, size_t pitch, int y, int x, float &c0, float &c1, float &c2)
+{
+    if (F32) {
+        const float *p = (const float *)((const char *)src + (size_t)y * pitch) + 3 * x;
+        c0 = p[0]; c1 = p[1]; c2 = p[2];
+    } else {
+        const uint8_t *p = (const uint8_t *)src + (size_t)y * pitch + 3 * x;
+        const float alpha = 1 / 255.0f;
+        c0 = __fmul_rn((float)p[0], alpha);
+        c1 = __fmul_rn((float)p[1], alpha);
+        c2 = __fmul_rn((float)p[2], alpha);
+    }
+}
+
+template <bool F32>
+__global__ __launch_bounds__(256) void k_prep(const void *src, size_t pitch, int W, int H, float4 *g1)
+{
+    int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x >= W) return;
+    float c0, c1, c2, l0, l1, l2, r0, r1, r2;
+    load_px<F32>(src, pitch, y, x, c0, c1, c2);
+    load_px<F32>(src, pitch, y, r101(x - 1, W), l0, l1, l2);
+    load_px<F32>(src, pitch, y, r101(x + 1, W), r0, r1, r2);
+    float grd = __fsub_rn(gray_of(r0, r1, r2), gray_of(l0, l1, l2));
+    g1[(size_t)y * W + x] = make_float4(c0, c1, c2, grd);
+}
+
+void launch_prep(hipStream_t s, const void *src, size_t pitch, int depth_f32, int W, int H, float4 *g1)
+{
+    dim3 grid((W + 255) / 256, H);
+    if (depth_f32)
+        hipLaunchKernelGGL(k_prep<true>, grid, dim3(256), 0, s, src, pitch, W, H, g1);
+    else
+        hipLaunchKernelGGL(k_prep<false>, grid, dim3(256), 0, s, src, pitch, W, H, g1);
+}
+
+// ------------------------------------------------------------------------------------------
+// guidance precompute (CVF::preprocess, src/CVF.cpp:44-70, + the d-invariant part of the solve,
+// src/CVF.cpp:120-132).  Two passes over 9 channels: I0,I1,I2,I0I0,I0I1,I0I2,I1I1,I1I2,I2I2.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_guide_h(const float4 *g1, int W, int H, double *hs9)
+{
+    int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x >= W) return;
+    double t[9][8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        float4 g = g1[(size_t)y * W + r101(x - 4 + i, W)];
+        t[0][i] = g.x;
+        t[1][i] = g.y;
+        t[2][i] = g.z;
+        t[3][i] = __fmul_rn(g.x, g.x);
+        t[4][i] = __fmul_rn(g.x, g.y);
+        t[5][i] = __fmul_rn(g.x, g.z);
+        t[6][i] = __fmul_rn(g.y, g.y);
+        t[7][i] = __fmul_rn(g.y, g.z);
+        t[8][i] = __fmul_rn(g.z, g.z);
+    }
+    const size_t HW = (size_t)H * W;
+#pragma unroll
+    for (int c = 0; c < 9; ++c)
+        hs9[c * HW + (size_t)y * W + x] = t8(t[c][0], t[c][1], t[c][2], t[c][3], t[c][4], t[c][5], t[c][6], t[c][7]);
+}
+
+__global__ __launch_bounds__(256) void k_guide_v(const double *hs9, int W, int H, float4 *g2, float4 *g3, float2 *g4)
+{
+    int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x >= W) return;
+    const size_t HW = (size_t)H * W;
+    int ry[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) ry[j] = r101(y - 4 + j, H);
+    float m[9];
+#pragma unroll
+    for (int c = 0; c < 9; ++c) {
+        const double *h = hs9 + c * HW + x;
+        m[c] = box_out(t8(h[(size_t)ry[0] * W], h[(size_t)ry[1] * W], h[(size_t)ry[2] * W], h[(size_t)ry[3] * W],
+                          h[(size_t)ry[4] * W], h[(size_t)ry[5] * W], h[(size_t)ry[6] * W], h[(size_t)ry[7] * W]));
+    }
+    // var_k = box(I_c*I_c') - mean_c*mean_c'   (src/CVF.cpp:58-68)
+    const float eps = 0.0001f;  // GIF_EPS, include/ComFunc.h:50
+    float v0 = __fsub_rn(m[3], __fmul_rn(m[0], m[0]));
+    float v1 = __fsub_rn(m[4], __fmul_rn(m[0], m[1]));
+    float v2 = __fsub_rn(m[5], __fmul_rn(m[0], m[2]));
+    float v3 = __fsub_rn(m[6], __fmul_rn(m[1], m[1]));
+    float v4 = __fsub_rn(m[7], __fmul_rn(m[1], m[2]));
+    float v5 = __fsub_rn(m[8], __fmul_rn(m[2], m[2]));
+    // src/CVF.cpp:120-128
+    float a11 = __fadd_rn(v0, eps), a12 = v1, a13 = v2;
+    float a21 = v1, a22 = __fadd_rn(v3, eps), a23 = v4;
+    float a31 = v2, a32 = v4, a33 = __fadd_rn(v5, eps);
+    // src/CVF.cpp:129-132
+    float X = __fsub_rn(__fmul_rn(a33, a22), __fmul_rn(a32, a23));
+    float Y = __fsub_rn(__fmul_rn(a33, a12), __fmul_rn(a32, a13));
+    float Z = __fsub_rn(__fmul_rn(a23, a12), __fmul_rn(a22, a13));
+    float det = __fadd_rn(__fsub_rn(__fmul_rn(a11, X), __fmul_rn(a21, Y)), __fmul_rn(a31, Z));
+    float inv = __fdiv_rn(1.0f, det);
+    // adjugate entries as written at src/CVF.cpp:133-147 (the matrix is symmetric, so the
+    // nine expressions take six distinct values bit for bit)
+    float A00 = __fsub_rn(__fmul_rn(a33, a22), __fmul_rn(a32, a23));
+    float A01 = __fsub_rn(__fmul_rn(a31, a23), __fmul_rn(a33, a21));
+    float A02 = __fsub_rn(__fmul_rn(a32, a21), __fmul_rn(a31, a22));
+    float A11 = __fsub_rn(__fmul_rn(a33, a11), __fmul_rn(a31, a13));
+    float A12 = __fsub_rn(__fmul_rn(a31, a12), __fmul_rn(a32, a11));
+    float A22 = __fsub_rn(__fmul_rn(a22, a11), __fmul_rn(a21, a12));
+    size_t o = (size_t)y * W + x;
+    g2[o] = make_float4(m[0], m[1], m[2], inv);
+    g3[o] = make_float4(A00, A01, A02, A11);
+    g4[o] = make_float2(A12, A22);
+}
+
+void launch_guidance(hipStream_t s, Guidance g, double *hs9, int W, int H)
+{
+    dim3 grid((W + 255) / 256, H);
+    hipLaunchKernelGGL(k_guide_h, grid, dim3(256), 0, s, (const float4 *)g.g1, W, H, hs9);
+    hipLaunchKernelGGL(k_guide_v, grid, dim3(256), 0, s, (const double *)hs9, W, H, g.g2, g.g3, g.g4);
+}
+
+// ------------------------------------------------------------------------------------------
+// CVC: cost volume construction (src/CVC.cpp:18-39,122-179).  One thread = one pixel, DC
+// consecutive disparities; lanes run along x so every store is a coalesced row segment and the
+// partner-image reads of neighbouring lanes / iterations overlap in L1.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ float cost_pair(float4 a, float4 b)
+{  // myCostGrd(lC, rC, lG, rG), src/CVC.cpp:18-27
+    float clr = __fadd_rn(__fadd_rn(fabsf(__fsub_rn(a.x, b.x)), fabsf(__fsub_rn(a.y, b.y))), fabsf(__fsub_rn(a.z, b.z)));
+    float grd = fabsf(__fsub_rn(a.w, b.w));
+    return __fadd_rn(__fmul_rn(0.9f, clr), __fmul_rn(__fsub_rn(1.0f, 0.9f), grd));
+}
+__device__ __forceinline__ float cost_border(float4 a)
+{  // myCostGrd(lC, lG), src/CVC.cpp:30-39: BC_32F is the double 1.0 -> double differences/sum
+    double s = __dadd_rn(__dadd_rn(fabs(__dsub_rn((double)a.x, 1.0)), fabs(__dsub_rn((double)a.y, 1.0))),
+                         fabs(__dsub_rn((double)a.z, 1.0)));
+    float clr = (float)s;
+    float grd = (float)fabs(__dsub_rn((double)a.w, 1.0));
+    return __fadd_rn(__fmul_rn(0.9f, clr), __fmul_rn(__fsub_rn(1.0f, 0.9f), grd));
+}
+
+constexpr int CVC_DC = 8;
+template <bool RIGHT>
+__global__ __launch_bounds__(256) void k_cvc(const float4 *__restrict__ base, const float4 *__restrict__ other,
+                                            float *__restrict__ vol, int W, int H, int d_begin, int Dloc)
+{
+    int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    int dl0 = blockIdx.z * CVC_DC;
+    if (x >= W) return;
+    const size_t HW = (size_t)H * W;
+    const size_t row = (size_t)y * W;
+    float4 a = base[row + x];
+    float cb = cost_border(a);
+#pragma unroll
+    for (int k = 0; k < CVC_DC; ++k) {
+        int dl = dl0 + k;
+        if (dl >= Dloc) break;
+        int d = d_begin + dl;
+        float c;
+        if (RIGHT) {  // buildCV_right: partner x+d while x < W-d
+            if (x < W - d) c = cost_pair(a, other[row + x + d]); else c = cb;
+        } else {      // buildCV_left: partner x-d while x >= d
+            if (x >= d) c = cost_pair(a, other[row + x - d]); else c = cb;
+        }
+        vol[(size_t)dl * HW + row + x] = c;
+    }
+}
+
+void launch_cvc(hipStream_t s, const float4 *g1_base, const float4 *g1_other, float *vol, int W, int H,
+                int d_begin, int Dloc, int right)
+{
+    dim3 grid((W + 255) / 256, H, (Dloc + CVC_DC - 1) / CVC_DC);
+    if (right)
+        hipLaunchKernelGGL(k_cvc<true>, grid, dim3(256), 0, s, g1_base, g1_other, vol, W, H, d_begin, Dloc);
+    else
+        hipLaunchKernelGGL(k_cvc<false>, grid, dim3(256), 0, s, g1_base, g1_other, vol, W, H, d_begin, Dloc);
+}
+
+// ------------------------------------------------------------------------------------------
+// marching kernels
+// ------------------------------------------------------------------------------------------
+constexpr int OUT_PER_WAVE = 57;  // 64 lanes - 7 halo columns
+
+struct MarchPos {
+    int d, lane, cs, xo, y0, y1;
+    bool ok, ovalid;
+};
+
+// Block -> (column strip, y segment, slice group).  Blocks are observed to be dispatched
+// round-robin over the 8 XCDs (block b -> XCD b%8); every XCD gets a contiguous range of
+// (strip,segment) pairs and walks the slice groups of one pair back to back, so the pair's
+// guidance stays in that XCD's L2 while all D slices stream past it.  Speed only - nothing
+// depends on the placement.
+template <int NW>
+__device__ __forceinline__ MarchPos march_pos(int W, int H, int Dloc, int nstrips, int nsegs, int seg_rows, int nzg)
+{
+    MarchPos p;
+    const int npairs = nstrips * nsegs;
+    const int p8 = (npairs + 7) >> 3;
+    int id = blockIdx.x;
+    int xcd = id & 7, j = id >> 3;
+    int zg = j % nzg, pl = j / nzg;
+    int pair = xcd * p8 + pl;
+    int wave = threadIdx.x >> 6;
+    p.lane = threadIdx.x & 63;
+    p.d = zg * NW + wave;
+    p.ok = pl < p8 && pair < npairs && p.d < Dloc;
+    int strip = pair % nstrips, seg = pair / nstrips;
+    int x0 = strip * OUT_PER_WAVE;
+    p.cs = r101c(x0 - 4 + p.lane, W);
+    p.xo = x0 + p.lane;
+    p.ovalid = p.lane < OUT_PER_WAVE && p.xo < W;
+    p.y0 = seg * seg_rows;
+    p.y1 = min(H, p.y0 + seg_rows);
+    return p;
+}
+
+#define PSM_LANE_IDX()                             \
+    const int i1 = ((pos.lane + 1) & 63) << 2;     \
+    const int i2 = ((pos.lane + 2) & 63) << 2;     \
+    const int i4 = ((pos.lane + 4) & 63) << 2
+
+// ---- stage A: p -> (a0,a1,a2,b) -------------------------------------------------------------
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void k_cvf_a(const float *__restrict__ vol, float4 *__restrict__ ab,
+                                                  const float4 *__restrict__ G1, const float4 *__restrict__ G2,
+                                                  const float4 *__restrict__ G3, const float2 *__restrict__ G4,
+                                                  int W, int H, int Dloc, int nstrips, int nsegs, int seg_rows, int nzg)
+{
+    const MarchPos pos = march_pos<NW>(W, H, Dloc, nstrips, nsegs, seg_rows, nzg);
+    if (!pos.ok) return;
+    PSM_LANE_IDX();
+    const size_t HW = (size_t)H * W;
+    const float *vd = vol + (size_t)pos.d * HW;
+    float4 *abd = ab + (size_t)pos.d * HW;
+    VTree t0 = {}, t1 = {}, t2 = {}, t3 = {};
+    const int n = (pos.y1 - pos.y0) + 7;
+    const int ybase = pos.y0 - 4;
+
+    float pv[4];
+    float4 gv[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        size_t off = (size_t)r101c(ybase + k, H) * W + pos.cs;
+        pv[k] = vd[off];
+        gv[k] = G1[off];
+    }
+    for (int i = 0; i < n; i += 4) {
+        float pc[4];
+        float4 gc[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { pc[k] = pv[k]; gc[k] = gv[k]; }
+        if (i + 4 < n) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                size_t off = (size_t)r101c(ybase + i + 4 + k, H) * W + pos.cs;
+                pv[k] = vd[off];
+                gv[k] = G1[off];
+            }
+        }
+#define PSM_STEP_A(K)                                                                               \
+    {                                                                                               \
+        const float p = pc[K];                                                                      \
+        double h0 = hsum8(p, i1, i2, i4);                                                           \
+        double h1 = hsum8(__fmul_rn(gc[K].x, p), i1, i2, i4);                                       \
+        double h2 = hsum8(__fmul_rn(gc[K].y, p), i1, i2, i4);                                       \
+        double h3 = hsum8(__fmul_rn(gc[K].z, p), i1, i2, i4);                                       \
+        double n0 = vstep<K>(t0, h0), n1 = vstep<K>(t1, h1), n2 = vstep<K>(t2, h2), n3 = vstep<K>(t3, h3); \
+        const int step = i + K;                                                                     \
+        if (step >= 7 && step < n && pos.ovalid) {                                                  \
+            const size_t oo = (size_t)(ybase + step - 3) * W + pos.xo;                              \
+            float4 r = solve_ab(box_out(n0), box_out(n1), box_out(n2), box_out(n3), G2[oo], G3[oo], G4[oo]); \
+            abd[oo] = r;                                                                            \
+        }                                                                                           \
+    }
+        PSM_STEP_A(0) PSM_STEP_A(1) PSM_STEP_A(2) PSM_STEP_A(3)
+#undef PSM_STEP_A
+    }
+}
+
+// ---- stage B: (a0,a1,a2,b) -> q -------------------------------------------------------------
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void k_cvf_b(const float4 *__restrict__ ab, float *__restrict__ vol,
+                                                  const float4 *__restrict__ G1, int W, int H, int Dloc,
+                                                  int nstrips, int nsegs, int seg_rows, int nzg)
+{
+    const MarchPos pos = march_pos<NW>(W, H, Dloc, nstrips, nsegs, seg_rows, nzg);
+    if (!pos.ok) return;
+    PSM_LANE_IDX();
+    const size_t HW = (size_t)H * W;
+    const float4 *abd = ab + (size_t)pos.d * HW;
+    float *vd = vol + (size_t)pos.d * HW;
+    VTree t0 = {}, t1 = {}, t2 = {}, t3 = {};
+    const int n = (pos.y1 - pos.y0) + 7;
+    const int ybase = pos.y0 - 4;
+
+    float4 av[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) av[k] = abd[(size_t)r101c(ybase + k, H) * W + pos.cs];
+    for (int i = 0; i < n; i += 4) {
+        float4 ac[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) ac[k] = av[k];
+        if (i + 4 < n) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) av[k] = abd[(size_t)r101c(ybase + i + 4 + k, H) * W + pos.cs];
+        }
+#define PSM_STEP_B(K)                                                                               \
+    {                                                                                               \
+        double h0 = hsum8(ac[K].x, i1, i2, i4);                                                     \
+        double h1 = hsum8(ac[K].y, i1, i2, i4);                                                     \
+        double h2 = hsum8(ac[K].z, i1, i2, i4);                                                     \
+        double h3 = hsum8(ac[K].w, i1, i2, i4);                                                     \
+        double n0 = vstep<K>(t0, h0), n1 = vstep<K>(t1, h1), n2 = vstep<K>(t2, h2), n3 = vstep<K>(t3, h3); \
+        const int step = i + K;                                                                     \
+        if (step >= 7 && step < n && pos.ovalid) {                                                  \
+            const size_t oo = (size_t)(ybase + step - 3) * W + pos.xo;                              \
+            vd[oo] = recombine(box_out(n0), box_out(n1), box_out(n2), box_out(n3), G1[oo]);         \
+        }                                                                                           \
+    }
+        PSM_STEP_B(0) PSM_STEP_B(1) PSM_STEP_B(2) PSM_STEP_B(3)
+#undef PSM_STEP_B
+    }
+}
+
+// ---- plain box filter of every slice ----------------------------------------------------------
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void k_box8(const float *__restrict__ vol, float *__restrict__ out, int W,
+                                                 int H, int Dloc, int nstrips, int nsegs, int seg_rows, int nzg)
+{
+    const MarchPos pos = march_pos<NW>(W, H, Dloc, nstrips, nsegs, seg_rows, nzg);
+    if (!pos.ok) return;
+    PSM_LANE_IDX();
+    const size_t HW = (size_t)H * W;
+    const float *vd = vol + (size_t)pos.d * HW;
+    float *od = out + (size_t)pos.d * HW;
+    VTree t0 = {};
+    const int n = (pos.y1 - pos.y0) + 7;
+    const int ybase = pos.y0 - 4;
+    float pv[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) pv[k] = vd[(size_t)r101c(ybase + k, H) * W + pos.cs];
+    for (int i = 0; i < n; i += 8) {
+        float pc[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) pc[k] = pv[k];
+        if (i + 8 < n) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) pv[k] = vd[(size_t)r101c(ybase + i + 8 + k, H) * W + pos.cs];
+        }
+#define PSM_STEP_X(K)                                                      \
+    {                                                                      \
+        double n0 = vstep<K>(t0, hsum8(pc[K], i1, i2, i4));                \
+        const int step = i + K;                                            \
+        if (step >= 7 && step < n && pos.ovalid)                           \
+            od[(size_t)(ybase + step - 3) * W + pos.xo] = box_out(n0);     \
+    }
+        PSM_STEP_X(0) PSM_STEP_X(1) PSM_STEP_X(2) PSM_STEP_X(3) PSM_STEP_X(4) PSM_STEP_X(5) PSM_STEP_X(6) PSM_STEP_X(7)
+#undef PSM_STEP_X
+    }
+}
+
+// ---- direct (per-voxel) variants: an independent formulation of the same arithmetic, used to
+// cross-check the marching kernels (PSM_OPT_KERNEL_VARIANT=1).  64 taps per channel per voxel.
+__global__ __launch_bounds__(256) void k_cvf_a_direct(const float *__restrict__ vol, float4 *__restrict__ ab,
+                                                     const float4 *__restrict__ G1, const float4 *__restrict__ G2,
+                                                     const float4 *__restrict__ G3, const float2 *__restrict__ G4,
+                                                     int W, int H)
+{
+    int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y, d = blockIdx.z;
+    if (x >= W) return;
+    const size_t HW = (size_t)H * W;
+    const float *vd = vol + (size_t)d * HW;
+    int rx[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) rx[i] = r101(x - 4 + i, W);
+    double hs[4][8];
+    for (int j = 0; j < 8; ++j) {
+        size_t row = (size_t)r101(y - 4 + j, H) * W;
+        double t[4][8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            float p = vd[row + rx[i]];
+            float4 g = G1[row + rx[i]];
+            t[0][i] = p;
+            t[1][i] = __fmul_rn(g.x, p);
+            t[2][i] = __fmul_rn(g.y, p);
+            t[3][i] = __fmul_rn(g.z, p);
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+            hs[c][j] = t8(t[c][0], t[c][1], t[c][2], t[c][3], t[c][4], t[c][5], t[c][6], t[c][7]);
+    }
+    float m[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+        m[c] = box_out(t8(hs[c][0], hs[c][1], hs[c][2], hs[c][3], hs[c][4], hs[c][5], hs[c][6], hs[c][7]));
+    size_t oo = (size_t)y * W + x;
+    ab[(size_t)d * HW + oo] = solve_ab(m[0], m[1], m[2], m[3], G2[oo], G3[oo], G4[oo]);
+}
+
+__global__ __launch_bounds__(256) void k_cvf_b_direct(const float4 *__restrict__ ab, float *__restrict__ vol,
+                                                     const float4 *__restrict__ G1, int W, int H)
+{
+    int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y, d = blockIdx.z;
+    if (x >= W) return;
+    const size_t HW = (size_t)H * W;
+    const float4 *abd = ab + (size_t)d * HW;
+    int rx[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) rx[i] = r101(x - 4 + i, W);
+    double hs[4][8];
+    for (int j = 0; j < 8; ++j) {
+        size_t row = (size_t)r101(y - 4 + j, H) * W;
+        double t[4][8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            float4 a = abd[row + rx[i]];
+            t[0][i] = a.x; t[1][i] = a.y; t[2][i] = a.z; t[3][i] = a.w;
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+            hs[c][j] = t8(t[c][0], t[c][1], t[c][2], t[c][3], t[c][4], t[c][5], t[c][6], t[c][7]);
+    }
+    float m[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+        m[c] = box_out(t8(hs[c][0], hs[c][1], hs[c][2], hs[c][3], hs[c][4], hs[c][5], hs[c][6], hs[c][7]));
+    size_t oo = (size_t)y * W + x;
+    vol[(size_t)d * HW + oo] = recombine(m[0], m[1], m[2], m[3], G1[oo]);
+}
+
+__global__ __launch_bounds__(256) void k_box8_direct(const float *__restrict__ vol, float *__restrict__ out, int W, int H)
+{
+    int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y, d = blockIdx.z;
+    if (x >= W) return;
+    const size_t HW = (size_t)H * W;
+    const float *vd = vol + (size_t)d * HW;
+    double hs[8];
+    for (int j = 0; j < 8; ++j) {
+        size_t row = (size_t)r101(y - 4 + j, H) * W;
+        double t[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) t[i] = vd[row + r101(x - 4 + i, W)];
+        hs[j] = t8(t[0], t[1], t[2], t[3], t[4], t[5], t[6], t[7]);
+    }
+    out[(size_t)d * HW + (size_t)y * W + x] = box_out(t8(hs[0], hs[1], hs[2], hs[3], hs[4], hs[5], hs[6], hs[7]));
+}
+
+struct MarchGrid {
+    int nstrips, nsegs, seg_rows, nzg, nblocks;
+};
+static MarchGrid march_grid(March m, int W, int H, int Dloc)
+{
+    MarchGrid g;
+    g.nstrips = (W + OUT_PER_WAVE - 1) / OUT_PER_WAVE;
+    g.seg_rows = m.seg_rows > 0 ? m.seg_rows : H;
+    if (g.seg_rows > H) g.seg_rows = H;
+    g.nsegs = (H + g.seg_rows - 1) / g.seg_rows;
+    g.nzg = (Dloc + m.waves - 1) / m.waves;
+    int npairs = g.nstrips * g.nsegs;
+    g.nblocks = 8 * ((npairs + 7) / 8) * g.nzg;
+    return g;
+}
+
+#define PSM_DISPATCH_NW(NWV, KERNEL, ...)                                                               \
+    switch (NWV) {                                                                                      \
+    case 1: hipLaunchKernelGGL(KERNEL<1>, dim3(g.nblocks), dim3(64), 0, s, __VA_ARGS__); break;         \
+    case 2: hipLaunchKernelGGL(KERNEL<2>, dim3(g.nblocks), dim3(128), 0, s, __VA_ARGS__); break;        \
+    case 8: hipLaunchKernelGGL(KERNEL<8>, dim3(g.nblocks), dim3(512), 0, s, __VA_ARGS__); break;        \
+    default: hipLaunchKernelGGL(KERNEL<4>, dim3(g.nblocks), dim3(256), 0, s, __VA_ARGS__); break;       \
+    }
+
+static int norm_waves(int w) { return (w == 1 || w == 2 || w == 8) ? w : 4; }
+
+void launch_cvf_a(hipStream_t s, int variant, March m, const float *vol, float4 *ab, Guidance gd, int W, int H, int Dloc)
+{
+    if (variant == 1) {
+        dim3 grid((W + 255) / 256, H, Dloc);
+        hipLaunchKernelGGL(k_cvf_a_direct, grid, dim3(256), 0, s, vol, ab, (const float4 *)gd.g1, (const float4 *)gd.g2,
+                           (const float4 *)gd.g3, (const float2 *)gd.g4, W, H);
+        return;
+    }
+    m.waves = norm_waves(m.waves);
+    MarchGrid g = march_grid(m, W, H, Dloc);
+    PSM_DISPATCH_NW(m.waves, k_cvf_a, vol, ab, (const float4 *)gd.g1, (const float4 *)gd.g2, (const float4 *)gd.g3,
+                    (const float2 *)gd.g4, W, H, Dloc, g.nstrips, g.nsegs, g.seg_rows, g.nzg)
+}
+
+void launch_cvf_b(hipStream_t s, int variant, March m, const float4 *ab, float *vol, Guidance gd, int W, int H, int Dloc)
+{
+    if (variant == 1) {
+        dim3 grid((W + 255) / 256, H, Dloc);
+        hipLaunchKernelGGL(k_cvf_b_direct, grid, dim3(256), 0, s, ab, vol, (const float4 *)gd.g1, W, H);
+        return;
+    }
+    m.waves = norm_waves(m.waves);
+    MarchGrid g = march_grid(m, W, H, Dloc);
+    PSM_DISPATCH_NW(m.waves, k_cvf_b, ab, vol, (const float4 *)gd.g1, W, H, Dloc, g.nstrips, g.nsegs, g.seg_rows, g.nzg)
+}
+
+void launch_box8(hipStream_t s, int variant, March m, const float *vol, float *out, int W, int H, int Dloc)
+{
+    if (variant == 1) {
+        dim3 grid((W + 255) / 256, H, Dloc);
+        hipLaunchKernelGGL(k_box8_direct, grid, dim3(256), 0, s, vol, out, W, H);
+        return;
+    }
+    m.waves = norm_waves(m.waves);
+    MarchGrid g = march_grid(m, W, H, Dloc);
+    PSM_DISPATCH_NW(m.waves, k_box8, vol, out, W, H, Dloc, g.nstrips, g.nsegs, g.seg_rows, g.nzg)
+}
+
+// ------------------------------------------------------------------------------------------
+// DispSel: WTA (src/DispSel.cpp:83-109) over the local slices, with global semantics
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ long long pack_key_f32(float cost, int d)
+{
+    cost = __fadd_rn(cost, 0.0f);  // -0 -> +0 so that equal costs compare equal
+    unsigned u = __float_as_uint(cost);
+    u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);  // monotone map float -> uint
+    unsigned long long k = ((unsigned long long)u << 32) | (unsigned)d;
+    return (long long)(k ^ 0x8000000000000000ull);   // signed-comparable
+}
+
+__global__ __launch_bounds__(256) void k_wta(const float *__restrict__ vol, int HW, int d_begin, int Dloc,
+                                            long long *__restrict__ keys, uint8_t *__restrict__ map)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= HW) return;
+    float minCost = __builtin_inff();
+    int minDis = 0;
+    int dl = (d_begin == 0) ? 1 : 0;  // d = 0 is never a candidate (src/DispSel.cpp:96)
+    const float *p = vol + (size_t)dl * HW + i;
+#pragma unroll 8
+    for (; dl < Dloc; ++dl, p += HW) {
+        float c = *p;
+        if (c < minCost) {
+            minCost = c;
+            minDis = d_begin + dl;
+        }
+    }
+    if (keys) keys[i] = pack_key_f32(minCost, minDis);
+    if (map) map[i] = (uint8_t)minDis;
+}
+
+void launch_wta(hipStream_t s, const float *vol, int W, int H, int d_begin, int Dloc, long long *keys, uint8_t *map)
+{
+    int HW = W * H;
+    hipLaunchKernelGGL(k_wta, dim3((HW + 255) / 256), dim3(256), 0, s, vol, HW, d_begin, Dloc, keys, map);
+}
+
+__global__ __launch_bounds__(256) void k_merge(const long long *__restrict__ keys_all, size_t rank_stride, int nranks,
+                                              int n, uint8_t *__restrict__ map)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    long long best = keys_all[i];
+    for (int r = 1; r < nranks; ++r) {
+        long long k = keys_all[(size_t)r * rank_stride + i];
+        best = k < best ? k : best;
+    }
+    map[i] = (uint8_t)((unsigned long long)best & 0xffffffffull);
+}
+
+void launch_merge(hipStream_t s, const long long *keys_all, size_t rank_stride, int nranks, int n, uint8_t *map)
+{
+    hipLaunchKernelGGL(k_merge, dim3((n + 255) / 256), dim3(256), 0, s, keys_all, rank_stride, nranks, n, map);
+}
+
+// ------------------------------------------------------------------------------------------
+// PP lrCheck (src/PP.cpp:17-50)
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_lr_check(const uint8_t *__restrict__ l, const uint8_t *__restrict__ r, int W, int H,
+                                                 uint8_t *__restrict__ lv, uint8_t *__restrict__ rv)
+{
+    int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x >= W) return;
+    const uint8_t *lr = l + (size_t)y * W, *rr = r + (size_t)y * W;
+    int lDep = lr[x];
+    int rLoc = (x - lDep + W) % W;
+    int rDep = rr[rLoc];
+    lv[(size_t)y * W + x] = (lDep == rDep && lDep >= 2) ? 1 : 0;
+    rDep = rr[x];
+    int lLoc = (x + rDep + W) % W;
+    lDep = lr[lLoc];
+    rv[(size_t)y * W + x] = (rDep == lDep && rDep >= 2) ? 1 : 0;
+}
+
+void launch_lr_check(hipStream_t s, const uint8_t *l, const uint8_t *r, int W, int H, uint8_t *lv, uint8_t *rv)
+{
+    hipLaunchKernelGGL(k_lr_check, dim3((W + 255) / 256, H), dim3(256), 0, s, l, r, W, H, lv, rv);
+}
+
+// ------------------------------------------------------------------------------------------
+// 8-bit char mode (build-defined contract, DESIGN.md "8-bit mode"; oracle: psmo_*_u8)
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ int gray_u8(const uint8_t *p)
+{
+    return (p[0] * 4899 + p[1] * 9617 + p[2] * 1868 + (1 << 13)) >> 14;
+}
+
+// planes4[y][x] = {c0, c1, c2, grad} as one 32-bit word per pixel
+__global__ __launch_bounds__(256) void k_prep_u8(const uint8_t *src, size_t pitch, int W, int H, uchar4 *out)
+{
+    int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x >= W) return;
+    const uint8_t *row = src + (size_t)y * pitch;
+    const uint8_t *p = row + 3 * x;
+    int g = gray_u8(row + 3 * r101(x + 1, W)) - gray_u8(row + 3 * r101(x - 1, W));
+    g = g < 0 ? 0 : (g > 255 ? 255 : g);
+    out[(size_t)y * W + x] = make_uchar4(p[0], p[1], p[2], (uint8_t)g);
+}
+void launch_prep_u8(hipStream_t s, const uint8_t *src, size_t pitch, int W, int H, uint8_t *planes4)
+{
+    hipLaunchKernelGGL(k_prep_u8, dim3((W + 255) / 256, H), dim3(256), 0, s, src, pitch, W, H, (uchar4 *)planes4);
+}
+
+__device__ __forceinline__ uint8_t cost_u8(int clr3, int grd)
+{  // assets/cvc.cl:279-301
+    float f = __fadd_rn(__fmul_rn(0.9f, (float)(clr3 / 3)), __fmul_rn(__fsub_rn(1.0f, 0.9f), (float)grd));
+    return (uint8_t)f;
+}
+template <bool RIGHT>
+__global__ __launch_bounds__(256) void k_cvc_u8(const uchar4 *__restrict__ base, const uchar4 *__restrict__ other,
+                                               uint8_t *__restrict__ vol, int W, int H, int d_begin, int Dloc)
+{
+    int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    int dl0 = blockIdx.z * CVC_DC;
+    if (x >= W) return;
+    const size_t HW = (size_t)H * W, row = (size_t)y * W;
+    uchar4 a = base[row + x];
+    uint8_t cb = cost_u8(abs(a.x - 255) + abs(a.y - 255) + abs(a.z - 255), abs(a.w - 255));
+#pragma unroll
+    for (int k = 0; k < CVC_DC; ++k) {
+        int dl = dl0 + k;
+        if (dl >= Dloc) break;
+        int d = d_begin + dl;
+        bool in = RIGHT ? (x < W - d) : (x >= d);
+        uint8_t c = cb;
+        if (in) {
+            uchar4 b = other[row + (RIGHT ? x + d : x - d)];
+            c = cost_u8(abs(a.x - b.x) + abs(a.y - b.y) + abs(a.z - b.z), abs(a.w - b.w));
+        }
+        vol[(size_t)dl * HW + row + x] = c;
+    }
+}
+void launch_cvc_u8(hipStream_t s, const uint8_t *base4, const uint8_t *other4, uint8_t *vol, int W, int H, int d_begin,
+                   int Dloc, int right)
+{
+    dim3 grid((W + 255) / 256, H, (Dloc + CVC_DC - 1) / CVC_DC);
+    if (right)
+        hipLaunchKernelGGL(k_cvc_u8<true>, grid, dim3(256), 0, s, (const uchar4 *)base4, (const uchar4 *)other4, vol, W, H, d_begin, Dloc);
+    else
+        hipLaunchKernelGGL(k_cvc_u8<false>, grid, dim3(256), 0, s, (const uchar4 *)base4, (const uchar4 *)other4, vol, W, H, d_begin, Dloc);
+}
+
+__global__ __launch_bounds__(256) void k_u8_to_f32(const uint8_t *__restrict__ src, float *__restrict__ dst, size_t n)
+{
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    const float alpha = 1 / 255.0f;
+    for (; i < n; i += stride) dst[i] = __fmul_rn((float)src[i], alpha);
+}
+__global__ __launch_bounds__(256) void k_f32_to_u8(const float *__restrict__ src, uint8_t *__restrict__ dst, size_t n)
+{
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) {
+        float r = rintf(__fmul_rn(src[i], 255.0f));  // round-half-even; NaN -> 0
+        dst[i] = !(r > 0.0f) ? 0 : (r > 255.0f ? 255 : (uint8_t)r);
+    }
+}
+static int grid_for(size_t n)
+{
+    size_t b = (n + 255) / 256;
+    return (int)(b > 8192 ? 8192 : (b ? b : 1));
+}
+void launch_u8_to_f32(hipStream_t s, const uint8_t *src, float *dst, size_t n)
+{
+    hipLaunchKernelGGL(k_u8_to_f32, dim3(grid_for(n)), dim3(256), 0, s, src, dst, n);
+}
+void launch_f32_to_u8(hipStream_t s, const float *src, uint8_t *dst, size_t n)
+{
+    hipLaunchKernelGGL(k_f32_to_u8, dim3(grid_for(n)), dim3(256), 0, s, src, dst, n);
+}
+
+__global__ __launch_bounds__(256) void k_wta_u8(const uint8_t *__restrict__ vol, int HW, int d_begin, int Dloc,
+                                               long long *__restrict__ keys, uint8_t *__restrict__ map)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= HW) return;
+    int minCost = 256, minDis = 0;  // assets/dispsel.cl:41-62, initial minimum 256 so 255 can win
+    int dl = (d_begin == 0) ? 1 : 0;
+    const uint8_t *p = vol + (size_t)dl * HW + i;
+    for (; dl < Dloc; ++dl, p += HW) {
+        int c = *p;
+        if (c < minCost) {
+            minCost = c;
+            minDis = d_begin + dl;
+        }
+    }
+    if (keys) keys[i] = ((long long)minCost << 32) | (long long)minDis;
+    if (map) map[i] = (uint8_t)minDis;
+}
+void launch_wta_u8(hipStream_t s, const uint8_t *vol, int W, int H, int d_begin, int Dloc, long long *keys, uint8_t *map)
+{
+    int HW = W * H;
+    hipLaunchKernelGGL(k_wta_u8, dim3((HW + 255) / 256), dim3(256), 0, s, vol, HW, d_begin, Dloc, keys, map);
+}
+
+}  // namespace psm

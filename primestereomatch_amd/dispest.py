@@ -1,0 +1,214 @@
+"""Python mirror of the reference's `DispEst` accelerator interface (include/DispEst.h:21-51,
+src/DispEst.cpp:272-328) on top of the C ABI.  Method names, argument meaning and return
+conventions follow the reference so that tests read like calls into the reference:
+
+    de = DispEst(l, r, maxDis, threads, useHIP=True)
+    de.setInputImages(l, r); de.CostConst_GPU(); de.CostFilter_GPU(); de.DispSelect_GPU()
+    de.lDisMap, de.rDisMap            # H x W uint8
+
+The C++ twin (primestereomatch_amd/host/DispEst.h) is what a C++ host links; this class exists
+for the Python tests and bench.  No CPU path lives here: without the HIP library and a GPU the
+constructor raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import capi
+
+MAX_CPU_THREADS = 8  # include/ComFunc.h:52
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+class DispEst:
+    def __init__(self, l, r, d: int, t: int = 8, ocl: bool = True, *, dtype: str = "f32",
+                 device: int = 0, d_range=None):
+        """l, r: H x W x 3 images (uint8 as loaded by imread, or float32 scaled by 1/255 as
+        StereoMatch::compute hands them over, src/StereoMatch.cpp:193-198); d: maxDis;
+        t: host threads (kept for interface parity; unused by the GPU path); ocl: must be true
+        (the accelerator path is the only one this package implements).
+        dtype: "f32" | "u8" (8-bit char mode).  d_range=(d_begin,d_end): disparity shard."""
+        if not ocl:
+            raise capi.PsmError("DispEst: only the accelerator ('m' / OCL_DE) path exists in this package")
+        l = np.asarray(l)
+        r = np.asarray(r)
+        if l.shape != r.shape or l.dtype != r.dtype:
+            # src/DispEst.cpp:21-29: exits on mismatching types
+            raise ValueError("DE: Error - Left & Right images are of different types.")
+        if l.ndim != 3 or l.shape[2] != 3:
+            raise ValueError("DispEst: images must be H x W x 3")
+        self.hei, self.wid = int(l.shape[0]), int(l.shape[1])
+        self.maxDis = int(d)
+        self.threads = int(t)
+        self.useOCL = True
+        self.subsample_rate = 4
+        self._lib = capi.load()
+        self._dtype = capi.PSM_U8 if dtype == "u8" else capi.PSM_F32
+        self._h = C.c_void_p()
+        d0, d1 = (0, self.maxDis) if d_range is None else (int(d_range[0]), int(d_range[1]))
+        self.d_begin, self.d_end = d0, d1
+        rc = self._lib.psm_create_shard(C.byref(self._h), self.wid, self.hei, self.maxDis, d0, d1,
+                                        self._dtype, int(device))
+        if rc != 0:
+            self._h = C.c_void_p()
+            raise capi.PsmError("DispEst: " + capi.last_error(None))
+        self.lDisMap = np.zeros((self.hei, self.wid), np.uint8)
+        self.rDisMap = np.zeros((self.hei, self.wid), np.uint8)
+        self.lValid = np.zeros((self.hei, self.wid), np.uint8)
+        self.rValid = np.zeros((self.hei, self.wid), np.uint8)
+        self.setInputImages(l, r)
+
+    # ---- lifetime -------------------------------------------------------------------------
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self._lib.psm_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def _ck(self, rc, what):
+        capi.check(rc, self._h, what)
+
+    # ---- reference interface ---------------------------------------------------------------
+    def setInputImages(self, l, r) -> int:
+        l = np.ascontiguousarray(l)
+        r = np.ascontiguousarray(r)
+        assert l.dtype == r.dtype  # src/DispEst.cpp:166
+        if l.shape != (self.hei, self.wid, 3) or r.shape != l.shape:
+            raise ValueError("setInputImages: image size differs from the one DispEst was built for")
+        if l.dtype == np.uint8:
+            depth = capi.PSM_IMG_U8
+        elif l.dtype == np.float32:
+            depth = capi.PSM_IMG_F32
+        else:
+            raise ValueError("setInputImages: images must be uint8 or float32")
+        self._ck(self._lib.psm_upload_pair(self._h, _ptr(l), _ptr(r), 3, l.strides[0], depth),
+                 "setInputImages")
+        return 0
+
+    def setThreads(self, newThreads: int) -> int:
+        if newThreads > MAX_CPU_THREADS:  # src/DispEst.cpp:172-179
+            return -1
+        self.threads = int(newThreads)
+        return 0
+
+    def setSubsampleRate(self, newRate: int) -> None:
+        self.subsample_rate = int(newRate)
+
+    def CostConst_GPU(self) -> int:
+        self._ck(self._lib.psm_cost_construct(self._h), "CostConst_GPU")
+        return 0
+
+    def CostFilter_GPU(self) -> int:
+        self._ck(self._lib.psm_cost_filter(self._h), "CostFilter_GPU")
+        return 0
+
+    def DispSelect_GPU(self) -> int:
+        self._ck(self._lib.psm_disp_select(self._h, _ptr(self.lDisMap), _ptr(self.rDisMap), self.wid),
+                 "DispSelect_GPU")
+        return 0
+
+    # ---- extensions beyond the reference surface --------------------------------------------
+    def LRCheck_GPU(self) -> int:
+        """PP lrCheck (src/PP.cpp:17-50) on the device -> lValid / rValid."""
+        self._ck(self._lib.psm_lr_check(self._h, _ptr(self.lValid), _ptr(self.rValid), self.wid),
+                 "LRCheck_GPU")
+        return 0
+
+    def set_option(self, option: int, value: int):
+        self._ck(self._lib.psm_set_option(self._h, int(option), int(value)), "set_option")
+
+    def set_stream(self, stream_ptr: int | None):
+        self._ck(self._lib.psm_set_stream(self._h, C.c_void_p(stream_ptr or 0)), "set_stream")
+
+    def synchronize(self):
+        self._ck(self._lib.psm_synchronize(self._h), "synchronize")
+
+    def DispSelect_partial(self, dev_keys_ptr: int | None = None):
+        self._ck(self._lib.psm_disp_select_partial(self._h, C.c_void_p(dev_keys_ptr or 0)),
+                 "DispSelect_partial")
+
+    def partial_keys(self):
+        p, n = C.c_void_p(), C.c_size_t()
+        self._ck(self._lib.psm_partial_keys(self._h, C.byref(p), C.byref(n)), "partial_keys")
+        return p.value, n.value
+
+    def DispSelect_merge(self, dev_keys_all_ptr: int, nranks: int, download: bool = True):
+        self._ck(self._lib.psm_disp_merge(self._h, C.c_void_p(dev_keys_all_ptr), int(nranks),
+                                          _ptr(self.lDisMap) if download else None,
+                                          _ptr(self.rDisMap) if download else None, self.wid),
+                 "DispSelect_merge")
+
+    def DispSelect_device(self):
+        """WTA with the maps left on the device (bench: D2H excluded from the timed region)."""
+        self._ck(self._lib.psm_disp_select(self._h, None, None, 0), "DispSelect_device")
+
+    def download_maps(self):
+        self._ck(self._lib.psm_download_maps(self._h, _ptr(self.lDisMap), _ptr(self.rDisMap), self.wid),
+                 "download_maps")
+        return self.lDisMap, self.rDisMap
+
+    def _vdtype(self):
+        return np.uint8 if self._dtype == capi.PSM_U8 else np.float32
+
+    def download_volume(self, side: int, d0: int | None = None, d1: int | None = None):
+        d0 = self.d_begin if d0 is None else d0
+        d1 = self.d_end if d1 is None else d1
+        out = np.empty((d1 - d0, self.hei, self.wid), self._vdtype())
+        self._ck(self._lib.psm_download_volume(self._h, side, d0, d1, _ptr(out)), "download_volume")
+        return out
+
+    def upload_volume(self, side: int, vol, d0: int | None = None):
+        vol = np.ascontiguousarray(vol, dtype=self._vdtype())
+        d0 = self.d_begin if d0 is None else d0
+        assert vol.shape[1:] == (self.hei, self.wid)
+        self._ck(self._lib.psm_upload_volume(self._h, side, d0, d0 + vol.shape[0], _ptr(vol)),
+                 "upload_volume")
+
+    def filter_stage_a(self, side: int):
+        self._ck(self._lib.psm_filter_stage_a(self._h, side), "filter_stage_a")
+
+    def download_ab(self, d0: int | None = None, d1: int | None = None):
+        d0 = self.d_begin if d0 is None else d0
+        d1 = self.d_end if d1 is None else d1
+        out = np.empty((d1 - d0, self.hei, self.wid, 4), np.float32)
+        self._ck(self._lib.psm_download_ab(self._h, d0, d1, _ptr(out)), "download_ab")
+        return out
+
+    def download_guidance(self, side: int):
+        out = np.empty((14, self.hei, self.wid), np.float32)
+        self._ck(self._lib.psm_download_guidance(self._h, side, _ptr(out)), "download_guidance")
+        return out
+
+    def box8_volume(self, side: int, download: bool = True):
+        out = np.empty((self.d_end - self.d_begin, self.hei, self.wid), np.float32) if download else None
+        self._ck(self._lib.psm_box8_volume(self._h, side, _ptr(out)), "box8_volume")
+        return out
+
+    def stage_time_us(self, stage: int) -> float:
+        v = C.c_double()
+        self._ck(self._lib.psm_stage_time_us(self._h, stage, C.byref(v)), "stage_time_us")
+        return v.value
+
+    def kernel_time_ms(self, kernel: int):
+        v, n = C.c_double(), C.c_int()
+        self._ck(self._lib.psm_kernel_time_ms(self._h, kernel, C.byref(v), C.byref(n)), "kernel_time_ms")
+        return v.value, n.value
+
+    def reset_kernel_times(self):
+        self._ck(self._lib.psm_reset_kernel_times(self._h), "reset_kernel_times")
