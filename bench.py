@@ -1,0 +1,232 @@
+#!/usr/bin/env python3
+"""bench.py - cost-volume voxels/s (CVC+CVF+WTA) of the HIP DispEst hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One "step" = one pass of the hot path over one synthetic stereo pair already resident in HBM:
+CostConst (gray/gradient + both cost volumes) -> CostFilter (guidance precompute + guided filter
+of both volumes) -> DispSel (WTA; for N > 1: local WTA -> one RCCL all-gather of the packed
+per-pixel minima -> final argmin).  Workload at N=1: BASELINE.json configs[3], 1920x1080, D=256,
+float32 - the configuration the metric is quoted on; for N > 1 the D slices of that same job are
+sharded over the ranks (total work fixed -> "scaling": "strong").
+
+Prints ONE JSON line (rank 0) with the contract fields plus
+  roofline     - dominant kernel: algorithmic HBM bytes per launch / its mean hipEvent duration
+  cpu_baseline - the CPU oracle (restatement of the reference pthreads path) timed on a bounded
+                 sample on this box's host cores (rank 0, N=1 only); a reported baseline.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy ceiling)
+CONFIGS = {
+    # name: (W, H, D, description)
+    "c4": (1920, 1080, 256, "synthetic 1920x1080 pair, D=256, float32 (BASELINE configs[3])"),
+    "c3": (1280, 720, 128, "synthetic 1280x720 pair, D=128, float32 (BASELINE configs[2])"),
+    "c5": (3840, 2160, 256, "synthetic 3840x2160 pair, D=256, float32 (BASELINE configs[4])"),
+    "c2": (450, 375, 64, "synthetic 450x375 pair, D=64, float32 (size of BASELINE configs[1])"),
+}
+# algorithmic HBM bytes per voxel (SURVEY.md 8d / DESIGN.md): stage A 4 R + 16 W, stage B 16 R + 4 W
+ALG_BYTES = {"cvf_a": 20.0, "cvf_b": 20.0, "cvc": 4.0, "wta": 4.0, "box8": 8.0, "pipeline": 48.0}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", default="c4", choices=sorted(CONFIGS))
+    ap.add_argument("--seg-rows", type=int, default=-1, help="marching-kernel y segment (-1: library default)")
+    ap.add_argument("--waves", type=int, default=0, help="waves per workgroup (0: library default)")
+    ap.add_argument("--variant", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-d", type=int, default=24, help="disparities in the CPU-baseline sample")
+    ap.add_argument("--force-dist", action="store_true", help="use the torch.distributed path even for N=1")
+    ap.add_argument("--box-bench", action="store_true", help="also time the plain box-filter pass")
+    args = ap.parse_args()
+
+    N = args.gpus
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    use_dist = (N > 1) or args.force_dist
+    torch = dist = None
+    if use_dist:
+        # torch first: libprimesm_hip.so then binds to the HIP runtime torch already loaded
+        # (same SONAME libamdhip64.so.7), so device pointers are interchangeable.
+        import torch
+        import torch.distributed as dist
+        if world != N:
+            raise SystemExit(f"bench.py --gpus {N} needs WORLD_SIZE={N} (got {world}); launch with torch.distributed.run")
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world,
+                                device_id=torch.device("cuda", local_rank))
+
+    import numpy as np
+    import primestereomatch_amd as P
+    from primestereomatch_amd import capi, synth
+
+    W, H, D, desc = CONFIGS[args.config]
+    if use_dist:
+        d0, d1 = D * rank // world, D * (rank + 1) // world
+    else:
+        d0, d1 = 0, D
+    l, r, _ = synth.make_pair(W, H, D, seed=0)
+    de = P.DispEst(l, r, D, 8, True, device=local_rank, d_range=(d0, d1))
+    if args.seg_rows >= 0:
+        de.set_option(capi.PSM_OPT_SEG_ROWS, args.seg_rows)
+    if args.waves:
+        de.set_option(capi.PSM_OPT_WAVES, args.waves)
+    de.set_option(capi.PSM_OPT_KERNEL_VARIANT, args.variant)
+    de.set_option(capi.PSM_OPT_ASYNC, 1)
+
+    keys_local = keys_all = None
+    if use_dist:
+        HW2 = 2 * H * W
+        keys_local = torch.empty(HW2, dtype=torch.int64, device="cuda")
+        keys_all = torch.empty(world * HW2, dtype=torch.int64, device="cuda")
+        # one non-default torch stream carries both our kernels and the RCCL collective, so the
+        # exchange is ordered against the kernels without host synchronisation
+        side_stream = torch.cuda.Stream()
+        torch.cuda.set_stream(side_stream)
+        de.set_stream(side_stream.cuda_stream)
+
+    def step():
+        de.CostConst_GPU()
+        de.CostFilter_GPU()
+        if use_dist:
+            de.DispSelect_partial(keys_local.data_ptr())
+            dist.all_gather_into_tensor(keys_all, keys_local)     # the one exchange step (RCCL)
+            de.DispSelect_merge(keys_all.data_ptr(), world, download=False)
+        else:
+            de.DispSelect_device()
+
+    def sync():
+        if use_dist:
+            torch.cuda.synchronize()
+        de.synchronize()
+
+    def barrier():
+        if use_dist:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        step()
+    sync(); barrier(); sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    sync(); barrier(); sync()
+    elapsed = time.perf_counter() - t0
+    if use_dist:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    ms_per_step = 1e3 * elapsed / args.steps
+    voxels_per_step = 2.0 * W * H * D           # both volumes, all ranks
+    value = voxels_per_step / (elapsed / args.steps)
+
+    # ---- per-kernel device time (hipEvents on the launch stream), separate pass -----------
+    de.set_option(capi.PSM_OPT_PROFILE, 1)
+    de.reset_kernel_times()
+    prof_steps = max(2, min(args.steps, 5))
+    for _ in range(prof_steps):
+        step()
+    sync()
+    names = {capi.PSM_K_PREP: "prep", capi.PSM_K_CVC: "cvc", capi.PSM_K_GUIDE: "guidance",
+             capi.PSM_K_CVF_A: "cvf_a", capi.PSM_K_CVF_B: "cvf_b", capi.PSM_K_WTA: "wta",
+             capi.PSM_K_MERGE: "merge"}
+    kern = {}
+    for k, nm in names.items():
+        tot, n = de.kernel_time_ms(k)
+        if n:
+            kern[nm] = {"avg_ms": tot / n, "launches_per_step": n / prof_steps}
+    de.set_option(capi.PSM_OPT_PROFILE, 0)
+    vox_per_launch = float(W) * H * (d1 - d0)   # one launch = all local slices of one side
+    dom = max(("cvf_a", "cvf_b"), key=lambda k: kern.get(k, {"avg_ms": 0})["avg_ms"])
+    dom_ms = kern[dom]["avg_ms"]
+    achieved = ALG_BYTES[dom] * vox_per_launch / (dom_ms * 1e-3) / 1e9
+    roofline = {"bound": "hbm", "kernel": "k_" + dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                "alg_bytes_per_launch": ALG_BYTES[dom] * vox_per_launch, "avg_launch_ms": round(dom_ms, 4),
+                "pipeline_alg_GBs": round(ALG_BYTES["pipeline"] * value / 1e9, 1),
+                "pipeline_frac": round(ALG_BYTES["pipeline"] * value / 1e9 / HBM_PEAK_GBS, 4)}
+    traffic_file = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(traffic_file):
+        try:
+            tr = json.load(open(traffic_file))
+            key = f"{args.config}:k_{dom}"
+            if key in tr and world == 1:
+                roofline["traffic"] = tr[key]    # HBM bytes per launch from rocprofv3 PMC passes
+        except Exception:
+            pass
+    for nm, v in kern.items():
+        if nm in ALG_BYTES:
+            v["alg_GBs"] = round(ALG_BYTES[nm] * vox_per_launch / (v["avg_ms"] * 1e-3) / 1e9, 1)
+        v["avg_ms"] = round(v["avg_ms"], 4)
+
+    box = None
+    if args.box_bench and not use_dist:
+        de.set_option(capi.PSM_OPT_PROFILE, 1)
+        de.reset_kernel_times()
+        for _ in range(5):
+            de.box8_volume(0, download=False)
+        de.synchronize()
+        tot, n = de.kernel_time_ms(capi.PSM_K_BOX)
+        de.set_option(capi.PSM_OPT_PROFILE, 0)
+        bms = tot / n
+        box = {"avg_ms": round(bms, 4), "alg_GBs": round(8.0 * vox_per_launch / (bms * 1e-3) / 1e9, 1),
+               "read_GBs": round(4.0 * vox_per_launch / (bms * 1e-3) / 1e9, 1),
+               "read_frac_of_peak": round(4.0 * vox_per_launch / (bms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+
+    # ---- CPU baseline: the oracle, driven like the reference pthreads path ------------------
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import psm_oracle_py as O   # checker / baseline only - never on the GPU path
+        cores = os.cpu_count() or 1
+        threads = min(8, cores)                 # MAX_CPU_THREADS (include/ComFunc.h:52)
+        sd = max(2, min(args.cpu_sample_d, D))
+        tcpu = time.perf_counter()
+        res = O.pipeline_f32(l, r, sd, threads=threads)
+        tcpu = time.perf_counter() - tcpu
+        stage_s = (res["cvc_ms"] + res["cvf_ms"] + res["dispsel_ms"]) * 1e-3
+        cpu = {"value": round(2.0 * W * H * sd / stage_s, 1), "unit": "voxels/s", "cores": threads,
+               "kind": "port", "host_cores": cores,
+               "sample": f"same {W}x{H} pair, first {sd} of {D} disparities (2*W*H*{sd} voxels), "
+                         f"{threads} pthreads in the reference's per-d block pattern; "
+                         f"cvc {res['cvc_ms']:.0f} ms, cvf {res['cvf_ms']:.0f} ms, dispsel {res['dispsel_ms']:.0f} ms "
+                         f"(wall {tcpu:.1f} s)"}
+
+    if rank == 0:
+        out = {
+            "metric": "cost-volume voxels/s (CVC+CVF+WTA)", "value": value, "unit": "voxels/s",
+            "n_gpus": N, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": desc, "W": W, "H": H, "D": D, "voxels_per_step": voxels_per_step,
+                       "parallelism": "1 GPU" if world == 1 else f"D sharded over {world} ranks + 1 RCCL all-gather of packed minima",
+                       "kernel_variant": args.variant},
+            "roofline": roofline, "cpu_baseline": cpu, "kernels": kern,
+        }
+        if box:
+            out["box_filter_pass"] = box
+        print(json.dumps(out))
+        sys.stdout.flush()
+    de.close()
+    if use_dist:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -125,6 +125,14 @@ int psm_partial_keys(psm_ctx *ctx, void **dev_keys, size_t *bytes);
 int psm_disp_merge(psm_ctx *ctx, const void *dev_keys_all, int nranks, uint8_t *lmap,
                    uint8_t *rmap, size_t stride);
 
+/* Single-process form of the exchange step: `shards` are nshards contexts of one job (on the
+ * same or on different devices) whose psm_disp_select_partial has run; their key planes are
+ * copied (peer copy across devices) into `root`'s gather buffer and merged there.  This is
+ * what a C++ host that drives several GPUs from one process uses instead of RCCL, and what
+ * the single-GPU "logical shard" tests use. */
+int psm_disp_merge_ctx(psm_ctx *root, psm_ctx *const *shards, int nshards, uint8_t *lmap,
+                       uint8_t *rmap, size_t stride);
+
 int psm_download_maps(psm_ctx *ctx, uint8_t *lmap, uint8_t *rmap, size_t stride);
 
 /* "next" row: PP lrCheck on the device (src/PP.cpp:17-50) on the maps of the last

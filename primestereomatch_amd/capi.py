@@ -40,6 +40,7 @@ SYMBOLS = [
     ("psm_disp_select_partial", _i, [_vp, _vp]),
     ("psm_partial_keys", _i, [_vp, C.POINTER(_vp), C.POINTER(_sz)]),
     ("psm_disp_merge", _i, [_vp, _vp, _i, _vp, _vp, _sz]),
+    ("psm_disp_merge_ctx", _i, [_vp, C.POINTER(_vp), _i, _vp, _vp, _sz]),
     ("psm_download_maps", _i, [_vp, _vp, _vp, _sz]),
     ("psm_lr_check", _i, [_vp, _vp, _vp, _sz]),
     ("psm_download_volume", _i, [_vp, _i, _i, _i, _vp]),

@@ -45,11 +45,13 @@ struct psm_ctx {
     float *fvol = nullptr;              // PSM_U8 only: float work volume of one side
     float4 *ab = nullptr;               // [Dloc][H][W] {a0,a1,a2,b}; also box8 output
     long long *keys = nullptr;          // [2][H][W]
+    long long *gather = nullptr;        // [gather_ranks][2][H][W], psm_disp_merge_ctx
+    int gather_ranks = 0;
     uint8_t *maps = nullptr;            // [2][H][W]
     uint8_t *valid = nullptr;           // [2][H][W]
     uint8_t *p4[2] = {nullptr, nullptr};  // PSM_U8 only: {c0,c1,c2,grad} words
 
-    bool have_images = false, have_cost = false, have_maps = false;
+    bool have_images = false, have_g1 = false, have_cost = false, have_maps = false;
 
     // options
     int opt_async = 0, opt_variant = 0, opt_profile = 0;
@@ -154,6 +156,7 @@ void free_all(psm_ctx *c)
     (void)hipFree(c->fvol);
     (void)hipFree(c->ab);
     (void)hipFree(c->keys);
+    (void)hipFree(c->gather);
     (void)hipFree(c->maps);
     (void)hipFree(c->valid);
     for (auto &t : c->timers)
@@ -163,6 +166,20 @@ void free_all(psm_ctx *c)
         }
     for (auto e : c->event_pool) (void)hipEventDestroy(e);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+}
+
+// planarise + scale + gray + x-gradient of both staged images -> g1 (and the 8-bit planes)
+int run_prep(psm_ctx *c)
+{
+    const size_t row = (size_t)c->W * 3 * (c->raw_depth == PSM_IMG_F32 ? 4 : 1);
+    for (int s = 0; s < 2; ++s) {
+        Prof p(c, PSM_K_PREP);
+        launch_prep(c->stream, c->raw[s], row, c->raw_depth == PSM_IMG_F32, c->W, c->H, c->g[s].g1);
+        if (c->dtype == PSM_U8) launch_prep_u8(c->stream, (const uint8_t *)c->raw[s], row, c->W, c->H, c->p4[s]);
+    }
+    if (check_launch(c, "prep")) return 1;
+    c->have_g1 = true;
+    return 0;
 }
 
 int flush_timers(psm_ctx *c)
@@ -326,6 +343,7 @@ int psm_upload_pair(psm_ctx *c, const void *l, const void *r, int channels, size
     PSM_HIP(c, hipStreamSynchronize(c->stream));
     c->raw_depth = depth;
     c->have_images = true;
+    c->have_g1 = false;
     c->have_cost = false;
     c->have_maps = false;
     return 0;
@@ -337,13 +355,7 @@ int psm_cost_construct(psm_ctx *c)
     if (!c->have_images) return fail(c, "psm_cost_construct: no image pair uploaded");
     if (bind(c)) return 1;
     const double t0 = now_us();
-    const size_t row = (size_t)c->W * 3 * (c->raw_depth == PSM_IMG_F32 ? 4 : 1);
-    for (int s = 0; s < 2; ++s) {
-        Prof p(c, PSM_K_PREP);
-        launch_prep(c->stream, c->raw[s], row, c->raw_depth == PSM_IMG_F32, c->W, c->H, c->g[s].g1);
-        if (c->dtype == PSM_U8) launch_prep_u8(c->stream, (const uint8_t *)c->raw[s], row, c->W, c->H, c->p4[s]);
-    }
-    if (check_launch(c, "prep")) return 1;
+    if (run_prep(c)) return 1;  // CVC::preprocess belongs to this stage (src/DispEst.cpp:232-233)
     for (int s = 0; s < 2; ++s) {
         Prof p(c, PSM_K_CVC);
         // buildCV_right is called with the images swapped (src/DispEst.cpp:217,260)
@@ -361,6 +373,7 @@ int psm_cost_construct(psm_ctx *c)
 static int filter_side(psm_ctx *c, int side, bool stage_b)
 {
     const size_t V = (size_t)c->W * c->H * c->Dloc;
+    if (!c->have_g1 && run_prep(c)) return 1;  // volume came from psm_upload_volume
     {
         Prof p(c, PSM_K_GUIDE);
         launch_guidance(c->stream, c->g[side], c->hs9, c->W, c->H);
@@ -404,11 +417,6 @@ int psm_filter_stage_a(psm_ctx *c, int side)
     if (side != PSM_LEFT && side != PSM_RIGHT) return fail(c, "psm_filter_stage_a: bad side %d", side);
     if (!c->have_cost || !c->have_images) return fail(c, "psm_filter_stage_a: needs images and a cost volume");
     if (bind(c)) return 1;
-    if (c->raw_depth >= 0) {
-        // guidance needs g1; make sure it exists even if psm_cost_construct was skipped
-        const size_t row = (size_t)c->W * 3 * (c->raw_depth == PSM_IMG_F32 ? 4 : 1);
-        launch_prep(c->stream, c->raw[side], row, c->raw_depth == PSM_IMG_F32, c->W, c->H, c->g[side].g1);
-    }
     if (filter_side(c, side, false)) return 1;
     PSM_HIP(c, hipStreamSynchronize(c->stream));
     return 0;
@@ -488,6 +496,39 @@ int psm_disp_merge(psm_ctx *c, const void *dev_keys_all, int nranks, uint8_t *lm
     if (!c->opt_async) PSM_HIP(c, hipStreamSynchronize(c->stream));
     c->stage_us[PSM_STAGE_DISPSEL] += now_us() - t0;
     return 0;
+}
+
+int psm_disp_merge_ctx(psm_ctx *root, psm_ctx *const *shards, int nshards, uint8_t *lmap, uint8_t *rmap, size_t stride)
+{
+    if (!root) return 1;
+    if (!shards || nshards < 1) return fail(root, "psm_disp_merge_ctx: bad arguments");
+    const size_t bytes = 2 * (size_t)root->W * root->H * sizeof(long long);
+    for (int i = 0; i < nshards; ++i) {
+        const psm_ctx *s = shards[i];
+        if (!s || s->W != root->W || s->H != root->H || s->D != root->D || s->dtype != root->dtype)
+            return fail(root, "psm_disp_merge_ctx: shard %d does not belong to this job", i);
+    }
+    if (bind(root)) return 1;
+    if (root->gather_ranks < nshards) {
+        PSM_HIP(root, hipStreamSynchronize(root->stream));
+        (void)hipFree(root->gather);
+        root->gather = nullptr;
+        root->gather_ranks = 0;
+        PSM_HIP(root, hipMalloc((void **)&root->gather, bytes * nshards));
+        root->gather_ranks = nshards;
+    }
+    for (int i = 0; i < nshards; ++i) {
+        psm_ctx *s = shards[i];
+        // the shard's partial WTA must have finished before its keys are read
+        (void)hipSetDevice(s->device);
+        PSM_HIP(root, hipStreamSynchronize(s->stream));
+        (void)hipSetDevice(root->device);
+        if (s->device == root->device)
+            PSM_HIP(root, hipMemcpyAsync((char *)root->gather + bytes * i, s->keys, bytes, hipMemcpyDeviceToDevice, root->stream));
+        else
+            PSM_HIP(root, hipMemcpyPeerAsync((char *)root->gather + bytes * i, root->device, s->keys, s->device, bytes, root->stream));
+    }
+    return psm_disp_merge(root, root->gather, nshards, lmap, rmap, stride);
 }
 
 int psm_download_maps(psm_ctx *c, uint8_t *lmap, uint8_t *rmap, size_t stride)

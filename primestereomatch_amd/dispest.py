@@ -154,6 +154,14 @@ class DispEst:
                                           _ptr(self.rDisMap) if download else None, self.wid),
                  "DispSelect_merge")
 
+    def DispSelect_merge_ctx(self, shards, download: bool = True):
+        """Single-process exchange: merge the partial keys of `shards` (DispEst objects)."""
+        arr = (C.c_void_p * len(shards))(*[s._h for s in shards])
+        self._ck(self._lib.psm_disp_merge_ctx(self._h, arr, len(shards),
+                                              _ptr(self.lDisMap) if download else None,
+                                              _ptr(self.rDisMap) if download else None, self.wid),
+                 "DispSelect_merge_ctx")
+
     def DispSelect_device(self):
         """WTA with the maps left on the device (bench: D2H excluded from the timed region)."""
         self._ck(self._lib.psm_disp_select(self._h, None, None, 0), "DispSelect_device")

@@ -1,0 +1,85 @@
+// DispEst.h - C++ host-side mirror of the reference's DispEst class (include/DispEst.h:21-109)
+// for the accelerator ('m' / OCL_DE) compute mode, on top of the C ABI of libprimesm_hip.so.
+//
+// Kept from the reference: constructor signature (l, r, d, t, useAccel), setInputImages /
+// setThreads / setSubsampleRate, CostConst_GPU / CostFilter_GPU / DispSelect_GPU /
+// PostProcess_GPU, the public outputs lDisMap / rDisMap (8-bit, one byte per pixel), `int`
+// returns with 0 = ok (the reference's *_GPU methods always return 0, src/DispEst.cpp:272-328;
+// here a failing device call returns 1 and prints, like the _cl wrappers).
+// cv::Mat is replaced by the POD view psm::Mat below because OpenCV is not part of this build;
+// field names follow cv::Mat (rows, cols, data, step).
+#pragma once
+#include <cstddef>
+#include <cstdint>
+#include <vector>
+
+#include "hipUtil.h"
+
+namespace psm {
+
+enum { PSM_8U = 0, PSM_32F = 1 };  // cv depth codes the path uses (CV_8U, CV_32F)
+
+struct Mat {
+    int rows = 0, cols = 0, channels = 0, depth = PSM_8U;
+    size_t step = 0;  // bytes per row
+    unsigned char *data = nullptr;
+    std::vector<unsigned char> store;  // owning storage when created with create()
+
+    Mat() {}
+    Mat(int r, int c, int ch, int dp, void *ext, size_t stp = 0)
+        : rows(r), cols(c), channels(ch), depth(dp), step(stp ? stp : (size_t)c * ch * (dp == PSM_32F ? 4 : 1)),
+          data((unsigned char *)ext) {}
+    static Mat zeros(int r, int c, int ch, int dp)
+    {
+        Mat m;
+        m.rows = r; m.cols = c; m.channels = ch; m.depth = dp;
+        m.step = (size_t)c * ch * (dp == PSM_32F ? 4 : 1);
+        m.store.assign(m.step * r, 0);
+        m.data = m.store.data();
+        return m;
+    }
+    int type() const { return depth * 8 + channels; }
+    template <typename T> T *ptr(int y) { return (T *)(data + step * y); }
+    template <typename T> const T *ptr(int y) const { return (const T *)(data + step * y); }
+};
+
+#define MAX_CPU_THREADS 8  // include/ComFunc.h:52
+
+class DispEst {
+public:
+    // l, r: H x W x 3 images, cv::imread channel order, CV_8U or CV_32F (already scaled by
+    // 1/255.0f, src/StereoMatch.cpp:193-198).  d: maxDis; t: host threads (interface parity);
+    // ocl: accelerator available (the reference's gotOCLDev).  ndev > 1 shards the disparity
+    // range over the first ndev devices of this process.
+    DispEst(Mat l, Mat r, const int d, int t, bool ocl, int ndev = 1, int dtype = PSM_F32);
+    ~DispEst(void);
+
+    Mat lDisMap;
+    Mat rDisMap;
+    Mat lValid;
+    Mat rValid;
+
+    int setInputImages(Mat l, Mat r);
+    int setThreads(unsigned int newThreads);
+    void setSubsampleRate(unsigned int newRate) { subsample_rate = newRate; }
+
+    int CostConst_GPU();
+    int CostFilter_GPU();
+    int DispSelect_GPU();
+    // The reference's PostProcess_GPU runs the CPU JointWMF (src/DispEst.cpp:338-344), which is
+    // out of scope here; this one runs the device left-right check
+    // (src/PP.cpp:17-50) and leaves the maps untouched.
+    int PostProcess_GPU();
+
+    bool ok() const { return !ctx.empty(); }
+    double stageTimeUs(int stage) const;
+
+private:
+    Mat lImg, rImg;
+    int hei, wid, maxDis, threads;
+    bool useOCL;
+    unsigned int subsample_rate = 4;
+    std::vector<psm_ctx *> ctx;  // one per device (disparity shards)
+};
+
+}  // namespace psm

@@ -1,0 +1,80 @@
+// psm_demo - headless counterpart of the reference's StereoMatch::compute accelerator branch
+// (src/StereoMatch.cpp:193-262): raw B,G,R uint8 pair in, four timed stages, raw uint8 maps out.
+//   psm_demo <left.raw> <right.raw> <W> <H> <maxDis> <out_prefix> [ndev] [f32|u8] [float_input]
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "DispEst.h"
+
+static bool slurp(const char *path, std::vector<unsigned char> &buf, size_t n)
+{
+    FILE *f = fopen(path, "rb");
+    if (!f) return false;
+    buf.resize(n);
+    size_t got = fread(buf.data(), 1, n, f);
+    fclose(f);
+    return got == n;
+}
+static bool dump(const std::string &path, const unsigned char *p, size_t n)
+{
+    FILE *f = fopen(path.c_str(), "wb");
+    if (!f) return false;
+    size_t put = fwrite(p, 1, n, f);
+    fclose(f);
+    return put == n;
+}
+
+int main(int argc, char **argv)
+{
+    if (argc < 7) {
+        fprintf(stderr, "usage: %s left.raw right.raw W H maxDis out_prefix [ndev] [f32|u8] [float_input]\n", argv[0]);
+        return 2;
+    }
+    const int W = atoi(argv[3]), H = atoi(argv[4]), D = atoi(argv[5]);
+    const std::string out = argv[6];
+    const int ndev = argc > 7 ? atoi(argv[7]) : 1;
+    const int dtype = (argc > 8 && !strcmp(argv[8], "u8")) ? PSM_U8 : PSM_F32;
+    const bool float_input = argc > 9 && atoi(argv[9]) != 0;
+    std::vector<unsigned char> lraw, rraw;
+    if (!slurp(argv[1], lraw, (size_t)W * H * 3) || !slurp(argv[2], rraw, (size_t)W * H * 3)) {
+        fprintf(stderr, "psm_demo: cannot read the input pair\n");
+        return 2;
+    }
+    int gotDev = psm::hipUtil::hipDevicePoll();  // src/main.cpp:29 openCLdevicepoll()
+    if (gotDev <= 0) {
+        fprintf(stderr, "psm_demo: no HIP device / library (%s)\n", psm::hipUtil::error().c_str());
+        return 3;
+    }
+    psm::Mat l(H, W, 3, psm::PSM_8U, lraw.data()), r(H, W, 3, psm::PSM_8U, rraw.data());
+    std::vector<float> lf, rf;
+    if (float_input) {  // src/StereoMatch.cpp:195-196 convertTo(CV_32F, 1/255.0f)
+        lf.resize(lraw.size());
+        rf.resize(rraw.size());
+        const float alpha = 1 / 255.0f;
+        for (size_t i = 0; i < lraw.size(); ++i) {
+            lf[i] = (float)lraw[i] * alpha;
+            rf[i] = (float)rraw[i] * alpha;
+        }
+        l = psm::Mat(H, W, 3, psm::PSM_32F, lf.data());
+        r = psm::Mat(H, W, 3, psm::PSM_32F, rf.data());
+    }
+    psm::DispEst SMDE(l, r, D, 8, gotDev > 0, ndev, dtype);
+    if (!SMDE.ok()) return 4;
+    SMDE.setInputImages(l, r);
+    SMDE.setThreads(8);
+    SMDE.setSubsampleRate(4);
+    int rc = 0;
+    rc |= SMDE.CostConst_GPU();
+    rc |= SMDE.CostFilter_GPU();
+    rc |= SMDE.DispSelect_GPU();
+    rc |= SMDE.PostProcess_GPU();
+    if (rc) return 5;
+    printf("STEREO GIF Module Times:\nCVC Time:\t %4.2f ms\nCVF Time:\t %4.2f ms\nDispSel Time:\t %4.2f ms\nPP Time:\t %4.2f ms\n",
+           SMDE.stageTimeUs(PSM_STAGE_CVC) / 1000, SMDE.stageTimeUs(PSM_STAGE_CVF) / 1000,
+           SMDE.stageTimeUs(PSM_STAGE_DISPSEL) / 1000, SMDE.stageTimeUs(PSM_STAGE_PP) / 1000);
+    bool ok = dump(out + "_ldisp.raw", SMDE.lDisMap.data, (size_t)W * H) && dump(out + "_rdisp.raw", SMDE.rDisMap.data, (size_t)W * H) &&
+              dump(out + "_lvalid.raw", SMDE.lValid.data, (size_t)W * H) && dump(out + "_rvalid.raw", SMDE.rValid.data, (size_t)W * H);
+    return ok ? 0 : 6;
+}

@@ -1,0 +1,71 @@
+"""world_size-2 (and 3) CPU test of the N > 1 exchange protocol with the gloo backend: every
+rank runs the local WTA of its disparity shard (CPU oracle standing in for k_wta), packs the
+keys exactly as the device does, ONE all_gather, signed minimum -> must equal the unsharded
+DispSel::CVSelect result.  The GPU flavour of the same steps is bench.py --gpus N (RCCL)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import ROOT
+
+
+def _worker(rank, world, port, D, H, W, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from oracle import psm_oracle_py as O
+        from primestereomatch_amd.shard import pack_keys, shard_bounds, unpack_disp
+        rng = np.random.default_rng(123)                       # same volume on every rank
+        vol = rng.integers(0, 5, size=(2, D, H, W)).astype(np.float32)   # many ties
+        vol[0, :, 0, 0] = np.nan
+        vol[1, min(3, D - 1), 1, 1] = -0.0
+        d0, d1 = shard_bounds(D, world)[rank]
+        keys = np.empty((2, H, W), np.int64)
+        for side in range(2):
+            if d1 > d0:
+                c, d = O.wta_partial(vol[side, d0:d1], d0, d1)
+            else:
+                c, d = np.full((H, W), np.inf, np.float32), np.zeros((H, W), np.int32)
+            keys[side] = pack_keys(c, d)
+        local = torch.from_numpy(keys.reshape(-1))
+        gathered = torch.empty(world * local.numel(), dtype=torch.int64)
+        dist.all_gather_into_tensor(gathered, local)            # the one exchange step
+        best = gathered.view(world, -1).min(dim=0).values.numpy()
+        maps = unpack_disp(best).reshape(2, H, W)
+        ref = np.stack([O.wta(vol[0]), O.wta(vol[1])])
+        q.put((rank, bool(np.array_equal(maps, ref))))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,D", [(2, 16), (3, 7), (2, 1)])
+def test_allgather_min_reproduces_wta(world, D):
+    from oracle import psm_oracle_py as O
+    O.build()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29600 + world * 10 + D
+    procs = [ctx.Process(target=_worker, args=(r, world, port, D, 9, 13, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=60) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert all(ok for _, ok in res), res
+
+
+def test_pack_keys_order():
+    from primestereomatch_amd.shard import pack_keys, unpack_disp
+    c = np.array([np.inf, 1.0, 1.0, -2.0, 0.0, -0.0, 3e-39], np.float32)
+    d = np.array([0, 5, 4, 9, 7, 6, 2], np.int32)
+    k = pack_keys(c, d)
+    order = np.argsort(k, kind="stable")
+    assert list(order) == [3, 5, 4, 6, 2, 1, 0]     # -2 < (+-0: d=6 < d=7) < denormal < (1.0: d=4 < d=5) < inf
+    assert np.array_equal(unpack_disp(k), d.astype(np.uint8))

@@ -1,0 +1,436 @@
+"""-m gpu parity tests: the HIP path (through the C ABI, via the DispEst mirror) against the CPU
+oracle on the same seeded inputs, against the committed golden fixtures, and - at BASELINE.json
+sizes - through size-independent properties.
+
+Bar (north_star): float mode within 1e-4 of the CPU path, WTA maps identical; 8-bit mode
+bit-exact.  Because the kernels evaluate the oracle's canonical arithmetic (same fp64 tree
+order, uncontracted fp32) the float results are in fact expected to be bit-identical; the
+`exact` assertions below hold the kernels to that."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-4  # north_star: "within 1e-4 in 32-bit float mode"
+
+
+@pytest.fixture(scope="module")
+def psm():
+    from primestereomatch_amd import capi
+    capi.load()
+    assert capi.device_count() >= 1, "no HIP device visible"
+    import primestereomatch_amd as P
+    return P
+
+
+def rand_pair(H, W, seed):
+    rng = np.random.default_rng(seed)
+    l = rng.integers(0, 256, size=(H, W, 3), dtype=np.uint8)
+    r = rng.integers(0, 256, size=(H, W, 3), dtype=np.uint8)
+    # a flat patch exercises the ill-conditioned (det ~ eps^3) regime of the solve
+    l[H // 4:H // 2, W // 4:W // 2] = 77
+    r[H // 4:H // 2, W // 4:W // 2] = 77
+    return l, r
+
+
+def report(name, a, b):
+    d = np.abs(a.astype(np.float64) - b.astype(np.float64))
+    print(f"[parity] {name}: max|d|={d.max():.3e}  frac>1e-4={np.mean(d > TOL):.3e}  "
+          f"bit-mismatch={np.mean(a != b):.3e}")
+    return d.max()
+
+
+# ------------------------------------------------------------------------------------------
+# stage by stage, small seeded inputs, both kernel variants
+# ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("H,W,D", [(24, 40, 8), (37, 61, 5), (64, 130, 16), (8, 8, 3)])
+def test_cvc_bit_exact(psm, oracle, H, W, D):
+    l, r = rand_pair(H, W, 1)
+    with psm.DispEst(l, r, D) as de:
+        de.CostConst_GPU()
+        gl, gr = de.download_volume(0), de.download_volume(1)
+        g = de.download_guidance(0)
+    ref = oracle.pipeline_f32(l, r, D, threads=4, want_raw=True)
+    lf = oracle.u8_to_f32(l)
+    assert np.array_equal(g[:3], lf.transpose(2, 0, 1))          # planarised, scaled by 1/255.0f
+    assert np.array_equal(g[3], oracle.cvc_preprocess(lf))       # x-gradient of gray
+    assert np.array_equal(gl, ref["raw_l"]) and np.array_equal(gr, ref["raw_r"])
+
+
+def test_cvc_float_images(psm, oracle):
+    """setInputImages with CV_32F images, as StereoMatch::compute passes them."""
+    l, r = rand_pair(20, 33, 2)
+    lf, rf = oracle.u8_to_f32(l), oracle.u8_to_f32(r)
+    with psm.DispEst(lf, rf, 6) as de:
+        de.CostConst_GPU()
+        gl = de.download_volume(0)
+    ref = oracle.pipeline_f32(l, r, 6, threads=2, want_raw=True)
+    assert np.array_equal(gl, ref["raw_l"])
+
+
+def _expected_guidance(oracle, img_f32):
+    rgb, mean, var = oracle.cvf_preprocess(img_f32)
+    eps = np.float32(1e-4)
+    a11, a12, a13 = var[0] + eps, var[1], var[2]
+    a21, a22, a23 = var[1], var[3] + eps, var[4]
+    a31, a32, a33 = var[2], var[4], var[5] + eps
+    det = (a11 * (a33 * a22 - a32 * a23) - a21 * (a33 * a12 - a32 * a13)) + a31 * (a23 * a12 - a22 * a13)
+    inv = np.float32(1) / det
+    A = [a33 * a22 - a32 * a23, a31 * a23 - a33 * a21, a32 * a21 - a31 * a22,
+         a33 * a11 - a31 * a13, a31 * a12 - a32 * a11, a22 * a11 - a21 * a12]
+    return mean, inv, A
+
+
+@pytest.mark.parametrize("H,W", [(24, 40), (37, 61), (8, 9)])
+def test_guidance_bit_exact(psm, oracle, H, W):
+    l, r = rand_pair(H, W, 3)
+    vol = np.zeros((2, H, W), np.float32)
+    with psm.DispEst(l, r, 2) as de:
+        de.upload_volume(0, vol)
+        de.filter_stage_a(0)
+        g = de.download_guidance(0)
+    mean, inv, A = _expected_guidance(oracle, oracle.u8_to_f32(l))
+    assert np.array_equal(g[4:7], mean)
+    assert np.array_equal(g[7], inv)
+    for k in range(6):
+        assert np.array_equal(g[8 + k], A[k]), k
+
+
+@pytest.mark.parametrize("variant", [0, 1])
+@pytest.mark.parametrize("D,H,W,seg,waves", [(3, 19, 70, 0, 4), (5, 33, 130, 8, 2), (2, 8, 8, 3, 1),
+                                             (9, 40, 57, 16, 8), (4, 64, 200, 0, 4)])
+def test_box8_volume(psm, oracle, variant, D, H, W, seg, waves):
+    from primestereomatch_amd import capi, synth
+    vol = synth.random_volume(D, H, W, seed=11)
+    l, r = rand_pair(H, W, 4)
+    with psm.DispEst(l, r, D) as de:
+        de.set_option(capi.PSM_OPT_KERNEL_VARIANT, variant)
+        de.set_option(capi.PSM_OPT_SEG_ROWS, seg)
+        de.set_option(capi.PSM_OPT_WAVES, waves)
+        de.upload_volume(1, vol)
+        out = de.box8_volume(1)
+    ref = np.stack([oracle.box8(vol[d]) for d in range(D)])
+    assert report(f"box8 v{variant}", out, ref) <= 1e-6
+    assert np.array_equal(out, ref)
+
+
+@pytest.mark.parametrize("variant", [0, 1])
+@pytest.mark.parametrize("H,W,D,seg,waves", [(24, 40, 6, 0, 4), (37, 61, 5, 8, 2), (64, 130, 9, 16, 8), (8, 8, 2, 0, 1)])
+def test_cvf_stages(psm, oracle, variant, H, W, D, seg, waves):
+    from primestereomatch_amd import capi
+    l, r = rand_pair(H, W, 5)
+    rng = np.random.default_rng(6)
+    vol = (rng.random((D, H, W), dtype=np.float32) * 2.7).astype(np.float32)
+    with psm.DispEst(l, r, D) as de:
+        de.set_option(capi.PSM_OPT_KERNEL_VARIANT, variant)
+        de.set_option(capi.PSM_OPT_SEG_ROWS, seg)
+        de.set_option(capi.PSM_OPT_WAVES, waves)
+        de.upload_volume(0, vol)
+        de.upload_volume(1, vol)
+        de.filter_stage_a(0)
+        ab = de.download_ab()
+        de.CostFilter_GPU()
+        ql, qr = de.download_volume(0), de.download_volume(1)
+    for side, (img, q) in enumerate(((l, ql), (r, qr))):
+        rgb, mean, var = oracle.cvf_preprocess(oracle.u8_to_f32(img))
+        for d in range(D):
+            qref, abref = oracle.guided_filter(rgb, mean, var, vol[d], want_ab=True)
+            if side == 0:
+                m = report(f"ab v{variant} d{d}", ab[d], abref.transpose(1, 2, 0))
+                assert np.array_equal(ab[d], abref.transpose(1, 2, 0))
+            assert report(f"q v{variant} side{side} d{d}", q[d], qref) <= TOL
+            assert np.array_equal(q[d], qref)
+
+
+def test_wta_semantics_on_device(psm, oracle):
+    D, H, W = 6, 9, 12
+    l, r = rand_pair(H, W, 7)
+    vol = np.full((D, H, W), 5.0, np.float32)
+    vol[0] = -1.0
+    vol[3, 1, 2] = vol[4, 1, 2] = 4.0
+    vol[:, 0, 0] = np.nan
+    vol[2, 5, 5], vol[4, 5, 5] = 0.0, -0.0   # +0 and -0 tie: lowest d wins
+    with psm.DispEst(l, r, D) as de:
+        de.upload_volume(0, vol)
+        de.upload_volume(1, vol[::-1].copy())
+        de.DispSelect_GPU()
+        assert np.array_equal(de.lDisMap, oracle.wta(vol))
+        assert np.array_equal(de.rDisMap, oracle.wta(vol[::-1].copy()))
+        assert de.lDisMap[0, 0] == 0 and de.lDisMap[1, 2] == 3 and de.lDisMap[5, 5] == 2
+
+
+# ------------------------------------------------------------------------------------------
+# whole path
+# ------------------------------------------------------------------------------------------
+def run_pipeline(psm, l, r, D, **kw):
+    with psm.DispEst(l, r, D, **kw) as de:
+        de.setThreads(8)
+        de.CostConst_GPU()
+        de.CostFilter_GPU()
+        de.DispSelect_GPU()
+        return de.lDisMap.copy(), de.rDisMap.copy(), de.download_volume(0), de.download_volume(1)
+
+
+@pytest.mark.parametrize("H,W,D,seed", [(48, 64, 16, 0), (61, 97, 21, 1), (120, 160, 32, 2)])
+def test_pipeline_synthetic(psm, oracle, H, W, D, seed):
+    from primestereomatch_amd import synth
+    l, r, _ = synth.make_pair(W, H, D, seed)
+    ld, rd, lv, rv = run_pipeline(psm, l, r, D)
+    ref = oracle.pipeline_f32(l, r, D, threads=8, want_volumes=True)
+    assert report("pipeline lvol", lv, ref["lvol"]) <= TOL and report("pipeline rvol", rv, ref["rvol"]) <= TOL
+    assert np.array_equal(lv, ref["lvol"]) and np.array_equal(rv, ref["rvol"])
+    assert np.array_equal(ld, ref["ldisp"]) and np.array_equal(rd, ref["rdisp"])
+
+
+@pytest.mark.parametrize("name", ["cones", "teddy"])
+def test_pipeline_middlebury_golden(psm, oracle, golden, name):
+    """BASELINE configs[0]/[1]: Cones / Teddy 450x375, D=64, float mode, vs the committed fixtures
+    (oracle outputs) - no oracle call needed for the maps, SHA-256 over the full volumes."""
+    import hashlib
+    pair, gold = golden(f"{name}_pair.npz"), golden(f"{name}_oracle_d64.npz")
+    man = json.load(open(os.path.join(GOLDEN, "manifest.json")))[name.capitalize()]
+    ld, rd, lv, rv = run_pipeline(psm, pair["l_bgr"], pair["r_bgr"], 64)
+    assert report(f"{name} lvol d17", lv[17], gold["lvol_d17"]) <= TOL
+    assert report(f"{name} rvol d17", rv[17], gold["rvol_d17"]) <= TOL
+    assert np.array_equal(ld, gold["ldisp"]) and np.array_equal(rd, gold["rdisp"])
+    assert hashlib.sha256(lv.tobytes()).hexdigest() == man["sha256"]["lvol"]
+    assert hashlib.sha256(rv.tobytes()).hexdigest() == man["sha256"]["rvol"]
+    bad, _ = oracle.eval_bad_pixels(ld, pair["gt_l"], pair["occl"], 64, 4, 4)
+    assert bad == man["bad_pixels_thr4_nonocc"]
+
+
+def test_pipeline_cones_crop_384x288(psm, oracle, golden):
+    """BASELINE configs[0] quotes 384x288; the shipped images are 450x375 - run the top-left crop too."""
+    pair = golden("cones_pair.npz")
+    l = np.ascontiguousarray(pair["l_bgr"][:288, :384])
+    r = np.ascontiguousarray(pair["r_bgr"][:288, :384])
+    ld, rd, lv, rv = run_pipeline(psm, l, r, 64)
+    ref = oracle.pipeline_f32(l, r, 64, threads=8, want_volumes=True)
+    assert np.array_equal(lv, ref["lvol"]) and np.array_equal(rv, ref["rvol"])
+    assert np.array_equal(ld, ref["ldisp"]) and np.array_equal(rd, ref["rdisp"])
+
+
+@pytest.mark.parametrize("name", ["cones", "teddy"])
+def test_u8_mode_bit_exact(psm, oracle, golden, name):
+    """8-bit char mode (BASELINE configs[0]): bit-exact against the CPU statement of the same
+    build-defined contract (the reference has no CPU 8-bit path - DESIGN.md)."""
+    pair, gold = golden(f"{name}_pair.npz"), golden(f"{name}_oracle_d64.npz")
+    ld, rd, lv, rv = run_pipeline(psm, pair["l_bgr"], pair["r_bgr"], 64, dtype="u8")
+    assert lv.dtype == np.uint8
+    assert np.array_equal(ld, gold["ldisp_u8mode"]) and np.array_equal(rd, gold["rdisp_u8mode"])
+    if name == "cones":
+        assert np.array_equal(lv[17], gold["lvol8_d17"])
+    ref = oracle.pipeline_u8(pair["l_bgr"], pair["r_bgr"], 64, threads=8, want_volumes=True)
+    assert np.array_equal(lv, ref["lvol"]) and np.array_equal(rv, ref["rvol"])
+
+
+def test_u8_mode_small_and_raw(psm, oracle):
+    l, r = rand_pair(33, 47, 8)
+    with psm.DispEst(l, r, 12, dtype="u8") as de:
+        de.CostConst_GPU()
+        raw_l, raw_r = de.download_volume(0), de.download_volume(1)
+        de.CostFilter_GPU()
+        de.DispSelect_GPU()
+        ref = oracle.pipeline_u8(l, r, 12, threads=3, want_volumes=True, want_raw=True)
+        assert np.array_equal(raw_l, ref["raw_l"]) and np.array_equal(raw_r, ref["raw_r"])
+        assert np.array_equal(de.download_volume(0), ref["lvol"])
+        assert np.array_equal(de.lDisMap, ref["ldisp"]) and np.array_equal(de.rDisMap, ref["rdisp"])
+
+
+# ------------------------------------------------------------------------------------------
+# disparity sharding (logical shards on one GPU; the RCCL flavour is bench.py --gpus N)
+# ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("G", [2, 3, 8])
+def test_logical_shards_equal_unsharded(psm, oracle, G):
+    from primestereomatch_amd import synth
+    H, W, D = 40, 72, 19
+    l, r, _ = synth.make_pair(W, H, D, 3)
+    ld, rd, lv, rv = run_pipeline(psm, l, r, D)
+    bounds = [D * g // G for g in range(G + 1)]
+    shards = [psm.DispEst(l, r, D, d_range=(bounds[g], bounds[g + 1])) for g in range(G) if bounds[g] < bounds[g + 1]]
+    try:
+        for s in shards:
+            s.CostConst_GPU()
+            s.CostFilter_GPU()
+            s.DispSelect_partial()
+            assert np.array_equal(s.download_volume(0), lv[s.d_begin:s.d_end])
+        root = shards[0]
+        root.DispSelect_merge_ctx(shards)
+        assert np.array_equal(root.lDisMap, ld) and np.array_equal(root.rDisMap, rd)
+        with pytest.raises(Exception):
+            shards[-1].DispSelect_GPU()      # unsharded select on a shard must refuse
+    finally:
+        for s in shards:
+            s.close()
+
+
+def test_lr_check_on_device(psm, oracle, golden):
+    pair = golden("teddy_pair.npz")
+    with psm.DispEst(pair["l_bgr"], pair["r_bgr"], 64) as de:
+        de.CostConst_GPU()
+        de.CostFilter_GPU()
+        de.DispSelect_GPU()
+        de.LRCheck_GPU()
+        lv, rv = oracle.lr_check(de.lDisMap, de.rDisMap)
+        assert np.array_equal(de.lValid, lv) and np.array_equal(de.rValid, rv)
+        assert 0.3 < lv.mean() < 1.0
+
+
+# ------------------------------------------------------------------------------------------
+# interface behaviour (error conventions of the _cl wrappers: non-zero + message)
+# ------------------------------------------------------------------------------------------
+def test_error_paths(psm):
+    from primestereomatch_amd import capi
+    l, r = rand_pair(16, 16, 9)
+    with pytest.raises(capi.PsmError):
+        psm.DispEst(l[:4], r[:4], 8)                       # smaller than the filter window
+    with pytest.raises(capi.PsmError):
+        psm.DispEst(l, r, 300)                             # maps are 8-bit
+    with pytest.raises(capi.PsmError):
+        psm.DispEst(l, r, 8, d_range=(4, 4))               # empty shard
+    with pytest.raises(ValueError):
+        psm.DispEst(l, r.astype(np.float32), 8)            # mismatching types (src/DispEst.cpp:21-29)
+    with psm.DispEst(l, r, 8) as de:
+        assert de.setThreads(9) == -1 and de.setThreads(8) == 0   # src/DispEst.cpp:172-179
+        with pytest.raises(capi.PsmError):
+            de.CostFilter_GPU()                            # no cost volume yet
+        with pytest.raises(capi.PsmError):
+            de.download_volume(0, 0, 9)
+        with pytest.raises(capi.PsmError):
+            de.LRCheck_GPU()
+        de.CostConst_GPU()
+        de.CostFilter_GPU()
+        de.DispSelect_GPU()
+        first = de.lDisMap.copy()
+        de.CostConst_GPU(); de.CostFilter_GPU(); de.DispSelect_GPU()   # idempotent across frames
+        assert np.array_equal(first, de.lDisMap)
+        assert de.stage_time_us(capi.PSM_STAGE_CVF) > 0
+
+
+def test_strided_host_images_and_maps(psm, oracle):
+    l, r = rand_pair(20, 30, 10)
+    big_l = np.zeros((20, 64, 3), np.uint8); big_l[:, :30] = l
+    big_r = np.zeros((20, 64, 3), np.uint8); big_r[:, :30] = r
+    ref = oracle.pipeline_f32(l, r, 8, threads=2)
+    with psm.DispEst(l, r, 8) as de:
+        import ctypes as C
+        lib = psm.capi.load()
+        rc = lib.psm_upload_pair(de._h, big_l.ctypes.data_as(C.c_void_p), big_r.ctypes.data_as(C.c_void_p), 3, big_l.strides[0], 0)
+        assert rc == 0
+        de.CostConst_GPU(); de.CostFilter_GPU()
+        lm = np.zeros((20, 48), np.uint8); rm = np.zeros((20, 48), np.uint8)
+        rc = lib.psm_disp_select(de._h, lm.ctypes.data_as(C.c_void_p), rm.ctypes.data_as(C.c_void_p), 48)
+        assert rc == 0
+        assert np.array_equal(lm[:, :30], ref["ldisp"]) and np.array_equal(rm[:, :30], ref["rdisp"])
+        assert not lm[:, 30:].any()
+
+
+# ------------------------------------------------------------------------------------------
+# BASELINE.json full sizes: size-independent properties + oracle on a band of slices/rows
+# ------------------------------------------------------------------------------------------
+def _full_size_checks(psm, oracle, W, H, D, d_lo, d_hi, band):
+    from primestereomatch_amd import capi, synth
+    l, r, gt = synth.make_pair(W, H, D, seed=0)
+    with psm.DispEst(l, r, D, d_range=(d_lo, d_hi)) as de:
+        de.CostConst_GPU()
+        raw = de.download_volume(0)
+        de.CostFilter_GPU()
+        q = de.download_volume(0)
+        qr = de.download_volume(1)
+        # (1) linearity: every op of the filter commutes exactly with a power-of-two scale
+        de.upload_volume(0, raw * np.float32(4.0))
+        de.upload_volume(1, raw)
+        de.CostFilter_GPU()
+        assert np.array_equal(de.download_volume(0), q * np.float32(4.0))
+        # (2) the marching and the direct formulation agree bit for bit on a few slices
+        de.set_option(capi.PSM_OPT_KERNEL_VARIANT, 1)
+        de.upload_volume(0, raw)
+        de.CostFilter_GPU()
+        assert np.array_equal(de.download_volume(0), q)
+    # (3) oracle on a row band (the filter's support is +-8 rows, CVC is row-local)
+    y0, y1 = band
+    pad = 24
+    ya, yb = max(0, y0 - pad), min(H, y1 + pad)
+    lf, rf = oracle.u8_to_f32(l[ya:yb]), oracle.u8_to_f32(r[ya:yb])
+    lG, rG = oracle.cvc_preprocess(lf), oracle.cvc_preprocess(rf)
+    if ya == 0 and yb == H:
+        rgb, mean, var = oracle.cvf_preprocess(lf)
+        for d in (d_lo, d_hi - 1):
+            p = oracle.cvc_build(lf, rf, lG, rG, d)
+            assert np.array_equal(raw[d - d_lo, ya:yb], p)
+            qq = oracle.guided_filter(rgb, mean, var, p)
+            assert report(f"full-size d{d}", q[d - d_lo], qq) <= TOL
+            assert np.array_equal(q[d - d_lo], qq)
+    else:
+        # interior rows of the band are unaffected by the crop's artificial borders
+        rgb, mean, var = oracle.cvf_preprocess(lf)
+        for d in (d_lo, d_hi - 1):
+            p = oracle.cvc_build(lf, rf, lG, rG, d)
+            assert np.array_equal(raw[d - d_lo, ya:yb], p)
+            qq = oracle.guided_filter(rgb, mean, var, p)
+            sl = slice(y0 - ya, y1 - ya)
+            assert report(f"full-size d{d}", q[d - d_lo, y0:y1], qq[sl]) <= TOL
+            assert np.array_equal(q[d - d_lo, y0:y1], qq[sl])
+    return qr
+
+
+def test_full_size_c3_1280x720(psm, oracle):
+    _full_size_checks(psm, oracle, 1280, 720, 128, 60, 68, (300, 380))
+
+
+def test_full_size_c4_1920x1080(psm, oracle):
+    _full_size_checks(psm, oracle, 1920, 1080, 256, 200, 206, (0, 64))
+
+
+def test_full_size_c4_sharded_wta_consistency(psm):
+    """1920x1080x256 on one GPU: unsharded maps == 4 logical shards merged (checksum of maps)."""
+    from primestereomatch_amd import synth
+    W, H, D = 1920, 1080, 256
+    l, r, gt = synth.make_pair(W, H, D, seed=1)
+    with psm.DispEst(l, r, D) as de:
+        de.CostConst_GPU(); de.CostFilter_GPU(); de.DispSelect_GPU()
+        ld, rd = de.lDisMap.copy(), de.rDisMap.copy()
+    assert ld.max() < D and ld.min() >= 0
+    # quality sanity: the filtered WTA recovers the ground-truth disparity on most textured pixels
+    assert np.mean(np.abs(ld.astype(np.int32) - gt)[:, D:] <= 1) > 0.5
+    shards = [psm.DispEst(l, r, D, d_range=(64 * g, 64 * (g + 1))) for g in range(4)]
+    try:
+        for s in shards:
+            s.CostConst_GPU(); s.CostFilter_GPU(); s.DispSelect_partial()
+        shards[0].DispSelect_merge_ctx(shards)
+        assert np.array_equal(shards[0].lDisMap, ld) and np.array_equal(shards[0].rDisMap, rd)
+    finally:
+        for s in shards:
+            s.close()
+
+
+# ------------------------------------------------------------------------------------------
+# C++ host mirror (hipUtil dlopen loader + DispEst class) through the same C ABI
+# ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("mode,float_input", [("f32", 0), ("f32", 1), ("u8", 0)])
+def test_cpp_dispest_demo(psm, oracle, golden, tmp_path, mode, float_input):
+    import subprocess
+    from conftest import ROOT
+    demo = os.path.join(ROOT, "primestereomatch_amd", "lib", "psm_demo")
+    if not os.path.exists(demo):
+        subprocess.run(["make", "-C", os.path.join(ROOT, "primestereomatch_amd", "host")], check=True)
+    pair, gold = golden("teddy_pair.npz"), golden("teddy_oracle_d64.npz")
+    H, W, _ = pair["l_bgr"].shape
+    pair["l_bgr"].tofile(tmp_path / "l.raw")
+    pair["r_bgr"].tofile(tmp_path / "r.raw")
+    env = dict(os.environ, PRIMESM_HIP_LIB=psm.capi.LIB_PATH)
+    p = subprocess.run([demo, str(tmp_path / "l.raw"), str(tmp_path / "r.raw"), str(W), str(H), "64",
+                        str(tmp_path / "o"), "1", mode, str(float_input)], env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr
+    assert "CVF Time" in p.stdout
+    ld = np.fromfile(tmp_path / "o_ldisp.raw", np.uint8).reshape(H, W)
+    rd = np.fromfile(tmp_path / "o_rdisp.raw", np.uint8).reshape(H, W)
+    key = ("ldisp", "rdisp") if mode == "f32" else ("ldisp_u8mode", "rdisp_u8mode")
+    assert np.array_equal(ld, gold[key[0]]) and np.array_equal(rd, gold[key[1]])
+    lv = np.fromfile(tmp_path / "o_lvalid.raw", np.uint8).reshape(H, W)
+    assert np.array_equal(lv, oracle.lr_check(ld, rd)[0])
