@@ -47,6 +47,7 @@ def main():
     ap.add_argument("--seg-rows", type=int, default=-1, help="marching-kernel y segment (-1: library default)")
     ap.add_argument("--waves", type=int, default=0, help="waves per workgroup (0: library default)")
     ap.add_argument("--variant", type=int, default=0)
+    ap.add_argument("--flags", type=int, default=-1, help="PSM_OPT_FLAGS tuning bits (-1: library default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-d", type=int, default=24, help="disparities in the CPU-baseline sample")
     ap.add_argument("--force-dist", action="store_true", help="use the torch.distributed path even for N=1")
@@ -88,6 +89,8 @@ def main():
     if args.waves:
         de.set_option(capi.PSM_OPT_WAVES, args.waves)
     de.set_option(capi.PSM_OPT_KERNEL_VARIANT, args.variant)
+    if args.flags >= 0:
+        de.set_option(capi.PSM_OPT_FLAGS, args.flags)
     de.set_option(capi.PSM_OPT_ASYNC, 1)
 
     keys_local = keys_all = None

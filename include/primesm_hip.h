@@ -50,7 +50,8 @@ enum {
     PSM_OPT_KERNEL_VARIANT = 1, /* 0: marching kernels (default), 1: direct per-voxel kernels */
     PSM_OPT_PROFILE = 2,        /* 1: bracket every kernel launch with hipEvents              */
     PSM_OPT_SEG_ROWS = 3,       /* rows per y-segment of the marching kernels (0 = auto)      */
-    PSM_OPT_WAVES = 4           /* waves (disparity slices) per workgroup: 1,2,4,8            */
+    PSM_OPT_WAVES = 4,          /* waves (disparity slices) per workgroup: 1,2,4,8            */
+    PSM_OPT_FLAGS = 5           /* tuning bits: 1 = nontemporal stores of 4-byte outputs      */
 };
 
 /* Number of usable HIP devices; 0 if none.  Replaces openCLdevicepoll()

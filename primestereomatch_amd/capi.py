@@ -19,7 +19,7 @@ PSM_LEFT, PSM_RIGHT = 0, 1
 PSM_STAGE_CVC, PSM_STAGE_CVF, PSM_STAGE_DISPSEL, PSM_STAGE_PP = 0, 1, 2, 3
 (PSM_K_PREP, PSM_K_CVC, PSM_K_GUIDE, PSM_K_CVF_A, PSM_K_CVF_B, PSM_K_WTA, PSM_K_MERGE, PSM_K_BOX,
  PSM_K_LRC) = range(9)
-PSM_OPT_ASYNC, PSM_OPT_KERNEL_VARIANT, PSM_OPT_PROFILE, PSM_OPT_SEG_ROWS, PSM_OPT_WAVES = range(5)
+PSM_OPT_ASYNC, PSM_OPT_KERNEL_VARIANT, PSM_OPT_PROFILE, PSM_OPT_SEG_ROWS, PSM_OPT_WAVES, PSM_OPT_FLAGS = range(6)
 
 # every symbol include/primesm_hip.h declares: (name, restype, argtypes)
 _vp, _i, _sz = C.c_void_p, C.c_int, C.c_size_t

@@ -55,7 +55,7 @@ struct psm_ctx {
 
     // options
     int opt_async = 0, opt_variant = 0, opt_profile = 0;
-    March march = {0, 4};
+    March march = {0, 4, 0};
 
     double stage_us[PSM_STAGE_COUNT] = {0, 0, 0, 0};
     KernelTimer timers[PSM_K_COUNT];
@@ -303,6 +303,7 @@ int psm_set_option(psm_ctx *c, int option, int value)
     case PSM_OPT_WAVES:
         if (value != 1 && value != 2 && value != 4 && value != 8) return fail(c, "psm_set_option: waves %d not in {1,2,4,8}", value);
         c->march.waves = value; return 0;
+    case PSM_OPT_FLAGS: c->march.flags = value; return 0;
     default: return fail(c, "psm_set_option: unknown option %d", option);
     }
 }
@@ -362,7 +363,7 @@ int psm_cost_construct(psm_ctx *c)
         if (c->dtype == PSM_U8)
             launch_cvc_u8(c->stream, c->p4[s], c->p4[1 - s], (uint8_t *)c->vol[s], c->W, c->H, c->d0, c->Dloc, s);
         else
-            launch_cvc(c->stream, c->g[s].g1, c->g[1 - s].g1, (float *)c->vol[s], c->W, c->H, c->d0, c->Dloc, s);
+            launch_cvc(c->stream, c->g[s].g1, c->g[1 - s].g1, (float *)c->vol[s], c->W, c->H, c->d0, c->Dloc, s, c->march.flags);
     }
     if (check_launch(c, "cvc")) return 1;
     c->have_cost = true;

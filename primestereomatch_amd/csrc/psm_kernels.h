@@ -19,8 +19,10 @@ struct Guidance {
 };
 
 struct March {       // geometry of the marching kernels
-    int seg_rows;    // output rows per y-segment
+    int seg_rows;    // output rows per y-segment (0 = auto)
     int waves;       // waves (= disparity slices) per workgroup: 1,2,4,8
+    int flags;       // bit 0: nontemporal stores of 4-byte outputs; bits 1-2: block traversal order;
+                     // bit 3: 16-byte-store CVC kernel
 };
 
 // image -> g1 (planarise, scale, gray, x-gradient).  src: device copy of the interleaved image.
@@ -29,7 +31,7 @@ void launch_prep(hipStream_t s, const void *src, size_t pitch, int depth_f32, in
 void launch_guidance(hipStream_t s, Guidance g, double *hs9, int W, int H);
 // cost volume slices [d_begin, d_begin+Dloc) of one side.  base: g1 of the side's own image.
 void launch_cvc(hipStream_t s, const float4 *g1_base, const float4 *g1_other, float *vol, int W, int H,
-                int d_begin, int Dloc, int right);
+                int d_begin, int Dloc, int right, int flags);
 // guided filter halves.  variant 0 = marching, 1 = direct per-voxel.
 void launch_cvf_a(hipStream_t s, int variant, March m, const float *vol, float4 *ab, Guidance g, int W,
                   int H, int Dloc);

@@ -10,7 +10,7 @@
 // src/DispSel.cpp:83-109, src/PP.cpp:17-50 (paths in the reference repository).
 //
 // Kernel design (DESIGN.md "Kernels"): the guided filter's two box-filter rounds are "marching"
-// kernels: one wave owns 64 adjacent columns of one disparity slice (57 outputs + 7 halo) and
+// kernels: one wave owns 64 adjacent columns of one disparity slice (56 outputs + 8 halo) and
 // walks down the rows.  Horizontal 8-tap sums are built with three cross-lane exchanges
 // (distance 1, 2, 4: a sliding balanced tree, 3 fp64 adds per output), vertical sums with a
 // register-resident sliding tree (7 doubles of state per channel, 3 fp64 adds per output).
@@ -280,9 +280,55 @@ __global__ __launch_bounds__(256) void k_cvc(const float4 *__restrict__ base, co
     }
 }
 
-void launch_cvc(hipStream_t s, const float4 *g1_base, const float4 *g1_other, float *vol, int W, int H,
-                int d_begin, int Dloc, int right)
+// Four consecutive pixels per thread -> one 16-byte store per lane: a wave then writes whole
+// 128-byte lines in one request and the L2 does not fill them from HBM first (dword stores did:
+// k_cvc read as many bytes as it wrote).  Needs W % 4 == 0.
+template <bool RIGHT>
+__global__ __launch_bounds__(256) void k_cvc4(const float4 *__restrict__ base, const float4 *__restrict__ other,
+                                             float *__restrict__ vol, int W, int H, int d_begin, int Dloc)
 {
+    int x = (blockIdx.x * blockDim.x + threadIdx.x) * 4, y = blockIdx.y;
+    int dl0 = blockIdx.z * CVC_DC;
+    if (x >= W) return;
+    const size_t HW = (size_t)H * W;
+    const size_t row = (size_t)y * W;
+    float4 a[4];
+    float cb[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        a[j] = base[row + x + j];
+        cb[j] = cost_border(a[j]);
+    }
+#pragma unroll
+    for (int k = 0; k < CVC_DC; ++k) {
+        int dl = dl0 + k;
+        if (dl >= Dloc) break;
+        int d = d_begin + dl;
+        float c[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            int xx = x + j;
+            if (RIGHT) {
+                if (xx < W - d) c[j] = cost_pair(a[j], other[row + xx + d]); else c[j] = cb[j];
+            } else {
+                if (xx >= d) c[j] = cost_pair(a[j], other[row + xx - d]); else c[j] = cb[j];
+            }
+        }
+        *reinterpret_cast<float4 *>(vol + (size_t)dl * HW + row + x) = make_float4(c[0], c[1], c[2], c[3]);
+    }
+}
+
+void launch_cvc(hipStream_t s, const float4 *g1_base, const float4 *g1_other, float *vol, int W, int H,
+                int d_begin, int Dloc, int right, int flags)
+{
+    if ((flags & 8) && (W & 3) == 0) {
+        dim3 grid((W / 4 + 255) / 256, H, (Dloc + CVC_DC - 1) / CVC_DC);
+        if (right)
+            hipLaunchKernelGGL(k_cvc4<true>, grid, dim3(256), 0, s, g1_base, g1_other, vol, W, H, d_begin, Dloc);
+        else
+            hipLaunchKernelGGL(k_cvc4<false>, grid, dim3(256), 0, s, g1_base, g1_other, vol, W, H, d_begin, Dloc);
+        return;
+    }
     dim3 grid((W + 255) / 256, H, (Dloc + CVC_DC - 1) / CVC_DC);
     if (right)
         hipLaunchKernelGGL(k_cvc<true>, grid, dim3(256), 0, s, g1_base, g1_other, vol, W, H, d_begin, Dloc);
@@ -293,7 +339,9 @@ void launch_cvc(hipStream_t s, const float4 *g1_base, const float4 *g1_other, fl
 // ------------------------------------------------------------------------------------------
 // marching kernels
 // ------------------------------------------------------------------------------------------
-constexpr int OUT_PER_WAVE = 57;  // 64 lanes - 7 halo columns
+constexpr int OUT_PER_WAVE = 56;  // 64 lanes - 7 halo columns, rounded down to a multiple of 8 so that a
+                                  // wave-row of float4 outputs (896 B) starts and ends on 128-byte lines:
+                                  // measured 5.4 TB/s for aligned full-line stores vs 3.2 TB/s with 57
 
 struct MarchPos {
     int d, lane, cs, xo, y0, y1;
@@ -305,21 +353,45 @@ struct MarchPos {
 // (strip,segment) pairs and walks the slice groups of one pair back to back, so the pair's
 // guidance stays in that XCD's L2 while all D slices stream past it.  Speed only - nothing
 // depends on the placement.
+// Block -> (column strip, y segment, slice group).  Blocks are observed to be dispatched in id
+// order, round-robin over the 8 XCDs (block b -> XCD b%8).  `order` picks the traversal:
+//   0: every XCD owns a contiguous range of (strip,segment) pairs and walks the slice groups of
+//      one pair back to back (guidance stays in that XCD's L2; DRAM sees 1000+ scattered streams)
+//   1: every XCD owns a contiguous range of strips; ids sweep strips fastest, then slice groups,
+//      then segments: all XCDs work on the same rows of the same slices at the same time (whole
+//      image rows are fetched together -> DRAM page locality) and an XCD still re-uses the
+//      guidance of its few strips for every slice group.
+//   2: as 1 but segments before slice groups.
+// Speed only - nothing depends on the placement.
 template <int NW>
-__device__ __forceinline__ MarchPos march_pos(int W, int H, int Dloc, int nstrips, int nsegs, int seg_rows, int nzg)
+__device__ __forceinline__ MarchPos march_pos(int W, int H, int Dloc, int nstrips, int nsegs, int seg_rows, int nzg, int order)
 {
     MarchPos p;
-    const int npairs = nstrips * nsegs;
-    const int p8 = (npairs + 7) >> 3;
     int id = blockIdx.x;
     int xcd = id & 7, j = id >> 3;
-    int zg = j % nzg, pl = j / nzg;
-    int pair = xcd * p8 + pl;
+    int zg, strip, seg;
+    bool ok;
+    if (order == 0) {
+        const int npairs = nstrips * nsegs;
+        const int p8 = (npairs + 7) >> 3;
+        zg = j % nzg;
+        int pl = j / nzg;
+        int pair = xcd * p8 + pl;
+        ok = pl < p8 && pair < npairs;
+        strip = pair % nstrips;
+        seg = pair / nstrips;
+    } else {
+        const int s8 = (nstrips + 7) >> 3;   // strips per XCD
+        int sl = j % s8, rest = j / s8;
+        strip = xcd * s8 + sl;
+        if (order == 1) { zg = rest % nzg; seg = rest / nzg; }
+        else            { seg = rest % nsegs; zg = rest / nsegs; }
+        ok = strip < nstrips && seg < nsegs && zg < nzg;
+    }
     int wave = threadIdx.x >> 6;
     p.lane = threadIdx.x & 63;
     p.d = zg * NW + wave;
-    p.ok = pl < p8 && pair < npairs && p.d < Dloc;
-    int strip = pair % nstrips, seg = pair / nstrips;
+    p.ok = ok && p.d < Dloc;
     int x0 = strip * OUT_PER_WAVE;
     p.cs = r101c(x0 - 4 + p.lane, W);
     p.xo = x0 + p.lane;
@@ -334,14 +406,29 @@ __device__ __forceinline__ MarchPos march_pos(int W, int H, int Dloc, int nstrip
     const int i2 = ((pos.lane + 2) & 63) << 2;     \
     const int i4 = ((pos.lane + 4) & 63) << 2
 
+// The loops below are software pipelined by hand: at step s a wave first ISSUES the loads of step
+// s+3 (input row and output-side guidance, clamped addresses, no branches), then consumes the
+// registers of step s.  vmcnt retires in order, so the only wait per step is for data issued
+// three steps earlier; with 3-4 waves per SIMD that covers the HBM/L2 latency.  The 4-slot
+// register rings are indexed with compile-time constants (unroll by 4).
+//
+// Store policy: a wave-wide dword store reaches the L2 as four 64-byte partial-line writes and
+// each allocates the line with a fill read from HBM (measured: k_cvc read as many bytes as it
+// wrote).  NT = nontemporal stores for the 4-byte-per-lane outputs.
+template <bool NT>
+__device__ __forceinline__ void store_f32(float *p, float v)
+{
+    if (NT) __builtin_nontemporal_store(v, p); else *p = v;
+}
+
 // ---- stage A: p -> (a0,a1,a2,b) -------------------------------------------------------------
 template <int NW>
 __global__ __launch_bounds__(NW * 64) void k_cvf_a(const float *__restrict__ vol, float4 *__restrict__ ab,
                                                   const float4 *__restrict__ G1, const float4 *__restrict__ G2,
                                                   const float4 *__restrict__ G3, const float2 *__restrict__ G4,
-                                                  int W, int H, int Dloc, int nstrips, int nsegs, int seg_rows, int nzg)
+                                                  int W, int H, int Dloc, int nstrips, int nsegs, int seg_rows, int nzg, int order)
 {
-    const MarchPos pos = march_pos<NW>(W, H, Dloc, nstrips, nsegs, seg_rows, nzg);
+    const MarchPos pos = march_pos<NW>(W, H, Dloc, nstrips, nsegs, seg_rows, nzg, order);
     if (!pos.ok) return;
     PSM_LANE_IDX();
     const size_t HW = (size_t)H * W;
@@ -350,55 +437,113 @@ __global__ __launch_bounds__(NW * 64) void k_cvf_a(const float *__restrict__ vol
     VTree t0 = {}, t1 = {}, t2 = {}, t3 = {};
     const int n = (pos.y1 - pos.y0) + 7;
     const int ybase = pos.y0 - 4;
+    const int xoc = min(pos.xo, W - 1);
 
-    float pv[4];
-    float4 gv[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        size_t off = (size_t)r101c(ybase + k, H) * W + pos.cs;
-        pv[k] = vd[off];
-        gv[k] = G1[off];
+    float pin[4];      // p        at (input row, input column)
+    float4 gin[4];     // g1
+    float4 o2[4], o3[4];  // g2, g3 at (output row, output column)
+    float2 o4[4];
+#define PSM_ISSUE_A(SLOT, STEP)                                                         \
+    {                                                                                   \
+        const size_t off_ = (size_t)r101c(ybase + (STEP), H) * W + pos.cs;              \
+        pin[SLOT] = vd[off_];                                                           \
+        gin[SLOT] = G1[off_];                                                           \
+        int yo_ = ybase + (STEP) - 3;                                                   \
+        yo_ = yo_ < 0 ? 0 : (yo_ > H - 1 ? H - 1 : yo_);                                \
+        const size_t oo_ = (size_t)yo_ * W + xoc;                                       \
+        o2[SLOT] = G2[oo_];                                                             \
+        o3[SLOT] = G3[oo_];                                                             \
+        o4[SLOT] = G4[oo_];                                                             \
     }
+    PSM_ISSUE_A(0, 0) __builtin_amdgcn_sched_barrier(0);
+    PSM_ISSUE_A(1, 1) __builtin_amdgcn_sched_barrier(0);
+    PSM_ISSUE_A(2, 2) __builtin_amdgcn_sched_barrier(0);
     for (int i = 0; i < n; i += 4) {
-        float pc[4];
-        float4 gc[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) { pc[k] = pv[k]; gc[k] = gv[k]; }
-        if (i + 4 < n) {
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                size_t off = (size_t)r101c(ybase + i + 4 + k, H) * W + pos.cs;
-                pv[k] = vd[off];
-                gv[k] = G1[off];
-            }
-        }
 #define PSM_STEP_A(K)                                                                               \
     {                                                                                               \
-        const float p = pc[K];                                                                      \
-        double h0 = hsum8(p, i1, i2, i4);                                                           \
-        double h1 = hsum8(__fmul_rn(gc[K].x, p), i1, i2, i4);                                       \
-        double h2 = hsum8(__fmul_rn(gc[K].y, p), i1, i2, i4);                                       \
-        double h3 = hsum8(__fmul_rn(gc[K].z, p), i1, i2, i4);                                       \
-        double n0 = vstep<K>(t0, h0), n1 = vstep<K>(t1, h1), n2 = vstep<K>(t2, h2), n3 = vstep<K>(t3, h3); \
         const int step = i + K;                                                                     \
-        if (step >= 7 && step < n && pos.ovalid) {                                                  \
-            const size_t oo = (size_t)(ybase + step - 3) * W + pos.xo;                              \
-            float4 r = solve_ab(box_out(n0), box_out(n1), box_out(n2), box_out(n3), G2[oo], G3[oo], G4[oo]); \
-            abd[oo] = r;                                                                            \
-        }                                                                                           \
+        PSM_ISSUE_A((K + 3) & 3, step + 3)                                                          \
+        const float p = pin[K];                                                                     \
+        double h0 = hsum8(p, i1, i2, i4);                                                           \
+        double h1 = hsum8(__fmul_rn(gin[K].x, p), i1, i2, i4);                                      \
+        double h2 = hsum8(__fmul_rn(gin[K].y, p), i1, i2, i4);                                      \
+        double h3 = hsum8(__fmul_rn(gin[K].z, p), i1, i2, i4);                                      \
+        double n0 = vstep<K>(t0, h0), n1 = vstep<K>(t1, h1), n2 = vstep<K>(t2, h2), n3 = vstep<K>(t3, h3); \
+        float4 r = solve_ab(box_out(n0), box_out(n1), box_out(n2), box_out(n3), o2[K], o3[K], o4[K]); \
+        if (step >= 7 && step < n && pos.ovalid) abd[(size_t)(ybase + step - 3) * W + pos.xo] = r;  \
+        __builtin_amdgcn_sched_barrier(0);                                                          \
     }
         PSM_STEP_A(0) PSM_STEP_A(1) PSM_STEP_A(2) PSM_STEP_A(3)
 #undef PSM_STEP_A
     }
+#undef PSM_ISSUE_A
+}
+
+// ---- kernels with 4-byte outputs (stage B, plain box) ------------------------------------------
+// A wave-row of 56 floats is 224 bytes: 1.75 cache lines at an odd offset.  Written straight from
+// the lanes it costs partial-line writes plus a fill read per line (measured ~3 TB/s).  So the four
+// waves of a workgroup take four ADJACENT strips of one slice (224 columns = 7 full 128-byte lines),
+// park four rows of results in LDS and each wave then writes one merged row with 16-byte lane
+// stores: every global store covers whole, aligned lines.
+constexpr int X4_COLS = 4 * OUT_PER_WAVE;  // 224 output columns per workgroup
+
+struct MarchPosX4 {
+    int d, lane, wave, cs, xo, xg, y0, y1;
+    bool ok;      // workgroup has work (uniform over the workgroup)
+    bool ovalid;  // this lane produces an output column
+};
+__device__ __forceinline__ MarchPosX4 march_pos_x4(int W, int H, int Dloc, int ngroups, int nsegs, int seg_rows)
+{
+    MarchPosX4 p;
+    int id = blockIdx.x;
+    int g = id % ngroups, rest = id / ngroups;   // strip groups fastest: neighbours in x run together
+    p.d = rest % Dloc;
+    int seg = rest / Dloc;
+    p.ok = seg < nsegs;
+    p.wave = threadIdx.x >> 6;
+    p.lane = threadIdx.x & 63;
+    p.xg = g * X4_COLS;
+    int x0 = p.xg + p.wave * OUT_PER_WAVE;
+    p.cs = r101c(x0 - 4 + p.lane, W);
+    p.xo = x0 + p.lane;
+    p.ovalid = p.lane < OUT_PER_WAVE && p.xo < W;
+    p.y0 = seg * seg_rows;
+    p.y1 = min(H, p.y0 + seg_rows);
+    return p;
+}
+
+// rows[4][224] of the current 4-step batch -> global.  Called by all 256 threads.
+template <bool VEC4>
+__device__ __forceinline__ void flush_rows_x4(float *lds_buf, const float (&qb)[4], const MarchPosX4 &pos, float *vd,
+                                              int W, int ybase, int i, int n)
+{
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        if (pos.lane < OUT_PER_WAVE) lds_buf[k * X4_COLS + pos.wave * OUT_PER_WAVE + pos.lane] = qb[k];
+    __syncthreads();
+    const int step = i + pos.wave;  // wave w writes the row produced at step i+w
+    if (step >= 7 && step < n) {
+        float *row = vd + (size_t)(ybase + step - 3) * W + pos.xg;
+        if (VEC4) {
+            int c = pos.lane * 4;
+            if (pos.lane < X4_COLS / 4 && pos.xg + c < W)
+                *reinterpret_cast<float4 *>(row + c) = *reinterpret_cast<const float4 *>(lds_buf + pos.wave * X4_COLS + c);
+        } else {
+#pragma unroll
+            for (int c = pos.lane; c < X4_COLS; c += 64)
+                if (pos.xg + c < W) row[c] = lds_buf[pos.wave * X4_COLS + c];
+        }
+    }
 }
 
 // ---- stage B: (a0,a1,a2,b) -> q -------------------------------------------------------------
-template <int NW>
-__global__ __launch_bounds__(NW * 64) void k_cvf_b(const float4 *__restrict__ ab, float *__restrict__ vol,
-                                                  const float4 *__restrict__ G1, int W, int H, int Dloc,
-                                                  int nstrips, int nsegs, int seg_rows, int nzg)
+template <bool VEC4>
+__global__ __launch_bounds__(256) void k_cvf_b(const float4 *__restrict__ ab, float *__restrict__ vol,
+                                              const float4 *__restrict__ G1, int W, int H, int Dloc,
+                                              int ngroups, int nsegs, int seg_rows)
 {
-    const MarchPos pos = march_pos<NW>(W, H, Dloc, nstrips, nsegs, seg_rows, nzg);
+    __shared__ __attribute__((aligned(16))) float lds[2][4 * X4_COLS];
+    const MarchPosX4 pos = march_pos_x4(W, H, Dloc, ngroups, nsegs, seg_rows);
     if (!pos.ok) return;
     PSM_LANE_IDX();
     const size_t HW = (size_t)H * W;
@@ -407,42 +552,48 @@ __global__ __launch_bounds__(NW * 64) void k_cvf_b(const float4 *__restrict__ ab
     VTree t0 = {}, t1 = {}, t2 = {}, t3 = {};
     const int n = (pos.y1 - pos.y0) + 7;
     const int ybase = pos.y0 - 4;
+    const int xoc = min(pos.xo, W - 1);
 
-    float4 av[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) av[k] = abd[(size_t)r101c(ybase + k, H) * W + pos.cs];
+    float4 ain[4];   // (a0,a1,a2,b) at (input row, input column)
+    float4 o1[4];    // g1 at (output row, output column)
+#define PSM_ISSUE_B(SLOT, STEP)                                                         \
+    {                                                                                   \
+        ain[SLOT] = abd[(size_t)r101c(ybase + (STEP), H) * W + pos.cs];                 \
+        int yo_ = ybase + (STEP) - 3;                                                   \
+        yo_ = yo_ < 0 ? 0 : (yo_ > H - 1 ? H - 1 : yo_);                                \
+        o1[SLOT] = G1[(size_t)yo_ * W + xoc];                                           \
+    }
+    PSM_ISSUE_B(0, 0) __builtin_amdgcn_sched_barrier(0);
+    PSM_ISSUE_B(1, 1) __builtin_amdgcn_sched_barrier(0);
+    PSM_ISSUE_B(2, 2) __builtin_amdgcn_sched_barrier(0);
     for (int i = 0; i < n; i += 4) {
-        float4 ac[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) ac[k] = av[k];
-        if (i + 4 < n) {
-#pragma unroll
-            for (int k = 0; k < 4; ++k) av[k] = abd[(size_t)r101c(ybase + i + 4 + k, H) * W + pos.cs];
-        }
+        float qb[4];
 #define PSM_STEP_B(K)                                                                               \
     {                                                                                               \
-        double h0 = hsum8(ac[K].x, i1, i2, i4);                                                     \
-        double h1 = hsum8(ac[K].y, i1, i2, i4);                                                     \
-        double h2 = hsum8(ac[K].z, i1, i2, i4);                                                     \
-        double h3 = hsum8(ac[K].w, i1, i2, i4);                                                     \
-        double n0 = vstep<K>(t0, h0), n1 = vstep<K>(t1, h1), n2 = vstep<K>(t2, h2), n3 = vstep<K>(t3, h3); \
         const int step = i + K;                                                                     \
-        if (step >= 7 && step < n && pos.ovalid) {                                                  \
-            const size_t oo = (size_t)(ybase + step - 3) * W + pos.xo;                              \
-            vd[oo] = recombine(box_out(n0), box_out(n1), box_out(n2), box_out(n3), G1[oo]);         \
-        }                                                                                           \
+        PSM_ISSUE_B((K + 3) & 3, step + 3)                                                          \
+        double h0 = hsum8(ain[K].x, i1, i2, i4);                                                    \
+        double h1 = hsum8(ain[K].y, i1, i2, i4);                                                    \
+        double h2 = hsum8(ain[K].z, i1, i2, i4);                                                    \
+        double h3 = hsum8(ain[K].w, i1, i2, i4);                                                    \
+        double n0 = vstep<K>(t0, h0), n1 = vstep<K>(t1, h1), n2 = vstep<K>(t2, h2), n3 = vstep<K>(t3, h3); \
+        qb[K] = recombine(box_out(n0), box_out(n1), box_out(n2), box_out(n3), o1[K]);               \
+        __builtin_amdgcn_sched_barrier(0);                                                          \
     }
         PSM_STEP_B(0) PSM_STEP_B(1) PSM_STEP_B(2) PSM_STEP_B(3)
 #undef PSM_STEP_B
+        flush_rows_x4<VEC4>(lds[(i >> 2) & 1], qb, pos, vd, W, ybase, i, n);
     }
+#undef PSM_ISSUE_B
 }
 
 // ---- plain box filter of every slice ----------------------------------------------------------
-template <int NW>
-__global__ __launch_bounds__(NW * 64) void k_box8(const float *__restrict__ vol, float *__restrict__ out, int W,
-                                                 int H, int Dloc, int nstrips, int nsegs, int seg_rows, int nzg)
+template <bool VEC4>
+__global__ __launch_bounds__(256) void k_box8(const float *__restrict__ vol, float *__restrict__ out, int W,
+                                             int H, int Dloc, int ngroups, int nsegs, int seg_rows)
 {
-    const MarchPos pos = march_pos<NW>(W, H, Dloc, nstrips, nsegs, seg_rows, nzg);
+    __shared__ __attribute__((aligned(16))) float lds[2][4 * X4_COLS];
+    const MarchPosX4 pos = march_pos_x4(W, H, Dloc, ngroups, nsegs, seg_rows);
     if (!pos.ok) return;
     PSM_LANE_IDX();
     const size_t HW = (size_t)H * W;
@@ -458,18 +609,14 @@ __global__ __launch_bounds__(NW * 64) void k_box8(const float *__restrict__ vol,
         float pc[8];
 #pragma unroll
         for (int k = 0; k < 8; ++k) pc[k] = pv[k];
-        if (i + 8 < n) {
 #pragma unroll
-            for (int k = 0; k < 8; ++k) pv[k] = vd[(size_t)r101c(ybase + i + 8 + k, H) * W + pos.cs];
-        }
-#define PSM_STEP_X(K)                                                      \
-    {                                                                      \
-        double n0 = vstep<K>(t0, hsum8(pc[K], i1, i2, i4));                \
-        const int step = i + K;                                            \
-        if (step >= 7 && step < n && pos.ovalid)                           \
-            od[(size_t)(ybase + step - 3) * W + pos.xo] = box_out(n0);     \
-    }
-        PSM_STEP_X(0) PSM_STEP_X(1) PSM_STEP_X(2) PSM_STEP_X(3) PSM_STEP_X(4) PSM_STEP_X(5) PSM_STEP_X(6) PSM_STEP_X(7)
+        for (int k = 0; k < 8; ++k) pv[k] = vd[(size_t)r101c(ybase + i + 8 + k, H) * W + pos.cs];
+        float qa[4], qc[4];
+#define PSM_STEP_X(K, Q) Q[K & 3] = box_out(vstep<K>(t0, hsum8(pc[K], i1, i2, i4)));
+        PSM_STEP_X(0, qa) PSM_STEP_X(1, qa) PSM_STEP_X(2, qa) PSM_STEP_X(3, qa)
+        flush_rows_x4<VEC4>(lds[0], qa, pos, od, W, ybase, i, n);
+        PSM_STEP_X(4, qc) PSM_STEP_X(5, qc) PSM_STEP_X(6, qc) PSM_STEP_X(7, qc)
+        flush_rows_x4<VEC4>(lds[1], qc, pos, od, W, ybase, i + 4, n);
 #undef PSM_STEP_X
     }
 }
@@ -562,18 +709,26 @@ __global__ __launch_bounds__(256) void k_box8_direct(const float *__restrict__ v
 }
 
 struct MarchGrid {
-    int nstrips, nsegs, seg_rows, nzg, nblocks;
+    int nstrips, nsegs, seg_rows, nzg, nblocks, order;
 };
 static MarchGrid march_grid(March m, int W, int H, int Dloc)
 {
     MarchGrid g;
     g.nstrips = (W + OUT_PER_WAVE - 1) / OUT_PER_WAVE;
-    g.seg_rows = m.seg_rows > 0 ? m.seg_rows : H;
+    // auto: split H evenly into segments of about 128 rows (7 halo rows each: ~5 % extra row
+    // reads, but 8x more blocks than whole columns -> no tail at 1080p x 256; measured best)
+    if (m.seg_rows > 0) g.seg_rows = m.seg_rows;
+    else { int k = (H + 127) / 128; g.seg_rows = (H + k - 1) / k; }
     if (g.seg_rows > H) g.seg_rows = H;
     g.nsegs = (H + g.seg_rows - 1) / g.seg_rows;
     g.nzg = (Dloc + m.waves - 1) / m.waves;
-    int npairs = g.nstrips * g.nsegs;
-    g.nblocks = 8 * ((npairs + 7) / 8) * g.nzg;
+    g.order = (m.flags >> 1) & 3;
+    if (g.order == 0) {
+        int npairs = g.nstrips * g.nsegs;
+        g.nblocks = 8 * ((npairs + 7) / 8) * g.nzg;
+    } else {
+        g.nblocks = 8 * ((g.nstrips + 7) / 8) * g.nsegs * g.nzg;
+    }
     return g;
 }
 
@@ -583,6 +738,17 @@ static MarchGrid march_grid(March m, int W, int H, int Dloc)
     case 2: hipLaunchKernelGGL(KERNEL<2>, dim3(g.nblocks), dim3(128), 0, s, __VA_ARGS__); break;        \
     case 8: hipLaunchKernelGGL(KERNEL<8>, dim3(g.nblocks), dim3(512), 0, s, __VA_ARGS__); break;        \
     default: hipLaunchKernelGGL(KERNEL<4>, dim3(g.nblocks), dim3(256), 0, s, __VA_ARGS__); break;       \
+    }
+#define PSM_DISPATCH_NW_NT(NWV, NTV, KERNEL, ...)                                                                          \
+    switch ((NWV) * 2 + ((NTV) ? 1 : 0)) {                                                                                 \
+    case 2: hipLaunchKernelGGL(HIP_KERNEL_NAME(KERNEL<1, false>), dim3(g.nblocks), dim3(64), 0, s, __VA_ARGS__); break;    \
+    case 3: hipLaunchKernelGGL(HIP_KERNEL_NAME(KERNEL<1, true>), dim3(g.nblocks), dim3(64), 0, s, __VA_ARGS__); break;     \
+    case 4: hipLaunchKernelGGL(HIP_KERNEL_NAME(KERNEL<2, false>), dim3(g.nblocks), dim3(128), 0, s, __VA_ARGS__); break;   \
+    case 5: hipLaunchKernelGGL(HIP_KERNEL_NAME(KERNEL<2, true>), dim3(g.nblocks), dim3(128), 0, s, __VA_ARGS__); break;    \
+    case 16: hipLaunchKernelGGL(HIP_KERNEL_NAME(KERNEL<8, false>), dim3(g.nblocks), dim3(512), 0, s, __VA_ARGS__); break;  \
+    case 17: hipLaunchKernelGGL(HIP_KERNEL_NAME(KERNEL<8, true>), dim3(g.nblocks), dim3(512), 0, s, __VA_ARGS__); break;   \
+    case 9: hipLaunchKernelGGL(HIP_KERNEL_NAME(KERNEL<4, true>), dim3(g.nblocks), dim3(256), 0, s, __VA_ARGS__); break;    \
+    default: hipLaunchKernelGGL(HIP_KERNEL_NAME(KERNEL<4, false>), dim3(g.nblocks), dim3(256), 0, s, __VA_ARGS__); break;  \
     }
 
 static int norm_waves(int w) { return (w == 1 || w == 2 || w == 8) ? w : 4; }
@@ -598,7 +764,7 @@ void launch_cvf_a(hipStream_t s, int variant, March m, const float *vol, float4 
     m.waves = norm_waves(m.waves);
     MarchGrid g = march_grid(m, W, H, Dloc);
     PSM_DISPATCH_NW(m.waves, k_cvf_a, vol, ab, (const float4 *)gd.g1, (const float4 *)gd.g2, (const float4 *)gd.g3,
-                    (const float2 *)gd.g4, W, H, Dloc, g.nstrips, g.nsegs, g.seg_rows, g.nzg)
+                    (const float2 *)gd.g4, W, H, Dloc, g.nstrips, g.nsegs, g.seg_rows, g.nzg, g.order)
 }
 
 void launch_cvf_b(hipStream_t s, int variant, March m, const float4 *ab, float *vol, Guidance gd, int W, int H, int Dloc)
@@ -608,9 +774,13 @@ void launch_cvf_b(hipStream_t s, int variant, March m, const float4 *ab, float *
         hipLaunchKernelGGL(k_cvf_b_direct, grid, dim3(256), 0, s, ab, vol, (const float4 *)gd.g1, W, H);
         return;
     }
-    m.waves = norm_waves(m.waves);
     MarchGrid g = march_grid(m, W, H, Dloc);
-    PSM_DISPATCH_NW(m.waves, k_cvf_b, ab, vol, (const float4 *)gd.g1, W, H, Dloc, g.nstrips, g.nsegs, g.seg_rows, g.nzg)
+    const int ngroups = (W + X4_COLS - 1) / X4_COLS;
+    const int nblocks = ngroups * Dloc * g.nsegs;
+    if ((W & 3) == 0)
+        hipLaunchKernelGGL(k_cvf_b<true>, dim3(nblocks), dim3(256), 0, s, ab, vol, (const float4 *)gd.g1, W, H, Dloc, ngroups, g.nsegs, g.seg_rows);
+    else
+        hipLaunchKernelGGL(k_cvf_b<false>, dim3(nblocks), dim3(256), 0, s, ab, vol, (const float4 *)gd.g1, W, H, Dloc, ngroups, g.nsegs, g.seg_rows);
 }
 
 void launch_box8(hipStream_t s, int variant, March m, const float *vol, float *out, int W, int H, int Dloc)
@@ -620,9 +790,13 @@ void launch_box8(hipStream_t s, int variant, March m, const float *vol, float *o
         hipLaunchKernelGGL(k_box8_direct, grid, dim3(256), 0, s, vol, out, W, H);
         return;
     }
-    m.waves = norm_waves(m.waves);
     MarchGrid g = march_grid(m, W, H, Dloc);
-    PSM_DISPATCH_NW(m.waves, k_box8, vol, out, W, H, Dloc, g.nstrips, g.nsegs, g.seg_rows, g.nzg)
+    const int ngroups = (W + X4_COLS - 1) / X4_COLS;
+    const int nblocks = ngroups * Dloc * g.nsegs;
+    if ((W & 3) == 0)
+        hipLaunchKernelGGL(k_box8<true>, dim3(nblocks), dim3(256), 0, s, vol, out, W, H, Dloc, ngroups, g.nsegs, g.seg_rows);
+    else
+        hipLaunchKernelGGL(k_box8<false>, dim3(nblocks), dim3(256), 0, s, vol, out, W, H, Dloc, ngroups, g.nsegs, g.seg_rows);
 }
 
 // ------------------------------------------------------------------------------------------

@@ -1,0 +1,26 @@
+"""Small driver for rocprofv3 counter passes: a few launches of every hot kernel at a BASELINE size.
+    python scripts/prof_run.py [config] [seg_rows] [waves]
+"""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import primestereomatch_amd as P  # noqa: E402
+from primestereomatch_amd import capi, synth  # noqa: E402
+
+cfg = {"c4": (1920, 1080, 256), "c3": (1280, 720, 128), "c2": (450, 375, 64)}[sys.argv[1] if len(sys.argv) > 1 else "c4"]
+W, H, D = cfg
+l, r, _ = synth.make_pair(W, H, D, seed=0)
+de = P.DispEst(l, r, D)
+if len(sys.argv) > 2:
+    de.set_option(capi.PSM_OPT_SEG_ROWS, int(sys.argv[2]))
+if len(sys.argv) > 3:
+    de.set_option(capi.PSM_OPT_WAVES, int(sys.argv[3]))
+for _ in range(2):
+    de.CostConst_GPU()
+    de.box8_volume(0, download=False)
+    de.CostFilter_GPU()
+    de.DispSelect_device()
+de.synchronize()
+de.close()

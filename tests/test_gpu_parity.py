@@ -434,3 +434,23 @@ def test_cpp_dispest_demo(psm, oracle, golden, tmp_path, mode, float_input):
     assert np.array_equal(ld, gold[key[0]]) and np.array_equal(rd, gold[key[1]])
     lv = np.fromfile(tmp_path / "o_lvalid.raw", np.uint8).reshape(H, W)
     assert np.array_equal(lv, oracle.lr_check(ld, rd)[0])
+
+
+@pytest.mark.parametrize("flags", [0, 1, 2, 4, 3, 8, 15])
+def test_tuning_flags_do_not_change_results(psm, oracle, flags):
+    """PSM_OPT_FLAGS only changes store policy / block traversal / CVC store width."""
+    from primestereomatch_amd import capi, synth
+    H, W, D = 150, 260, 12          # 5 strips, 2 y-segments, W % 4 == 0
+    l, r, _ = synth.make_pair(W, H, D, 5)
+    ref = oracle.pipeline_f32(l, r, D, threads=8, want_volumes=True, want_raw=True)
+    with psm.DispEst(l, r, D) as de:
+        de.set_option(capi.PSM_OPT_FLAGS, flags)
+        de.set_option(capi.PSM_OPT_SEG_ROWS, 80)
+        de.CostConst_GPU()
+        assert np.array_equal(de.download_volume(1), ref["raw_r"])
+        box = de.box8_volume(0)
+        assert np.array_equal(box[3], oracle.box8(ref["raw_l"][3]))
+        de.CostFilter_GPU()
+        de.DispSelect_GPU()
+        assert np.array_equal(de.download_volume(0), ref["lvol"]) and np.array_equal(de.download_volume(1), ref["rvol"])
+        assert np.array_equal(de.lDisMap, ref["ldisp"]) and np.array_equal(de.rDisMap, ref["rdisp"])

@@ -6,7 +6,7 @@ themselves are checked against the oracle in the -m gpu tests.)"""
 import numpy as np
 import pytest
 
-OUT_PER_WAVE = 57
+OUT_PER_WAVE = 56
 
 
 def r101c(k, n):
@@ -40,7 +40,7 @@ class VTree:
         return n8
 
 
-def march_box8(vol, seg_rows, waves):
+def march_box8(vol, seg_rows, waves, order=0):
     D, H, W = vol.shape
     out = np.full(vol.shape, np.nan, np.float32)
     written = np.zeros(vol.shape, np.int32)
@@ -50,17 +50,28 @@ def march_box8(vol, seg_rows, waves):
     nzg = (D + waves - 1) // waves
     npairs = nstrips * nsegs
     p8 = (npairs + 7) >> 3
-    nblocks = 8 * p8 * nzg
+    s8 = (nstrips + 7) >> 3
+    nblocks = 8 * p8 * nzg if order == 0 else 8 * s8 * nsegs * nzg
     lanes = np.arange(64)
     for bid in range(nblocks):
         xcd, j = bid & 7, bid >> 3
-        zg, pl = j % nzg, j // nzg
-        pair = xcd * p8 + pl
+        if order == 0:
+            zg, pl = j % nzg, j // nzg
+            pair = xcd * p8 + pl
+            ok = pl < p8 and pair < npairs
+            strip, seg = pair % nstrips, pair // nstrips
+        else:
+            sl, rest = j % s8, j // s8
+            strip = xcd * s8 + sl
+            if order == 1:
+                zg, seg = rest % nzg, rest // nzg
+            else:
+                seg, zg = rest % nsegs, rest // nsegs
+            ok = strip < nstrips and seg < nsegs and zg < nzg
         for wave in range(waves):
             d = zg * waves + wave
-            if not (pl < p8 and pair < npairs and d < D):
+            if not (ok and d < D):
                 continue
-            strip, seg = pair % nstrips, pair // nstrips
             x0 = strip * OUT_PER_WAVE
             cs = np.array([r101c(x0 - 4 + l, W) for l in lanes])
             xo = x0 + lanes
@@ -85,12 +96,13 @@ def march_box8(vol, seg_rows, waves):
     return out, written
 
 
+@pytest.mark.parametrize("order", [0, 1, 2])
 @pytest.mark.parametrize("shape,seg_rows,waves", [((3, 19, 70), 0, 4), ((5, 33, 130), 8, 2),
-                                                  ((2, 8, 8), 3, 1), ((9, 40, 57), 16, 8)])
-def test_march_model_matches_oracle(oracle, shape, seg_rows, waves):
+                                                  ((2, 8, 8), 3, 1), ((9, 40, 57), 16, 8), ((3, 20, 600), 7, 2)])
+def test_march_model_matches_oracle(oracle, shape, seg_rows, waves, order):
     rng = np.random.default_rng(11)
     vol = (rng.random(shape, dtype=np.float32) * 2.7).astype(np.float32)
-    out, written = march_box8(vol, seg_rows, waves)
+    out, written = march_box8(vol, seg_rows, waves, order)
     assert np.all(written == 1)                     # every voxel produced exactly once
     for d in range(shape[0]):
         assert np.array_equal(out[d], oracle.box8(vol[d]))   # bit-exact: same tree order
