@@ -35,7 +35,7 @@ CONFIGS = {
     "c2": (450, 375, 64, "synthetic 450x375 pair, D=64, float32 (size of BASELINE configs[1])"),
 }
 # algorithmic HBM bytes per voxel (SURVEY.md 8d / DESIGN.md): stage A 4 R + 16 W, stage B 16 R + 4 W
-ALG_BYTES = {"cvf_a": 20.0, "cvf_b": 20.0, "cvc": 4.0, "wta": 4.0, "box8": 8.0, "pipeline": 48.0}
+ALG_BYTES = {"cvf_fused": 40.0, "cvf_a": 20.0, "cvf_b": 20.0, "cvc": 4.0, "wta": 4.0, "box8": 8.0, "pipeline": 48.0}
 
 
 def main():
@@ -146,7 +146,7 @@ def main():
     for _ in range(prof_steps):
         step()
     sync()
-    names = {capi.PSM_K_PREP: "prep", capi.PSM_K_CVC: "cvc", capi.PSM_K_GUIDE: "guidance",
+    names = {capi.PSM_K_PREP: "prep", capi.PSM_K_CVC: "cvc", capi.PSM_K_GUIDE: "guidance", capi.PSM_K_CVF_F: "cvf_fused",
              capi.PSM_K_CVF_A: "cvf_a", capi.PSM_K_CVF_B: "cvf_b", capi.PSM_K_WTA: "wta",
              capi.PSM_K_MERGE: "merge"}
     kern = {}
@@ -156,7 +156,7 @@ def main():
             kern[nm] = {"avg_ms": tot / n, "launches_per_step": n / prof_steps}
     de.set_option(capi.PSM_OPT_PROFILE, 0)
     vox_per_launch = float(W) * H * (d1 - d0)   # one launch = all local slices of one side
-    dom = max(("cvf_a", "cvf_b"), key=lambda k: kern.get(k, {"avg_ms": 0})["avg_ms"])
+    dom = max(("cvf_fused", "cvf_a", "cvf_b"), key=lambda k: kern.get(k, {"avg_ms": 0})["avg_ms"])
     dom_ms = kern[dom]["avg_ms"]
     achieved = ALG_BYTES[dom] * vox_per_launch / (dom_ms * 1e-3) / 1e9
     roofline = {"bound": "hbm", "kernel": "k_" + dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,

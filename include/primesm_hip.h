@@ -43,7 +43,7 @@ enum { PSM_STAGE_CVC = 0, PSM_STAGE_CVF = 1, PSM_STAGE_DISPSEL = 2, PSM_STAGE_PP
        PSM_STAGE_COUNT = 4 };
 /* kernels whose device time can be queried with psm_kernel_time_ms() */
 enum { PSM_K_PREP = 0, PSM_K_CVC = 1, PSM_K_GUIDE = 2, PSM_K_CVF_A = 3, PSM_K_CVF_B = 4,
-       PSM_K_WTA = 5, PSM_K_MERGE = 6, PSM_K_BOX = 7, PSM_K_LRC = 8, PSM_K_COUNT = 9 };
+       PSM_K_WTA = 5, PSM_K_MERGE = 6, PSM_K_BOX = 7, PSM_K_LRC = 8, PSM_K_CVF_F = 9, PSM_K_COUNT = 10 };
 /* options for psm_set_option */
 enum {
     PSM_OPT_ASYNC = 0,          /* 1: stage calls only enqueue; use psm_synchronize()        */
@@ -51,7 +51,8 @@ enum {
     PSM_OPT_PROFILE = 2,        /* 1: bracket every kernel launch with hipEvents              */
     PSM_OPT_SEG_ROWS = 3,       /* rows per y-segment of the marching kernels (0 = auto)      */
     PSM_OPT_WAVES = 4,          /* waves (disparity slices) per workgroup: 1,2,4,8            */
-    PSM_OPT_FLAGS = 5           /* tuning bits: 1 = nontemporal stores of 4-byte outputs      */
+    PSM_OPT_FLAGS = 5           /* tuning bits: 2,4 = block traversal order of stage A; 8 = 16-byte-store
+                                   CVC kernel; 16 = two-stage guided filter instead of the fused one */
 };
 
 /* Number of usable HIP devices; 0 if none.  Replaces openCLdevicepoll()

@@ -18,7 +18,7 @@ PSM_IMG_U8, PSM_IMG_F32 = 0, 1
 PSM_LEFT, PSM_RIGHT = 0, 1
 PSM_STAGE_CVC, PSM_STAGE_CVF, PSM_STAGE_DISPSEL, PSM_STAGE_PP = 0, 1, 2, 3
 (PSM_K_PREP, PSM_K_CVC, PSM_K_GUIDE, PSM_K_CVF_A, PSM_K_CVF_B, PSM_K_WTA, PSM_K_MERGE, PSM_K_BOX,
- PSM_K_LRC) = range(9)
+ PSM_K_LRC, PSM_K_CVF_F) = range(10)
 PSM_OPT_ASYNC, PSM_OPT_KERNEL_VARIANT, PSM_OPT_PROFILE, PSM_OPT_SEG_ROWS, PSM_OPT_WAVES, PSM_OPT_FLAGS = range(6)
 
 # every symbol include/primesm_hip.h declares: (name, restype, argtypes)
@@ -67,7 +67,7 @@ def load(path: str | None = None):
     global _lib
     if _lib is not None and path is None:
         return _lib
-    p = path or LIB_PATH
+    p = path or os.environ.get("PRIMESM_HIP_LIB") or LIB_PATH   # same override as the C++ hipUtil
     if not os.path.exists(p):
         raise PsmError(
             f"{p} not found: build it with `make -C primestereomatch_amd/csrc` "

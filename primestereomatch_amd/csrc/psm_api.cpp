@@ -43,6 +43,7 @@ struct psm_ctx {
     double *hs9 = nullptr;
     void *vol[2] = {nullptr, nullptr};  // [Dloc][H][W] float (PSM_F32) or uint8 (PSM_U8)
     float *fvol = nullptr;              // PSM_U8 only: float work volume of one side
+    float *spare = nullptr;             // PSM_F32: output volume of the fused filter (ping-pong with vol[side])
     float4 *ab = nullptr;               // [Dloc][H][W] {a0,a1,a2,b}; also box8 output
     long long *keys = nullptr;          // [2][H][W]
     long long *gather = nullptr;        // [gather_ranks][2][H][W], psm_disp_merge_ctx
@@ -154,6 +155,7 @@ void free_all(psm_ctx *c)
     }
     (void)hipFree(c->hs9);
     (void)hipFree(c->fvol);
+    (void)hipFree(c->spare);
     (void)hipFree(c->ab);
     (void)hipFree(c->keys);
     (void)hipFree(c->gather);
@@ -248,6 +250,7 @@ int psm_create_shard(psm_ctx **out, int width, int height, int max_disp, int d_b
     if (e == hipSuccess) e = hipMalloc((void **)&c->hs9, 9 * HW * sizeof(double));
     if (e == hipSuccess) e = hipMalloc((void **)&c->ab, V * sizeof(float4));
     if (e == hipSuccess && dtype == PSM_U8) e = hipMalloc((void **)&c->fvol, V * sizeof(float));
+    if (e == hipSuccess && dtype == PSM_F32) e = hipMalloc((void **)&c->spare, V * sizeof(float));
     if (e == hipSuccess) e = hipMalloc((void **)&c->keys, 2 * HW * sizeof(long long));
     if (e == hipSuccess) e = hipMalloc((void **)&c->maps, 2 * HW);
     if (e == hipSuccess) e = hipMalloc((void **)&c->valid, 2 * HW);
@@ -374,24 +377,52 @@ int psm_cost_construct(psm_ctx *c)
 static int filter_side(psm_ctx *c, int side, bool stage_b)
 {
     const size_t V = (size_t)c->W * c->H * c->Dloc;
+    const int W = c->W, H = c->H;
     if (!c->have_g1 && run_prep(c)) return 1;  // volume came from psm_upload_volume
     {
         Prof p(c, PSM_K_GUIDE);
-        launch_guidance(c->stream, c->g[side], c->hs9, c->W, c->H);
+        launch_guidance(c->stream, c->g[side], c->hs9, W, H);
     }
     float *fv = (float *)c->vol[side];
     if (c->dtype == PSM_U8) {
         fv = c->fvol;
         launch_u8_to_f32(c->stream, (const uint8_t *)c->vol[side], fv, V);
     }
+    const bool fused = stage_b && c->dtype == PSM_F32 && c->opt_variant == 0 && !(c->march.flags & 16);
+    if (fused) {
+        // rows 4 .. H-4 in one pass (p -> q); the border rows, whose second box filter reflects
+        // model rows, go through the two-stage kernels on thin bands (7 model rows, 4+3 outputs)
+        float *out = c->spare;
+        {
+            Prof p(c, PSM_K_CVF_A);
+            if (H >= 14) {
+                launch_cvf_a(c->stream, 0, c->march, fv, c->ab, c->g[side], W, H, c->Dloc, 0, 7);
+                launch_cvf_a(c->stream, 0, c->march, fv, c->ab, c->g[side], W, H, c->Dloc, H - 7, H);
+            } else {
+                launch_cvf_a(c->stream, 0, c->march, fv, c->ab, c->g[side], W, H, c->Dloc, 0, H);
+            }
+        }
+        {
+            Prof p(c, PSM_K_CVF_B);
+            launch_cvf_b(c->stream, 0, c->march, c->ab, out, c->g[side], W, H, c->Dloc, 0, 4);
+            launch_cvf_b(c->stream, 0, c->march, c->ab, out, c->g[side], W, H, c->Dloc, H - 3 > 4 ? H - 3 : 4, H);
+        }
+        {
+            Prof p(c, PSM_K_CVF_F);
+            launch_cvf_fused(c->stream, c->march, fv, out, c->g[side], W, H, c->Dloc, 4, H - 3);
+        }
+        c->spare = fv;          // ping-pong: the filtered volume becomes vol[side]
+        c->vol[side] = out;
+        return check_launch(c, "cvf (fused)");
+    }
     {
         Prof p(c, PSM_K_CVF_A);
-        launch_cvf_a(c->stream, c->opt_variant, c->march, fv, c->ab, c->g[side], c->W, c->H, c->Dloc);
+        launch_cvf_a(c->stream, c->opt_variant, c->march, fv, c->ab, c->g[side], W, H, c->Dloc, 0, H);
     }
     if (stage_b) {
         {
             Prof p(c, PSM_K_CVF_B);
-            launch_cvf_b(c->stream, c->opt_variant, c->march, c->ab, fv, c->g[side], c->W, c->H, c->Dloc);
+            launch_cvf_b(c->stream, c->opt_variant, c->march, c->ab, fv, c->g[side], W, H, c->Dloc, 0, H);
         }
         if (c->dtype == PSM_U8) launch_f32_to_u8(c->stream, fv, (uint8_t *)c->vol[side], V);
     }

@@ -33,10 +33,14 @@ void launch_guidance(hipStream_t s, Guidance g, double *hs9, int W, int H);
 void launch_cvc(hipStream_t s, const float4 *g1_base, const float4 *g1_other, float *vol, int W, int H,
                 int d_begin, int Dloc, int right, int flags);
 // guided filter halves.  variant 0 = marching, 1 = direct per-voxel.
+// [ybeg, yend): output rows of this launch (the arithmetic always refers to the full H-row planes)
 void launch_cvf_a(hipStream_t s, int variant, March m, const float *vol, float4 *ab, Guidance g, int W,
-                  int H, int Dloc);
+                  int H, int Dloc, int ybeg, int yend);
 void launch_cvf_b(hipStream_t s, int variant, March m, const float4 *ab, float *vol, Guidance g, int W,
-                  int H, int Dloc);
+                  int H, int Dloc, int ybeg, int yend);
+// fused stage A+B: vin -> vout (distinct buffers), output rows [ybeg, yend) within [4, H-3)
+void launch_cvf_fused(hipStream_t s, March m, const float *vin, float *vout, Guidance g, int W, int H, int Dloc,
+                      int ybeg, int yend);
 // plain 8x8 box filter of every slice (the north-star kernel in isolation)
 void launch_box8(hipStream_t s, int variant, March m, const float *vol, float *out, int W, int H, int Dloc);
 // WTA over local slices -> packed keys (keys != NULL) and/or final map (map != NULL)

@@ -62,12 +62,32 @@ __device__ __forceinline__ double lane_get(double v, int byte_idx)
     return __hiloint2double(hi, lo);
 }
 
+// One-lane rotation of the whole wave in the VALU (DPP wave_rol:1: lane l <- lane l+1, lane 63 <-
+// lane 0; verified on gfx950).  No LDS round trip, unlike ds_bpermute.
+__device__ __forceinline__ int rol1(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x134, 0xf, 0xf, false); }
+__device__ __forceinline__ float rol1(float v) { return __int_as_float(rol1(__float_as_int(v))); }
+__device__ __forceinline__ double rol2(double v)
+{
+    int lo = rol1(rol1(__double2loint(v))), hi = rol1(rol1(__double2hiint(v)));
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double rol4(double v)
+{
+    int lo = rol1(rol1(rol1(rol1(__double2loint(v))))), hi = rol1(rol1(rol1(rol1(__double2hiint(v)))));
+    return __hiloint2double(hi, lo);
+}
+
 // Horizontal 8-tap window sum over lanes l..l+7 (sliding balanced tree).
+// PSM_XLANE_MODE: which exchange levels use DPP rotations instead of ds_bpermute
+//   0: none, 1: distance 1, 2: distances 1 and 2, 3: all (1, 2, 4)
+#ifndef PSM_XLANE_MODE
+#define PSM_XLANE_MODE 1
+#endif
 __device__ __forceinline__ double hsum8(float v, int i1, int i2, int i4)
 {
-    double s2 = __dadd_rn((double)v, (double)lane_get(v, i1));
-    double s4 = __dadd_rn(s2, lane_get(s2, i2));
-    return __dadd_rn(s4, lane_get(s4, i4));
+    double s2 = __dadd_rn((double)v, (double)(PSM_XLANE_MODE >= 1 ? rol1(v) : lane_get(v, i1)));
+    double s4 = __dadd_rn(s2, PSM_XLANE_MODE >= 2 ? rol2(s2) : lane_get(s2, i2));
+    return __dadd_rn(s4, PSM_XLANE_MODE >= 3 ? rol4(s4) : lane_get(s4, i4));
 }
 
 // Vertical 8-tap sliding tree.  After feeding row yy, returns the window sum of rows yy-7..yy.
@@ -364,7 +384,7 @@ struct MarchPos {
 //   2: as 1 but segments before slice groups.
 // Speed only - nothing depends on the placement.
 template <int NW>
-__device__ __forceinline__ MarchPos march_pos(int W, int H, int Dloc, int nstrips, int nsegs, int seg_rows, int nzg, int order)
+__device__ __forceinline__ MarchPos march_pos(int W, int ybeg, int yend, int Dloc, int nstrips, int nsegs, int seg_rows, int nzg, int order)
 {
     MarchPos p;
     int id = blockIdx.x;
@@ -396,8 +416,8 @@ __device__ __forceinline__ MarchPos march_pos(int W, int H, int Dloc, int nstrip
     p.cs = r101c(x0 - 4 + p.lane, W);
     p.xo = x0 + p.lane;
     p.ovalid = p.lane < OUT_PER_WAVE && p.xo < W;
-    p.y0 = seg * seg_rows;
-    p.y1 = min(H, p.y0 + seg_rows);
+    p.y0 = ybeg + seg * seg_rows;
+    p.y1 = min(yend, p.y0 + seg_rows);
     return p;
 }
 
@@ -415,6 +435,7 @@ __device__ __forceinline__ MarchPos march_pos(int W, int H, int Dloc, int nstrip
 // Store policy: a wave-wide dword store reaches the L2 as four 64-byte partial-line writes and
 // each allocates the line with a fill read from HBM (measured: k_cvc read as many bytes as it
 // wrote).  NT = nontemporal stores for the 4-byte-per-lane outputs.
+typedef float f4v __attribute__((ext_vector_type(4)));
 template <bool NT>
 __device__ __forceinline__ void store_f32(float *p, float v)
 {
@@ -426,9 +447,11 @@ template <int NW>
 __global__ __launch_bounds__(NW * 64) void k_cvf_a(const float *__restrict__ vol, float4 *__restrict__ ab,
                                                   const float4 *__restrict__ G1, const float4 *__restrict__ G2,
                                                   const float4 *__restrict__ G3, const float2 *__restrict__ G4,
-                                                  int W, int H, int Dloc, int nstrips, int nsegs, int seg_rows, int nzg, int order)
+                                                  int W, int H, int Dloc, int nstrips, int nsegs, int seg_rows, int nzg, int order,
+                                                  int ybeg, int yend)
 {
-    const MarchPos pos = march_pos<NW>(W, H, Dloc, nstrips, nsegs, seg_rows, nzg, order);
+    const bool nt_store = (order & 4) != 0;
+    const MarchPos pos = march_pos<NW>(W, ybeg, yend, Dloc, nstrips, nsegs, seg_rows, nzg, order & 3);
     if (!pos.ok) return;
     PSM_LANE_IDX();
     const size_t HW = (size_t)H * W;
@@ -470,7 +493,11 @@ __global__ __launch_bounds__(NW * 64) void k_cvf_a(const float *__restrict__ vol
         double h3 = hsum8(__fmul_rn(gin[K].z, p), i1, i2, i4);                                      \
         double n0 = vstep<K>(t0, h0), n1 = vstep<K>(t1, h1), n2 = vstep<K>(t2, h2), n3 = vstep<K>(t3, h3); \
         float4 r = solve_ab(box_out(n0), box_out(n1), box_out(n2), box_out(n3), o2[K], o3[K], o4[K]); \
-        if (step >= 7 && step < n && pos.ovalid) abd[(size_t)(ybase + step - 3) * W + pos.xo] = r;  \
+        if (step >= 7 && step < n && pos.ovalid) {                                                  \
+            float4 *dst_ = abd + (size_t)(ybase + step - 3) * W + pos.xo;                           \
+            if (nt_store) { f4v rv_ = {r.x, r.y, r.z, r.w}; __builtin_nontemporal_store(rv_, (f4v *)dst_); } \
+            else *dst_ = r;                                                                         \
+        }                                                                                           \
         __builtin_amdgcn_sched_barrier(0);                                                          \
     }
         PSM_STEP_A(0) PSM_STEP_A(1) PSM_STEP_A(2) PSM_STEP_A(3)
@@ -492,7 +519,7 @@ struct MarchPosX4 {
     bool ok;      // workgroup has work (uniform over the workgroup)
     bool ovalid;  // this lane produces an output column
 };
-__device__ __forceinline__ MarchPosX4 march_pos_x4(int W, int H, int Dloc, int ngroups, int nsegs, int seg_rows)
+__device__ __forceinline__ MarchPosX4 march_pos_x4(int W, int ybeg, int yend, int Dloc, int ngroups, int nsegs, int seg_rows)
 {
     MarchPosX4 p;
     int id = blockIdx.x;
@@ -507,8 +534,8 @@ __device__ __forceinline__ MarchPosX4 march_pos_x4(int W, int H, int Dloc, int n
     p.cs = r101c(x0 - 4 + p.lane, W);
     p.xo = x0 + p.lane;
     p.ovalid = p.lane < OUT_PER_WAVE && p.xo < W;
-    p.y0 = seg * seg_rows;
-    p.y1 = min(H, p.y0 + seg_rows);
+    p.y0 = ybeg + seg * seg_rows;
+    p.y1 = min(yend, p.y0 + seg_rows);
     return p;
 }
 
@@ -540,10 +567,10 @@ __device__ __forceinline__ void flush_rows_x4(float *lds_buf, const float (&qb)[
 template <bool VEC4>
 __global__ __launch_bounds__(256) void k_cvf_b(const float4 *__restrict__ ab, float *__restrict__ vol,
                                               const float4 *__restrict__ G1, int W, int H, int Dloc,
-                                              int ngroups, int nsegs, int seg_rows)
+                                              int ngroups, int nsegs, int seg_rows, int ybeg, int yend)
 {
     __shared__ __attribute__((aligned(16))) float lds[2][4 * X4_COLS];
-    const MarchPosX4 pos = march_pos_x4(W, H, Dloc, ngroups, nsegs, seg_rows);
+    const MarchPosX4 pos = march_pos_x4(W, ybeg, yend, Dloc, ngroups, nsegs, seg_rows);
     if (!pos.ok) return;
     PSM_LANE_IDX();
     const size_t HW = (size_t)H * W;
@@ -587,13 +614,293 @@ __global__ __launch_bounds__(256) void k_cvf_b(const float4 *__restrict__ ab, fl
 #undef PSM_ISSUE_B
 }
 
+// ---- fused guided filter: p -> q without the (a0,a1,a2,b) round trip through HBM ----------------
+// Stage A and stage B chained inside one wave.  Lane l of a wave whose first output column is x0
+//   reads the input column      x0 - 8 + l   (p, g1)
+//   owns the linear model at    x0 - 4 + l   (window sums of lanes l..l+7, solve -> a0,a1,a2,b)
+//   owns the output column      x0     + l   (window sums of the models of lanes l..l+7)
+// so 48 of the 64 lanes produce outputs (two 7-column halos).  Rows work the same way: the model
+// rows trail the input rows by 3 and the output rows trail the model rows by 3; the second tree
+// starts once 8 model rows exist.  The volume is read once and written once (8 B/voxel instead of
+// 40); the 16 B/voxel store that bounded stage A (and the vmcnt it tied up) is gone.
+// BORDER_REFLECT_101 of the (a,b) planes, which the second box filter sees at the image border:
+//   * columns: a lane whose model column falls outside the image takes the model of the mirrored
+//     column from the lane that owns it (one extra cross-lane gather, only in border strips);
+//   * rows: this kernel only produces output rows 4 .. H-4, whose windows need no reflected model
+//     row; rows 0..3 and H-3..H-1 are produced by the unfused kernels on two thin bands.
+constexpr int OUT_FUSED = 48;
+constexpr int XF_COLS = 4 * OUT_FUSED;  // 192 output columns = 6 full lines per workgroup
+
+template <bool VEC4>
+__global__ __launch_bounds__(256) void k_cvf_fused(const float *__restrict__ vin, float *__restrict__ vout,
+                                                  const float4 *__restrict__ G1, const float4 *__restrict__ G2,
+                                                  const float4 *__restrict__ G3, const float2 *__restrict__ G4,
+                                                  int W, int H, int Dloc, int ngroups, int nsegs, int seg_rows,
+                                                  int ybeg, int yend)
+{
+    __shared__ __attribute__((aligned(16))) float lds[2][4 * XF_COLS];
+    int id = blockIdx.x;
+    const int g = id % ngroups, rest = id / ngroups;
+    const int d = rest % Dloc, seg = rest / Dloc;
+    if (seg >= nsegs) return;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int xg = g * XF_COLS;
+    const int x0 = xg + wave * OUT_FUSED;
+    const int ci = r101c(x0 - 8 + lane, W);          // input column
+    const int xa = x0 - 4 + lane;                    // model column (may be outside the image)
+    const int xac = xa < 0 ? 0 : (xa > W - 1 ? W - 1 : xa);
+    const int xb = x0 + lane;                        // output column
+    const int xbc = min(xb, W - 1);
+    const int y0 = ybeg + seg * seg_rows, y1 = min(yend, y0 + seg_rows);
+    const int i1 = ((lane + 1) & 63) << 2, i2 = ((lane + 2) & 63) << 2, i4 = ((lane + 4) & 63) << 2;
+    // mirror lane for REFLECT_101 of the model columns (wave-uniform switch)
+    const bool need_mirror = (x0 - 4 < 0) || (x0 + 59 > W - 1);
+    int ml = r101(xa, W) - (x0 - 4);
+    ml = ml < 0 ? 0 : (ml > 63 ? 63 : ml);
+    const int im = ml << 2;
+
+    const size_t HW = (size_t)H * W;
+    const float *vd = vin + (size_t)d * HW;
+    float *od = vout + (size_t)d * HW;
+    VTree ta0 = {}, ta1 = {}, ta2 = {}, ta3 = {}, tb0 = {}, tb1 = {}, tb2 = {}, tb3 = {};
+    const int n = (y1 - y0) + 14;
+    const int ybase = y0 - 8;   // input row of step 0; model row = ybase+s-3; output row = ybase+s-6
+
+    float pin[4];
+    float4 gin[4], o2[4], o3[4], o1[4];
+    float2 o4[4];
+#define PSM_ISSUE_F(SLOT, STEP)                                                         \
+    {                                                                                   \
+        const size_t off_ = (size_t)r101c(ybase + (STEP), H) * W + ci;                  \
+        pin[SLOT] = vd[off_];                                                           \
+        gin[SLOT] = G1[off_];                                                           \
+        int ya_ = ybase + (STEP) - 3;                                                   \
+        ya_ = ya_ < 0 ? 0 : (ya_ > H - 1 ? H - 1 : ya_);                                \
+        const size_t oa_ = (size_t)ya_ * W + xac;                                       \
+        o2[SLOT] = G2[oa_];                                                             \
+        o3[SLOT] = G3[oa_];                                                             \
+        o4[SLOT] = G4[oa_];                                                             \
+        int yb_ = ybase + (STEP) - 6;                                                   \
+        yb_ = yb_ < 0 ? 0 : (yb_ > H - 1 ? H - 1 : yb_);                                \
+        o1[SLOT] = G1[(size_t)yb_ * W + xbc];                                           \
+    }
+    PSM_ISSUE_F(0, 0) __builtin_amdgcn_sched_barrier(0);
+    PSM_ISSUE_F(1, 1) __builtin_amdgcn_sched_barrier(0);
+    PSM_ISSUE_F(2, 2) __builtin_amdgcn_sched_barrier(0);
+    for (int i = 0; i < n; i += 4) {
+        float qb[4];
+#define PSM_STEP_F(K)                                                                               \
+    {                                                                                               \
+        const int step = i + K;                                                                     \
+        PSM_ISSUE_F((K + 3) & 3, step + 3)                                                          \
+        const float p = pin[K];                                                                     \
+        double h0 = hsum8(p, i1, i2, i4);                                                           \
+        double h1 = hsum8(__fmul_rn(gin[K].x, p), i1, i2, i4);                                      \
+        double h2 = hsum8(__fmul_rn(gin[K].y, p), i1, i2, i4);                                      \
+        double h3 = hsum8(__fmul_rn(gin[K].z, p), i1, i2, i4);                                      \
+        double n0 = vstep<K>(ta0, h0), n1 = vstep<K>(ta1, h1), n2 = vstep<K>(ta2, h2), n3 = vstep<K>(ta3, h3); \
+        float4 r = solve_ab(box_out(n0), box_out(n1), box_out(n2), box_out(n3), o2[K], o3[K], o4[K]); \
+        if (need_mirror) {                                                                          \
+            r.x = lane_get(r.x, im); r.y = lane_get(r.y, im); r.z = lane_get(r.z, im); r.w = lane_get(r.w, im); \
+        }                                                                                           \
+        double e0 = hsum8(r.x, i1, i2, i4), e1 = hsum8(r.y, i1, i2, i4);                            \
+        double e2 = hsum8(r.z, i1, i2, i4), e3 = hsum8(r.w, i1, i2, i4);                            \
+        /* rows fed before step 7 are not models yet; they have left the window by step 14 */      \
+        double m0 = vstep<K>(tb0, e0), m1 = vstep<K>(tb1, e1), m2 = vstep<K>(tb2, e2), m3 = vstep<K>(tb3, e3); \
+        qb[K] = recombine(box_out(m0), box_out(m1), box_out(m2), box_out(m3), o1[K]);               \
+        __builtin_amdgcn_sched_barrier(0);                                                          \
+    }
+        PSM_STEP_F(0) PSM_STEP_F(1) PSM_STEP_F(2) PSM_STEP_F(3)
+#undef PSM_STEP_F
+        // merged, line-aligned store of the four output rows of this batch
+        float *buf = lds[(i >> 2) & 1];
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (lane < OUT_FUSED) buf[k * XF_COLS + wave * OUT_FUSED + lane] = qb[k];
+        __syncthreads();
+        const int step = i + wave;
+        if (step >= 14 && step < n) {
+            float *row = od + (size_t)(ybase + step - 6) * W + xg;
+            if (VEC4) {
+                const int c = lane * 4;
+                if (lane < XF_COLS / 4 && xg + c < W)
+                    *reinterpret_cast<float4 *>(row + c) = *reinterpret_cast<const float4 *>(buf + wave * XF_COLS + c);
+            } else {
+#pragma unroll
+                for (int c = lane; c < XF_COLS; c += 64)
+                    if (xg + c < W) row[c] = buf[wave * XF_COLS + c];
+            }
+        }
+    }
+#undef PSM_ISSUE_F
+}
+
+// ---- fused guided filter, producer/consumer form ---------------------------------------------------
+// The single-wave fusion above needs both sliding trees in one wave (250 VGPRs, 1-2 waves per SIMD)
+// and is latency bound.  Here the two halves run in DIFFERENT waves of one workgroup and the linear
+// models (a0,a1,a2,b) are handed over through LDS instead of HBM:
+//   waves 0,1 ("A"): p, g1 -> window sums -> solve -> model rows into an LDS ring (52 columns each)
+//   waves 2,3 ("B"): model rows from LDS (mirror-indexed at the image border) -> window sums -> q
+// One barrier per batch of four rows; B runs one batch behind A, the merged line-aligned store of q
+// one batch behind B.  Each wave carries one tree (~140 VGPRs, 3 waves per SIMD).  Output rows 4..H-4
+// only (see k_cvf_fused); 96 output columns (3 full lines) per workgroup.
+constexpr int PC_OUT_B = 48;                 // output columns per B wave
+constexpr int PC_OUT_A = 52;                 // model columns per A wave
+constexpr int PC_COLS = 2 * PC_OUT_B;        // 96 output columns per workgroup
+constexpr int PC_MCOLS = 2 * PC_OUT_A;       // 104 model columns per workgroup (>= 96 + 7)
+
+template <bool VEC4>
+__global__ __launch_bounds__(256) void k_cvf_pc(const float *__restrict__ vin, float *__restrict__ vout,
+                                               const float4 *__restrict__ G1, const float4 *__restrict__ G2,
+                                               const float4 *__restrict__ G3, const float2 *__restrict__ G4,
+                                               int W, int H, int Dloc, int ngroups, int nsegs, int seg_rows,
+                                               int ybeg, int yend)
+{
+    __shared__ __attribute__((aligned(16))) float4 ring[2][4][PC_MCOLS];   // model rows, two batches
+    __shared__ __attribute__((aligned(16))) float qbuf[2][4][PC_COLS];     // output rows, two batches
+    int id = blockIdx.x;
+    const int g = id % ngroups, rest = id / ngroups;
+    const int d = rest % Dloc, seg = rest / Dloc;
+    if (seg >= nsegs) return;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const bool is_a = wave < 2;
+    const int xg = g * PC_COLS;                       // first output column of the workgroup
+    const int xm0 = xg - 4;                           // first model column of the workgroup
+    const int y0 = ybeg + seg * seg_rows, y1 = min(yend, y0 + seg_rows);
+    const int n = (y1 - y0) + 14;                     // steps (input rows)
+    const int nb = (n + 3) >> 2;                      // batches
+    const int ybase = y0 - 8;                         // input row of step 0
+    const int i1 = ((lane + 1) & 63) << 2, i2 = ((lane + 2) & 63) << 2, i4 = ((lane + 4) & 63) << 2;
+    (void)i1;
+    const size_t HW = (size_t)H * W;
+
+    if (is_a) {
+        // ---------------- producer: stage A ----------------
+        const int xa0 = xm0 + wave * PC_OUT_A;        // first model column of this wave
+        const int ci = r101c(xa0 - 4 + lane, W);      // input column of this lane
+        const int xa = xa0 + lane;                    // model column of this lane
+        const int xac = xa < 0 ? 0 : (xa > W - 1 ? W - 1 : xa);
+        const bool mvalid = lane < PC_OUT_A;
+        const float *vd = vin + (size_t)d * HW;
+        VTree t0 = {}, t1 = {}, t2 = {}, t3 = {};
+        float pin[4];
+        float4 gin[4], o2[4], o3[4];
+        float2 o4[4];
+#define PSM_ISSUE_PA(SLOT, STEP)                                                        \
+    {                                                                                   \
+        const size_t off_ = (size_t)r101c(ybase + (STEP), H) * W + ci;                  \
+        pin[SLOT] = vd[off_];                                                           \
+        gin[SLOT] = G1[off_];                                                           \
+        int ya_ = ybase + (STEP) - 3;                                                   \
+        ya_ = ya_ < 0 ? 0 : (ya_ > H - 1 ? H - 1 : ya_);                                \
+        const size_t oa_ = (size_t)ya_ * W + xac;                                       \
+        o2[SLOT] = G2[oa_];                                                             \
+        o3[SLOT] = G3[oa_];                                                             \
+        o4[SLOT] = G4[oa_];                                                             \
+    }
+        PSM_ISSUE_PA(0, 0) __builtin_amdgcn_sched_barrier(0);
+        PSM_ISSUE_PA(1, 1) __builtin_amdgcn_sched_barrier(0);
+        PSM_ISSUE_PA(2, 2) __builtin_amdgcn_sched_barrier(0);
+        for (int b = 0; b < nb + 2; ++b) {
+            if (b < nb) {
+                const int i = b * 4;
+                float4 *dst = &ring[b & 1][0][wave * PC_OUT_A + lane];
+#define PSM_STEP_PA(K)                                                                              \
+    {                                                                                               \
+        PSM_ISSUE_PA((K + 3) & 3, i + K + 3)                                                        \
+        const float p = pin[K];                                                                     \
+        double h0 = hsum8(p, i1, i2, i4);                                                           \
+        double h1 = hsum8(__fmul_rn(gin[K].x, p), i1, i2, i4);                                      \
+        double h2 = hsum8(__fmul_rn(gin[K].y, p), i1, i2, i4);                                      \
+        double h3 = hsum8(__fmul_rn(gin[K].z, p), i1, i2, i4);                                      \
+        double n0 = vstep<K>(t0, h0), n1 = vstep<K>(t1, h1), n2 = vstep<K>(t2, h2), n3 = vstep<K>(t3, h3); \
+        float4 r = solve_ab(box_out(n0), box_out(n1), box_out(n2), box_out(n3), o2[K], o3[K], o4[K]); \
+        if (mvalid) dst[K * PC_MCOLS] = r;                                                          \
+        __builtin_amdgcn_sched_barrier(0);                                                          \
+    }
+                PSM_STEP_PA(0) PSM_STEP_PA(1) PSM_STEP_PA(2) PSM_STEP_PA(3)
+#undef PSM_STEP_PA
+            }
+            __syncthreads();
+        }
+#undef PSM_ISSUE_PA
+    } else {
+        // ---------------- consumer: stage B ----------------
+        const int wb = wave - 2;
+        const int xb0 = xg + wb * PC_OUT_B;           // first output column of this wave
+        const int xmod = xb0 - 4 + lane;              // model column this lane consumes
+        int mc = r101(xmod, W) - xm0;                 // REFLECT_101 of the model planes, as ring index
+        mc = mc < 0 ? 0 : (mc > PC_MCOLS - 1 ? PC_MCOLS - 1 : mc);
+        const int xb = xb0 + lane;                    // output column of this lane
+        const int xbc = min(xb, W - 1);
+        float *od = vout + (size_t)d * HW;
+        VTree t0 = {}, t1 = {}, t2 = {}, t3 = {};
+        float4 o1[4];                                 // g1 at (output row, output column), one batch ahead
+#define PSM_ISSUE_PB(SLOT, STEP)                                                        \
+    {                                                                                   \
+        int yb_ = ybase + (STEP) - 6;                                                   \
+        yb_ = yb_ < 0 ? 0 : (yb_ > H - 1 ? H - 1 : yb_);                                \
+        o1[SLOT] = G1[(size_t)yb_ * W + xbc];                                           \
+    }
+        PSM_ISSUE_PB(0, 0) PSM_ISSUE_PB(1, 1) PSM_ISSUE_PB(2, 2) PSM_ISSUE_PB(3, 3)
+        for (int b = 0; b < nb + 2; ++b) {
+            // merged store of the batch finished two iterations ago... (b-2): written to qbuf[(b-2)&1]
+            if (b >= 2) {
+                const int i = (b - 2) * 4;
+                const int w2 = wb * 2;                // each B wave stores two of the four rows
+#pragma unroll
+                for (int rr = 0; rr < 2; ++rr) {
+                    const int k = w2 + rr, step = i + k;
+                    if (step >= 14 && step < n) {
+                        float *row = od + (size_t)(ybase + step - 6) * W + xg;
+                        const float *src = &qbuf[b & 1][k][0];
+                        if (VEC4) {
+                            const int c = lane * 4;
+                            if (lane < PC_COLS / 4 && xg + c < W)
+                                *reinterpret_cast<float4 *>(row + c) = *reinterpret_cast<const float4 *>(src + c);
+                        } else {
+#pragma unroll
+                            for (int c = lane; c < PC_COLS; c += 64)
+                                if (xg + c < W) row[c] = src[c];
+                        }
+                    }
+                }
+            }
+            if (b >= 1 && b <= nb) {
+                const int i = (b - 1) * 4;
+                float4 ain[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) ain[k] = ring[(b - 1) & 1][k][mc];
+                float qv[4];
+#define PSM_STEP_PB(K)                                                                              \
+    {                                                                                               \
+        double h0 = hsum8(ain[K].x, i1, i2, i4);                                                    \
+        double h1 = hsum8(ain[K].y, i1, i2, i4);                                                    \
+        double h2 = hsum8(ain[K].z, i1, i2, i4);                                                    \
+        double h3 = hsum8(ain[K].w, i1, i2, i4);                                                    \
+        double n0 = vstep<K>(t0, h0), n1 = vstep<K>(t1, h1), n2 = vstep<K>(t2, h2), n3 = vstep<K>(t3, h3); \
+        qv[K] = recombine(box_out(n0), box_out(n1), box_out(n2), box_out(n3), o1[K]);               \
+        PSM_ISSUE_PB(K, i + K + 4)                                                                  \
+    }
+                PSM_STEP_PB(0) PSM_STEP_PB(1) PSM_STEP_PB(2) PSM_STEP_PB(3)
+#undef PSM_STEP_PB
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (lane < PC_OUT_B) qbuf[(b - 1) & 1][k][wb * PC_OUT_B + lane] = qv[k];
+            }
+            __syncthreads();
+        }
+#undef PSM_ISSUE_PB
+    }
+}
+
 // ---- plain box filter of every slice ----------------------------------------------------------
 template <bool VEC4>
 __global__ __launch_bounds__(256) void k_box8(const float *__restrict__ vol, float *__restrict__ out, int W,
                                              int H, int Dloc, int ngroups, int nsegs, int seg_rows)
 {
     __shared__ __attribute__((aligned(16))) float lds[2][4 * X4_COLS];
-    const MarchPosX4 pos = march_pos_x4(W, H, Dloc, ngroups, nsegs, seg_rows);
+    const MarchPosX4 pos = march_pos_x4(W, 0, H, Dloc, ngroups, nsegs, seg_rows);
     if (!pos.ok) return;
     PSM_LANE_IDX();
     const size_t HW = (size_t)H * W;
@@ -712,7 +1019,7 @@ struct MarchGrid {
     int nstrips, nsegs, seg_rows, nzg, nblocks, order;
 };
 static MarchGrid march_grid(March m, int W, int H, int Dloc)
-{
+{   // H = number of output rows of this launch
     MarchGrid g;
     g.nstrips = (W + OUT_PER_WAVE - 1) / OUT_PER_WAVE;
     // auto: split H evenly into segments of about 128 rows (7 halo rows each: ~5 % extra row
@@ -723,6 +1030,7 @@ static MarchGrid march_grid(March m, int W, int H, int Dloc)
     g.nsegs = (H + g.seg_rows - 1) / g.seg_rows;
     g.nzg = (Dloc + m.waves - 1) / m.waves;
     g.order = (m.flags >> 1) & 3;
+    if (g.order == 3) g.order = 0;
     if (g.order == 0) {
         int npairs = g.nstrips * g.nsegs;
         g.nblocks = 8 * ((npairs + 7) / 8) * g.nzg;
@@ -753,8 +1061,10 @@ static MarchGrid march_grid(March m, int W, int H, int Dloc)
 
 static int norm_waves(int w) { return (w == 1 || w == 2 || w == 8) ? w : 4; }
 
-void launch_cvf_a(hipStream_t s, int variant, March m, const float *vol, float4 *ab, Guidance gd, int W, int H, int Dloc)
+void launch_cvf_a(hipStream_t s, int variant, March m, const float *vol, float4 *ab, Guidance gd, int W, int H, int Dloc,
+                  int ybeg, int yend)
 {
+    if (yend <= ybeg) return;
     if (variant == 1) {
         dim3 grid((W + 255) / 256, H, Dloc);
         hipLaunchKernelGGL(k_cvf_a_direct, grid, dim3(256), 0, s, vol, ab, (const float4 *)gd.g1, (const float4 *)gd.g2,
@@ -762,25 +1072,57 @@ void launch_cvf_a(hipStream_t s, int variant, March m, const float *vol, float4 
         return;
     }
     m.waves = norm_waves(m.waves);
-    MarchGrid g = march_grid(m, W, H, Dloc);
+    MarchGrid g = march_grid(m, W, yend - ybeg, Dloc);
     PSM_DISPATCH_NW(m.waves, k_cvf_a, vol, ab, (const float4 *)gd.g1, (const float4 *)gd.g2, (const float4 *)gd.g3,
-                    (const float2 *)gd.g4, W, H, Dloc, g.nstrips, g.nsegs, g.seg_rows, g.nzg, g.order)
+                    (const float2 *)gd.g4, W, H, Dloc, g.nstrips, g.nsegs, g.seg_rows, g.nzg, g.order | ((m.flags & 1) ? 4 : 0), ybeg, yend)
 }
 
-void launch_cvf_b(hipStream_t s, int variant, March m, const float4 *ab, float *vol, Guidance gd, int W, int H, int Dloc)
+void launch_cvf_b(hipStream_t s, int variant, March m, const float4 *ab, float *vol, Guidance gd, int W, int H, int Dloc,
+                  int ybeg, int yend)
 {
+    if (yend <= ybeg) return;
     if (variant == 1) {
         dim3 grid((W + 255) / 256, H, Dloc);
         hipLaunchKernelGGL(k_cvf_b_direct, grid, dim3(256), 0, s, ab, vol, (const float4 *)gd.g1, W, H);
         return;
     }
-    MarchGrid g = march_grid(m, W, H, Dloc);
+    MarchGrid g = march_grid(m, W, yend - ybeg, Dloc);
     const int ngroups = (W + X4_COLS - 1) / X4_COLS;
     const int nblocks = ngroups * Dloc * g.nsegs;
     if ((W & 3) == 0)
-        hipLaunchKernelGGL(k_cvf_b<true>, dim3(nblocks), dim3(256), 0, s, ab, vol, (const float4 *)gd.g1, W, H, Dloc, ngroups, g.nsegs, g.seg_rows);
+        hipLaunchKernelGGL(k_cvf_b<true>, dim3(nblocks), dim3(256), 0, s, ab, vol, (const float4 *)gd.g1, W, H, Dloc, ngroups, g.nsegs, g.seg_rows, ybeg, yend);
     else
-        hipLaunchKernelGGL(k_cvf_b<false>, dim3(nblocks), dim3(256), 0, s, ab, vol, (const float4 *)gd.g1, W, H, Dloc, ngroups, g.nsegs, g.seg_rows);
+        hipLaunchKernelGGL(k_cvf_b<false>, dim3(nblocks), dim3(256), 0, s, ab, vol, (const float4 *)gd.g1, W, H, Dloc, ngroups, g.nsegs, g.seg_rows, ybeg, yend);
+}
+
+void launch_cvf_fused(hipStream_t s, March m, const float *vin, float *vout, Guidance gd, int W, int H, int Dloc,
+                      int ybeg, int yend)
+{
+    if (yend <= ybeg) return;
+    const int rows = yend - ybeg;
+    int seg_rows = m.seg_rows;
+    if (seg_rows <= 0) { int k = (rows + 179) / 180; seg_rows = (rows + k - 1) / k; }  // 14 halo rows per segment
+    if (seg_rows > rows) seg_rows = rows;
+    const int nsegs = (rows + seg_rows - 1) / seg_rows;
+    if (!(m.flags & 32)) {
+        const int ngroups = (W + PC_COLS - 1) / PC_COLS;
+        const int nblocks = ngroups * Dloc * nsegs;
+        if ((W & 3) == 0)
+            hipLaunchKernelGGL(k_cvf_pc<true>, dim3(nblocks), dim3(256), 0, s, vin, vout, (const float4 *)gd.g1, (const float4 *)gd.g2,
+                               (const float4 *)gd.g3, (const float2 *)gd.g4, W, H, Dloc, ngroups, nsegs, seg_rows, ybeg, yend);
+        else
+            hipLaunchKernelGGL(k_cvf_pc<false>, dim3(nblocks), dim3(256), 0, s, vin, vout, (const float4 *)gd.g1, (const float4 *)gd.g2,
+                               (const float4 *)gd.g3, (const float2 *)gd.g4, W, H, Dloc, ngroups, nsegs, seg_rows, ybeg, yend);
+        return;
+    }
+    const int ngroups = (W + XF_COLS - 1) / XF_COLS;
+    const int nblocks = ngroups * Dloc * nsegs;
+    if ((W & 3) == 0)
+        hipLaunchKernelGGL(k_cvf_fused<true>, dim3(nblocks), dim3(256), 0, s, vin, vout, (const float4 *)gd.g1, (const float4 *)gd.g2,
+                           (const float4 *)gd.g3, (const float2 *)gd.g4, W, H, Dloc, ngroups, nsegs, seg_rows, ybeg, yend);
+    else
+        hipLaunchKernelGGL(k_cvf_fused<false>, dim3(nblocks), dim3(256), 0, s, vin, vout, (const float4 *)gd.g1, (const float4 *)gd.g2,
+                           (const float4 *)gd.g3, (const float2 *)gd.g4, W, H, Dloc, ngroups, nsegs, seg_rows, ybeg, yend);
 }
 
 void launch_box8(hipStream_t s, int variant, March m, const float *vol, float *out, int W, int H, int Dloc)
