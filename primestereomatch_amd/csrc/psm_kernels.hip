@@ -64,7 +64,8 @@ __device__ __forceinline__ double lane_get(double v, int byte_idx)
 
 // One-lane rotation of the whole wave in the VALU (DPP wave_rol:1: lane l <- lane l+1, lane 63 <-
 // lane 0; verified on gfx950).  No LDS round trip, unlike ds_bpermute.
-__device__ __forceinline__ int rol1(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x134, 0xf, 0xf, false); }
+// bound_ctrl=1: every lane has a source under wave_rol, and it spares the compiler a v_mov to seed `old`
+__device__ __forceinline__ int rol1(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x134, 0xf, 0xf, true); }
 __device__ __forceinline__ float rol1(float v) { return __int_as_float(rol1(__float_as_int(v))); }
 __device__ __forceinline__ double rol2(double v)
 {
@@ -81,7 +82,7 @@ __device__ __forceinline__ double rol4(double v)
 // PSM_XLANE_MODE: which exchange levels use DPP rotations instead of ds_bpermute
 //   0: none, 1: distance 1, 2: distances 1 and 2, 3: all (1, 2, 4)
 #ifndef PSM_XLANE_MODE
-#define PSM_XLANE_MODE 1
+#define PSM_XLANE_MODE 2   // measured on the fused filter at 1080p x 256: mode 0 5.29 ms, 1 4.76, 2 4.69, 3 5.98
 #endif
 __device__ __forceinline__ double hsum8(float v, int i1, int i2, int i4)
 {
@@ -739,18 +740,39 @@ __global__ __launch_bounds__(256) void k_cvf_fused(const float *__restrict__ vin
 // The single-wave fusion above needs both sliding trees in one wave (250 VGPRs, 1-2 waves per SIMD)
 // and is latency bound.  Here the two halves run in DIFFERENT waves of one workgroup and the linear
 // models (a0,a1,a2,b) are handed over through LDS instead of HBM:
-//   waves 0,1 ("A"): p, g1 -> window sums -> solve -> model rows into an LDS ring (52 columns each)
-//   waves 2,3 ("B"): model rows from LDS (mirror-indexed at the image border) -> window sums -> q
-// One barrier per batch of four rows; B runs one batch behind A, the merged line-aligned store of q
-// one batch behind B.  Each wave carries one tree (~140 VGPRs, 3 waves per SIMD).  Output rows 4..H-4
-// only (see k_cvf_fused); 96 output columns (3 full lines) per workgroup.
-constexpr int PC_OUT_B = 48;                 // output columns per B wave
-constexpr int PC_OUT_A = 52;                 // model columns per A wave
-constexpr int PC_COLS = 2 * PC_OUT_B;        // 96 output columns per workgroup
-constexpr int PC_MCOLS = 2 * PC_OUT_A;       // 104 model columns per workgroup (>= 96 + 7)
+//   waves 0-2 ("A"): p, g1 -> window sums -> solve -> model rows into an LDS ring (57 columns each)
+//   waves 3-5 ("B"): model rows from LDS (mirror-indexed at the image border) -> window sums -> q
+// One barrier per batch of four rows; B runs one batch behind A, the merged 16-byte-lane store of q
+// one batch behind B.  Each wave carries one tree (~150 VGPRs, 3 waves per SIMD).  Output rows 4..H-4
+// only (see k_cvf_fused).  The kernel is VALU bound (95 % VALU busy measured), so the widths are
+// chosen for lane efficiency, not for line alignment: 3 x 57 = 171 model columns feed 164 output
+// columns (B waves 55 + 55 + 54; 164 is a multiple of 4 so the merged rows are float4-aligned).
+#ifndef PSM_PC_ATTR
+#define PSM_PC_ATTR
+#endif
+#ifndef PSM_PC_P
+#define PSM_PC_P 1          // (measured: 1 -> 4.14 ms, 3 -> 4.37 ms at 1080p x 256)  load look-ahead of the producer waves in steps: 3 (4-slot ring) or 1 (2 slots)
+#endif
+constexpr int PC_SLOTS = PSM_PC_P + 1;
+#ifndef PSM_PC_LAYOUT
+#define PSM_PC_LAYOUT 0
+#endif
+#if PSM_PC_LAYOUT == 0      // 2 A + 2 B waves, 52 / 48 columns: 96 outputs = 3 full lines per workgroup
+constexpr int PC_NA = 2, PC_NB = 2, PC_OUT_A = 52, PC_OUT_B = 48, PC_COLS = 96;
+#elif PSM_PC_LAYOUT == 1    // 3 A + 3 B waves, 57 / 54,54,52 columns: 160 outputs = 5 full lines
+constexpr int PC_NA = 3, PC_NB = 3, PC_OUT_A = 57, PC_OUT_B = 54, PC_COLS = 160;
+#elif PSM_PC_LAYOUT == 2    // 2 A + 2 B waves, 57 / 52,52 columns (not line aligned)
+constexpr int PC_NA = 2, PC_NB = 2, PC_OUT_A = 57, PC_OUT_B = 52, PC_COLS = 104;
+#elif PSM_PC_LAYOUT == 3    // 4 A + 4 B waves, 50 / 48 columns: 192 outputs = 6 full lines
+constexpr int PC_NA = 4, PC_NB = 4, PC_OUT_A = 50, PC_OUT_B = 48, PC_COLS = 192;
+#elif PSM_PC_LAYOUT == 4    // 1 A + 1 B wave, 39 / 32 columns: 32 outputs = 1 full line
+constexpr int PC_NA = 1, PC_NB = 1, PC_OUT_A = 39, PC_OUT_B = 32, PC_COLS = 32;
+#endif
+constexpr int PC_MCOLS = PC_NA * PC_OUT_A;   // model columns per workgroup (>= PC_COLS + 7)
+static_assert(PC_MCOLS >= PC_COLS + 7 && (PC_COLS % 4) == 0 && PC_OUT_A <= 57 && PC_OUT_B <= 57, "bad producer/consumer layout");
 
 template <bool VEC4>
-__global__ __launch_bounds__(256) void k_cvf_pc(const float *__restrict__ vin, float *__restrict__ vout,
+__global__ __launch_bounds__(64 * (PC_NA + PC_NB)) PSM_PC_ATTR void k_cvf_pc(const float *__restrict__ vin, float *__restrict__ vout,
                                                const float4 *__restrict__ G1, const float4 *__restrict__ G2,
                                                const float4 *__restrict__ G3, const float2 *__restrict__ G4,
                                                int W, int H, int Dloc, int ngroups, int nsegs, int seg_rows,
@@ -763,7 +785,14 @@ __global__ __launch_bounds__(256) void k_cvf_pc(const float *__restrict__ vin, f
     const int d = rest % Dloc, seg = rest / Dloc;
     if (seg >= nsegs) return;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const bool is_a = wave < 2;
+#ifdef PSM_PC_SWAP
+    // alternate the roles of the wave slots from workgroup to workgroup so that, whatever the
+    // wave->SIMD placement is, producer and consumer waves mix on every SIMD
+    const int role = (blockIdx.x & 1) ? (wave + PC_NA) % (PC_NA + PC_NB) : wave;
+#else
+    const int role = wave;
+#endif
+    const bool is_a = role < PC_NA;
     const int xg = g * PC_COLS;                       // first output column of the workgroup
     const int xm0 = xg - 4;                           // first model column of the workgroup
     const int y0 = ybeg + seg * seg_rows, y1 = min(yend, y0 + seg_rows);
@@ -776,16 +805,16 @@ __global__ __launch_bounds__(256) void k_cvf_pc(const float *__restrict__ vin, f
 
     if (is_a) {
         // ---------------- producer: stage A ----------------
-        const int xa0 = xm0 + wave * PC_OUT_A;        // first model column of this wave
+        const int xa0 = xm0 + role * PC_OUT_A;        // first model column of this wave
         const int ci = r101c(xa0 - 4 + lane, W);      // input column of this lane
         const int xa = xa0 + lane;                    // model column of this lane
         const int xac = xa < 0 ? 0 : (xa > W - 1 ? W - 1 : xa);
         const bool mvalid = lane < PC_OUT_A;
         const float *vd = vin + (size_t)d * HW;
         VTree t0 = {}, t1 = {}, t2 = {}, t3 = {};
-        float pin[4];
-        float4 gin[4], o2[4], o3[4];
-        float2 o4[4];
+        float pin[PC_SLOTS];
+        float4 gin[PC_SLOTS], o2[PC_SLOTS], o3[PC_SLOTS];
+        float2 o4[PC_SLOTS];
 #define PSM_ISSUE_PA(SLOT, STEP)                                                        \
     {                                                                                   \
         const size_t off_ = (size_t)r101c(ybase + (STEP), H) * W + ci;                  \
@@ -799,22 +828,24 @@ __global__ __launch_bounds__(256) void k_cvf_pc(const float *__restrict__ vin, f
         o4[SLOT] = G4[oa_];                                                             \
     }
         PSM_ISSUE_PA(0, 0) __builtin_amdgcn_sched_barrier(0);
+#if PSM_PC_P == 3
         PSM_ISSUE_PA(1, 1) __builtin_amdgcn_sched_barrier(0);
         PSM_ISSUE_PA(2, 2) __builtin_amdgcn_sched_barrier(0);
+#endif
         for (int b = 0; b < nb + 2; ++b) {
             if (b < nb) {
                 const int i = b * 4;
-                float4 *dst = &ring[b & 1][0][wave * PC_OUT_A + lane];
+                float4 *dst = &ring[b & 1][0][role * PC_OUT_A + lane];
 #define PSM_STEP_PA(K)                                                                              \
     {                                                                                               \
-        PSM_ISSUE_PA((K + 3) & 3, i + K + 3)                                                        \
-        const float p = pin[K];                                                                     \
+        PSM_ISSUE_PA((K + PSM_PC_P) & (PC_SLOTS - 1), i + K + PSM_PC_P)                             \
+        const float p = pin[K & (PC_SLOTS - 1)];                                                    \
         double h0 = hsum8(p, i1, i2, i4);                                                           \
-        double h1 = hsum8(__fmul_rn(gin[K].x, p), i1, i2, i4);                                      \
-        double h2 = hsum8(__fmul_rn(gin[K].y, p), i1, i2, i4);                                      \
-        double h3 = hsum8(__fmul_rn(gin[K].z, p), i1, i2, i4);                                      \
+        double h1 = hsum8(__fmul_rn(gin[K & (PC_SLOTS - 1)].x, p), i1, i2, i4);                     \
+        double h2 = hsum8(__fmul_rn(gin[K & (PC_SLOTS - 1)].y, p), i1, i2, i4);                     \
+        double h3 = hsum8(__fmul_rn(gin[K & (PC_SLOTS - 1)].z, p), i1, i2, i4);                     \
         double n0 = vstep<K>(t0, h0), n1 = vstep<K>(t1, h1), n2 = vstep<K>(t2, h2), n3 = vstep<K>(t3, h3); \
-        float4 r = solve_ab(box_out(n0), box_out(n1), box_out(n2), box_out(n3), o2[K], o3[K], o4[K]); \
+        float4 r = solve_ab(box_out(n0), box_out(n1), box_out(n2), box_out(n3), o2[K & (PC_SLOTS - 1)], o3[K & (PC_SLOTS - 1)], o4[K & (PC_SLOTS - 1)]); \
         if (mvalid) dst[K * PC_MCOLS] = r;                                                          \
         __builtin_amdgcn_sched_barrier(0);                                                          \
     }
@@ -826,7 +857,8 @@ __global__ __launch_bounds__(256) void k_cvf_pc(const float *__restrict__ vin, f
 #undef PSM_ISSUE_PA
     } else {
         // ---------------- consumer: stage B ----------------
-        const int wb = wave - 2;
+        const int wb = role - PC_NA;
+        const int bwidth = wb < PC_NB - 1 ? PC_OUT_B : PC_COLS - (PC_NB - 1) * PC_OUT_B;
         const int xb0 = xg + wb * PC_OUT_B;           // first output column of this wave
         const int xmod = xb0 - 4 + lane;              // model column this lane consumes
         int mc = r101(xmod, W) - xm0;                 // REFLECT_101 of the model planes, as ring index
@@ -847,11 +879,10 @@ __global__ __launch_bounds__(256) void k_cvf_pc(const float *__restrict__ vin, f
             // merged store of the batch finished two iterations ago... (b-2): written to qbuf[(b-2)&1]
             if (b >= 2) {
                 const int i = (b - 2) * 4;
-                const int w2 = wb * 2;                // each B wave stores two of the four rows
 #pragma unroll
-                for (int rr = 0; rr < 2; ++rr) {
-                    const int k = w2 + rr, step = i + k;
-                    if (step >= 14 && step < n) {
+                for (int k = 0; k < 4; ++k) {          // row k of the batch is stored by B wave k % PC_NB
+                    const int step = i + k;
+                    if (k % PC_NB == wb && step >= 14 && step < n) {
                         float *row = od + (size_t)(ybase + step - 6) * W + xg;
                         const float *src = &qbuf[b & 1][k][0];
                         if (VEC4) {
@@ -886,7 +917,7 @@ __global__ __launch_bounds__(256) void k_cvf_pc(const float *__restrict__ vin, f
 #undef PSM_STEP_PB
 #pragma unroll
                 for (int k = 0; k < 4; ++k)
-                    if (lane < PC_OUT_B) qbuf[(b - 1) & 1][k][wb * PC_OUT_B + lane] = qv[k];
+                    if (lane < bwidth) qbuf[(b - 1) & 1][k][wb * PC_OUT_B + lane] = qv[k];
             }
             __syncthreads();
         }
@@ -1101,17 +1132,17 @@ void launch_cvf_fused(hipStream_t s, March m, const float *vin, float *vout, Gui
     if (yend <= ybeg) return;
     const int rows = yend - ybeg;
     int seg_rows = m.seg_rows;
-    if (seg_rows <= 0) { int k = (rows + 179) / 180; seg_rows = (rows + k - 1) / k; }  // 14 halo rows per segment
+    if (seg_rows <= 0) { int k = (rows + 399) / 400; seg_rows = (rows + k - 1) / k; }  // 14 halo rows per segment; ~360 measured best
     if (seg_rows > rows) seg_rows = rows;
     const int nsegs = (rows + seg_rows - 1) / seg_rows;
     if (!(m.flags & 32)) {
         const int ngroups = (W + PC_COLS - 1) / PC_COLS;
         const int nblocks = ngroups * Dloc * nsegs;
         if ((W & 3) == 0)
-            hipLaunchKernelGGL(k_cvf_pc<true>, dim3(nblocks), dim3(256), 0, s, vin, vout, (const float4 *)gd.g1, (const float4 *)gd.g2,
+            hipLaunchKernelGGL(k_cvf_pc<true>, dim3(nblocks), dim3(64 * (PC_NA + PC_NB)), 0, s, vin, vout, (const float4 *)gd.g1, (const float4 *)gd.g2,
                                (const float4 *)gd.g3, (const float2 *)gd.g4, W, H, Dloc, ngroups, nsegs, seg_rows, ybeg, yend);
         else
-            hipLaunchKernelGGL(k_cvf_pc<false>, dim3(nblocks), dim3(256), 0, s, vin, vout, (const float4 *)gd.g1, (const float4 *)gd.g2,
+            hipLaunchKernelGGL(k_cvf_pc<false>, dim3(nblocks), dim3(64 * (PC_NA + PC_NB)), 0, s, vin, vout, (const float4 *)gd.g1, (const float4 *)gd.g2,
                                (const float4 *)gd.g3, (const float2 *)gd.g4, W, H, Dloc, ngroups, nsegs, seg_rows, ybeg, yend);
         return;
     }

@@ -16,11 +16,12 @@ run tcc1 FETCH_SIZE
 run tcc2 WRITE_SIZE TCC_HIT_sum TCC_MISS_sum
 run tcc3 TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum
 run tcp1 TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_TCC_WRITE_REQ_sum TCP_PENDING_STALL_CYCLES_sum
+run sq4 SQ_INSTS_VALU SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_CVT SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_FLAT SQ_INSTS_LDS SQ_INSTS_BRANCH
 cd $GRAFT_REPO_ROOT
-for n in sq1 sq2 sq3 tcc1 tcc2 tcc3 tcp1; do
+for n in sq1 sq2 sq3 sq4 tcc1 tcc2 tcc3 tcp1; do
   f=$(find $OUT/$n -name "*.db" | head -1)
   [ -n "$f" ] && python scripts/rocpd_summary.py $f > $OUT/$n.summary.txt 2>&1
   tail -3 $OUT/$n.log | cut -c1-200
 done
 find $OUT -name "*.db" -size +30M -delete
-cat $OUT/*.summary.txt | grep -v "^| psm::k_guide\|k_prep" | head -150
+echo pmc done
