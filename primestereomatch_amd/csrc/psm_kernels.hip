@@ -339,9 +339,57 @@ __global__ __launch_bounds__(256) void k_cvc4(const float4 *__restrict__ base, c
     }
 }
 
+// One pixel per lane for the (coalesced) loads and the arithmetic, but the eight cost rows of a wave
+// are parked in LDS and written back with 16 bytes per lane: one store instruction then covers four
+// 256-byte row pieces, each two complete cache lines, instead of four 64-byte partial writes per
+// dword store (which made the L2 fill every line from HBM first).  Needs W % 4 == 0.
+template <bool RIGHT>
+__global__ __launch_bounds__(256) void k_cvc_t(const float4 *__restrict__ base, const float4 *__restrict__ other,
+                                              float *__restrict__ vol, int W, int H, int d_begin, int Dloc)
+{
+    __shared__ __attribute__((aligned(16))) float lds[4][CVC_DC][64];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+    const int dl0 = blockIdx.z * CVC_DC;
+    const int xc = min(x, W - 1);
+    const size_t HW = (size_t)H * W;
+    const size_t row = (size_t)y * W;
+    const float4 a = base[row + xc];
+    const float cb = cost_border(a);
+#pragma unroll
+    for (int k = 0; k < CVC_DC; ++k) {
+        const int d = d_begin + dl0 + k;
+        float c;
+        if (RIGHT) {
+            if (xc < W - d) c = cost_pair(a, other[row + xc + d]); else c = cb;
+        } else {
+            if (xc >= d) c = cost_pair(a, other[row + xc - d]); else c = cb;
+        }
+        lds[wave][k][lane] = c;
+    }
+    __syncthreads();
+    const int q4 = (lane & 15) * 4;
+    const int xq = blockIdx.x * 256 + wave * 64 + q4;
+#pragma unroll
+    for (int j = 0; j < CVC_DC / 4; ++j) {
+        const int k = (lane >> 4) + 4 * j;
+        const int dl = dl0 + k;
+        if (dl < Dloc && xq < W)
+            *reinterpret_cast<float4 *>(vol + (size_t)dl * HW + row + xq) = *reinterpret_cast<const float4 *>(&lds[wave][k][q4]);
+    }
+}
+
 void launch_cvc(hipStream_t s, const float4 *g1_base, const float4 *g1_other, float *vol, int W, int H,
                 int d_begin, int Dloc, int right, int flags)
 {
+    if (!(flags & 64) && !(flags & 8) && (W & 3) == 0) {
+        dim3 grid((W + 255) / 256, H, (Dloc + CVC_DC - 1) / CVC_DC);
+        if (right)
+            hipLaunchKernelGGL(k_cvc_t<true>, grid, dim3(256), 0, s, g1_base, g1_other, vol, W, H, d_begin, Dloc);
+        else
+            hipLaunchKernelGGL(k_cvc_t<false>, grid, dim3(256), 0, s, g1_base, g1_other, vol, W, H, d_begin, Dloc);
+        return;
+    }
     if ((flags & 8) && (W & 3) == 0) {
         dim3 grid((W / 4 + 255) / 256, H, (Dloc + CVC_DC - 1) / CVC_DC);
         if (right)
