@@ -802,6 +802,9 @@ __global__ __launch_bounds__(256) void k_cvf_fused(const float *__restrict__ vin
 #define PSM_PC_P 1          // (measured: 1 -> 4.14 ms, 3 -> 4.37 ms at 1080p x 256)  load look-ahead of the producer waves in steps: 3 (4-slot ring) or 1 (2 slots)
 #endif
 constexpr int PC_SLOTS = PSM_PC_P + 1;
+#ifndef PSM_PC_ABL
+#define PSM_PC_ABL 0   // experiments: 1 no global loads in A, 2 no B compute, 4 no A compute, 8 no barriers-between (invalid results)
+#endif
 #ifndef PSM_PC_LAYOUT
 #define PSM_PC_LAYOUT 0
 #endif
@@ -866,35 +869,44 @@ __global__ __launch_bounds__(64 * (PC_NA + PC_NB)) PSM_PC_ATTR void k_cvf_pc(con
 #define PSM_ISSUE_PA(SLOT, STEP)                                                        \
     {                                                                                   \
         const size_t off_ = (size_t)r101c(ybase + (STEP), H) * W + ci;                  \
-        pin[SLOT] = vd[off_];                                                           \
-        gin[SLOT] = G1[off_];                                                           \
         int ya_ = ybase + (STEP) - 3;                                                   \
         ya_ = ya_ < 0 ? 0 : (ya_ > H - 1 ? H - 1 : ya_);                                \
         const size_t oa_ = (size_t)ya_ * W + xac;                                       \
-        o2[SLOT] = G2[oa_];                                                             \
-        o3[SLOT] = G3[oa_];                                                             \
-        o4[SLOT] = G4[oa_];                                                             \
+        if (PSM_PC_ABL & 1) {                                                           \
+            const float f_ = (float)(lane + (STEP)) * 1e-3f;                            \
+            pin[SLOT] = f_; gin[SLOT] = make_float4(f_, f_ * 2, f_ * 3, 0.f);           \
+            o2[SLOT] = make_float4(f_, f_, f_, 1.f); o3[SLOT] = make_float4(f_, f_, 1.f, f_); o4[SLOT] = make_float2(f_, 1.f); \
+        } else {                                                                        \
+            pin[SLOT] = vd[off_];                                                       \
+            gin[SLOT] = G1[off_];                                                       \
+            o2[SLOT] = G2[oa_];                                                         \
+            o3[SLOT] = G3[oa_];                                                         \
+            o4[SLOT] = G4[oa_];                                                         \
+        }                                                                               \
     }
         PSM_ISSUE_PA(0, 0) __builtin_amdgcn_sched_barrier(0);
 #if PSM_PC_P == 3
         PSM_ISSUE_PA(1, 1) __builtin_amdgcn_sched_barrier(0);
         PSM_ISSUE_PA(2, 2) __builtin_amdgcn_sched_barrier(0);
 #endif
-        for (int b = 0; b < nb + 2; ++b) {
-            if (b < nb) {
+        // (loop bodies are kept free of conditionals around the tree updates: a conditional makes the
+        // trees loop-carried phis and the compiler then keeps two copies of all 56 state registers)
+        for (int b = 0; b < nb; ++b) {
+            {
                 const int i = b * 4;
                 float4 *dst = &ring[b & 1][0][role * PC_OUT_A + lane];
 #define PSM_STEP_PA(K)                                                                              \
     {                                                                                               \
         PSM_ISSUE_PA((K + PSM_PC_P) & (PC_SLOTS - 1), i + K + PSM_PC_P)                             \
         const float p = pin[K & (PC_SLOTS - 1)];                                                    \
+        if (PSM_PC_ABL & 4) { if (mvalid) dst[K * PC_MCOLS] = make_float4(p, gin[K & (PC_SLOTS - 1)].x, o2[K & (PC_SLOTS - 1)].x + o3[K & (PC_SLOTS - 1)].x, o4[K & (PC_SLOTS - 1)].x); } else { \
         double h0 = hsum8(p, i1, i2, i4);                                                           \
         double h1 = hsum8(__fmul_rn(gin[K & (PC_SLOTS - 1)].x, p), i1, i2, i4);                     \
         double h2 = hsum8(__fmul_rn(gin[K & (PC_SLOTS - 1)].y, p), i1, i2, i4);                     \
         double h3 = hsum8(__fmul_rn(gin[K & (PC_SLOTS - 1)].z, p), i1, i2, i4);                     \
         double n0 = vstep<K>(t0, h0), n1 = vstep<K>(t1, h1), n2 = vstep<K>(t2, h2), n3 = vstep<K>(t3, h3); \
         float4 r = solve_ab(box_out(n0), box_out(n1), box_out(n2), box_out(n3), o2[K & (PC_SLOTS - 1)], o3[K & (PC_SLOTS - 1)], o4[K & (PC_SLOTS - 1)]); \
-        if (mvalid) dst[K * PC_MCOLS] = r;                                                          \
+        if (mvalid) dst[K * PC_MCOLS] = r; }                                                        \
         __builtin_amdgcn_sched_barrier(0);                                                          \
     }
                 PSM_STEP_PA(0) PSM_STEP_PA(1) PSM_STEP_PA(2) PSM_STEP_PA(3)
@@ -902,6 +914,8 @@ __global__ __launch_bounds__(64 * (PC_NA + PC_NB)) PSM_PC_ATTR void k_cvf_pc(con
             }
             __syncthreads();
         }
+        __syncthreads();   // the consumers' last batch
+        __syncthreads();   // the consumers' last store
 #undef PSM_ISSUE_PA
     } else {
         // ---------------- consumer: stage B ----------------
@@ -915,51 +929,58 @@ __global__ __launch_bounds__(64 * (PC_NA + PC_NB)) PSM_PC_ATTR void k_cvf_pc(con
         const int xbc = min(xb, W - 1);
         float *od = vout + (size_t)d * HW;
         VTree t0 = {}, t1 = {}, t2 = {}, t3 = {};
-        float4 o1[4];                                 // g1 at (output row, output column), one batch ahead
+        float o1x[4], o1y[4], o1z[4];                 // g1.xyz at (output row, output column), one batch ahead
 #define PSM_ISSUE_PB(SLOT, STEP)                                                        \
     {                                                                                   \
         int yb_ = ybase + (STEP) - 6;                                                   \
         yb_ = yb_ < 0 ? 0 : (yb_ > H - 1 ? H - 1 : yb_);                                \
-        o1[SLOT] = G1[(size_t)yb_ * W + xbc];                                           \
+        const float4 g_ = G1[(size_t)yb_ * W + xbc];                                    \
+        o1x[SLOT] = g_.x; o1y[SLOT] = g_.y; o1z[SLOT] = g_.z;                           \
     }
         PSM_ISSUE_PB(0, 0) PSM_ISSUE_PB(1, 1) PSM_ISSUE_PB(2, 2) PSM_ISSUE_PB(3, 3)
-        for (int b = 0; b < nb + 2; ++b) {
-            // merged store of the batch finished two iterations ago... (b-2): written to qbuf[(b-2)&1]
-            if (b >= 2) {
-                const int i = (b - 2) * 4;
+        // merged store of output batch `bs` (rows parked in qbuf[bs & 1] one iteration earlier)
+        auto store_batch = [&](int bs) {
+            const int i = bs * 4;
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {          // row k of the batch is stored by B wave k % PC_NB
-                    const int step = i + k;
-                    if (k % PC_NB == wb && step >= 14 && step < n) {
-                        float *row = od + (size_t)(ybase + step - 6) * W + xg;
-                        const float *src = &qbuf[b & 1][k][0];
-                        if (VEC4) {
-                            const int c = lane * 4;
-                            if (lane < PC_COLS / 4 && xg + c < W)
-                                *reinterpret_cast<float4 *>(row + c) = *reinterpret_cast<const float4 *>(src + c);
-                        } else {
+            for (int k = 0; k < 4; ++k) {          // row k of the batch is stored by B wave k % PC_NB
+                const int step = i + k;
+                if (k % PC_NB == wb && step >= 14 && step < n) {
+                    float *row = od + (size_t)(ybase + step - 6) * W + xg;
+                    const float *src = &qbuf[bs & 1][k][0];
+                    if (VEC4) {
+                        const int c = lane * 4;
+                        if (lane < PC_COLS / 4 && xg + c < W)
+                            *reinterpret_cast<float4 *>(row + c) = *reinterpret_cast<const float4 *>(src + c);
+                    } else {
 #pragma unroll
-                            for (int c = lane; c < PC_COLS; c += 64)
-                                if (xg + c < W) row[c] = src[c];
-                        }
+                        for (int c = lane; c < PC_COLS; c += 64)
+                            if (xg + c < W) row[c] = src[c];
                     }
                 }
             }
-            if (b >= 1 && b <= nb) {
+        };
+        __syncthreads();                               // iteration 0: producers fill batch 0
+        for (int b = 1; b <= nb; ++b) {                // iteration b: consume model batch b-1
+            if (b >= 2) store_batch(b - 2);
+            {
                 const int i = (b - 1) * 4;
-                float4 ain[4];
-#pragma unroll
-                for (int k = 0; k < 4; ++k) ain[k] = ring[(b - 1) & 1][k][mc];
+                const float4 *src = &ring[(b - 1) & 1][0][mc];
+                float4 a_cur = src[0], a_nxt;
                 float qv[4];
 #define PSM_STEP_PB(K)                                                                              \
     {                                                                                               \
-        double h0 = hsum8(ain[K].x, i1, i2, i4);                                                    \
-        double h1 = hsum8(ain[K].y, i1, i2, i4);                                                    \
-        double h2 = hsum8(ain[K].z, i1, i2, i4);                                                    \
-        double h3 = hsum8(ain[K].w, i1, i2, i4);                                                    \
+        if (K < 3) a_nxt = src[(K + 1) * PC_MCOLS];   /* model row of the next step, one step ahead */ \
+        if (PSM_PC_ABL & 2) { qv[K] = a_cur.x + a_cur.y + a_cur.z + a_cur.w + o1x[K]; } else {     \
+        double h0 = hsum8(a_cur.x, i1, i2, i4);                                                     \
+        double h1 = hsum8(a_cur.y, i1, i2, i4);                                                     \
+        double h2 = hsum8(a_cur.z, i1, i2, i4);                                                     \
+        double h3 = hsum8(a_cur.w, i1, i2, i4);                                                     \
         double n0 = vstep<K>(t0, h0), n1 = vstep<K>(t1, h1), n2 = vstep<K>(t2, h2), n3 = vstep<K>(t3, h3); \
-        qv[K] = recombine(box_out(n0), box_out(n1), box_out(n2), box_out(n3), o1[K]);               \
+        qv[K] = __fadd_rn(__fadd_rn(__fadd_rn(box_out(n3), __fmul_rn(box_out(n0), o1x[K])),        \
+                                    __fmul_rn(box_out(n1), o1y[K])), __fmul_rn(box_out(n2), o1z[K])); } \
         PSM_ISSUE_PB(K, i + K + 4)                                                                  \
+        a_cur = a_nxt;                                                                              \
+        __builtin_amdgcn_sched_barrier(0);                                                          \
     }
                 PSM_STEP_PB(0) PSM_STEP_PB(1) PSM_STEP_PB(2) PSM_STEP_PB(3)
 #undef PSM_STEP_PB
@@ -969,6 +990,8 @@ __global__ __launch_bounds__(64 * (PC_NA + PC_NB)) PSM_PC_ATTR void k_cvf_pc(con
             }
             __syncthreads();
         }
+        if (nb >= 1) store_batch(nb - 1);              // iteration nb+1
+        __syncthreads();
 #undef PSM_ISSUE_PB
     }
 }
@@ -1180,7 +1203,16 @@ void launch_cvf_fused(hipStream_t s, March m, const float *vin, float *vout, Gui
     if (yend <= ybeg) return;
     const int rows = yend - ybeg;
     int seg_rows = m.seg_rows;
-    if (seg_rows <= 0) { int k = (rows + 399) / 400; seg_rows = (rows + k - 1) / k; }  // 14 halo rows per segment; ~360 measured best
+    if (seg_rows <= 0) {
+        // 14 halo rows per segment: long segments are cheaper (~360 rows measured best at D=256), but a
+        // disparity shard with few slices needs more segments to keep >= ~4000 workgroups in the launch
+        const int per_seg = ((W + PC_COLS - 1) / PC_COLS) * Dloc;
+        int k = (rows + 399) / 400;
+        const int kmin = (4096 + per_seg - 1) / per_seg, kmax = rows / 64 > 1 ? rows / 64 : 1;
+        if (k < kmin) k = kmin;
+        if (k > kmax) k = kmax;
+        seg_rows = (rows + k - 1) / k;
+    }
     if (seg_rows > rows) seg_rows = rows;
     const int nsegs = (rows + seg_rows - 1) / seg_rows;
     if (!(m.flags & 32)) {
