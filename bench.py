@@ -51,6 +51,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-d", type=int, default=24, help="disparities in the CPU-baseline sample")
     ap.add_argument("--force-dist", action="store_true", help="use the torch.distributed path even for N=1")
+    ap.add_argument("--exchange", default="allreduce", choices=["allreduce", "allgather"],
+                    help="N>1 exchange step: one all_reduce(MIN) of the packed keys (default; ~2x33 MB per rank "
+                         "at 1080p whatever N) or one all_gather ((N-1)x33 MB per rank) + device-side minimum")
     ap.add_argument("--box-bench", action="store_true", help="also time the plain box-filter pass")
     args = ap.parse_args()
 
@@ -97,7 +100,7 @@ def main():
     if use_dist:
         HW2 = 2 * H * W
         keys_local = torch.empty(HW2, dtype=torch.int64, device="cuda")
-        keys_all = torch.empty(world * HW2, dtype=torch.int64, device="cuda")
+        keys_all = torch.empty(world * HW2 if args.exchange == "allgather" else 1, dtype=torch.int64, device="cuda")
         # one non-default torch stream carries both our kernels and the RCCL collective, so the
         # exchange is ordered against the kernels without host synchronisation
         side_stream = torch.cuda.Stream()
@@ -109,8 +112,12 @@ def main():
         de.CostFilter_GPU()
         if use_dist:
             de.DispSelect_partial(keys_local.data_ptr())
-            dist.all_gather_into_tensor(keys_all, keys_local)     # the one exchange step (RCCL)
-            de.DispSelect_merge(keys_all.data_ptr(), world, download=False)
+            if args.exchange == "allreduce":
+                dist.all_reduce(keys_local, op=dist.ReduceOp.MIN)     # the one exchange step (RCCL)
+                de.DispSelect_merge(keys_local.data_ptr(), 1, download=False)
+            else:
+                dist.all_gather_into_tensor(keys_all, keys_local)     # the one exchange step (RCCL)
+                de.DispSelect_merge(keys_all.data_ptr(), world, download=False)
         else:
             de.DispSelect_device()
 
@@ -217,7 +224,7 @@ def main():
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": desc, "W": W, "H": H, "D": D, "voxels_per_step": voxels_per_step,
-                       "parallelism": "1 GPU" if world == 1 else f"D sharded over {world} ranks + 1 RCCL all-gather of packed minima",
+                       "parallelism": "1 GPU" if world == 1 else f"D sharded over {world} ranks + 1 RCCL {args.exchange} of packed minima",
                        "kernel_variant": args.variant},
             "roofline": roofline, "cpu_baseline": cpu, "kernels": kern,
         }

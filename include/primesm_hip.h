@@ -142,6 +142,11 @@ int psm_download_maps(psm_ctx *ctx, uint8_t *lmap, uint8_t *rmap, size_t stride)
  * may be NULL (results stay on the device). */
 int psm_lr_check(psm_ctx *ctx, uint8_t *lvalid, uint8_t *rvalid, size_t stride);
 
+/* "next" row: PP fillInv on the device (src/PP.cpp:52-143): every pixel the last psm_lr_check
+ * marked invalid takes the smaller disparity of its nearest valid left/right neighbours in the row.
+ * Modifies the device maps in place; lmap/rmap (optional) receive them. */
+int psm_fill_invalid(psm_ctx *ctx, uint8_t *lmap, uint8_t *rmap, size_t stride);
+
 /* ---- debug / bench entry points (no counterpart in the reference) ---- */
 
 /* Copy slices [d0,d1) (global disparity numbers) of a volume to/from dense host memory

@@ -43,6 +43,7 @@ SYMBOLS = [
     ("psm_disp_merge_ctx", _i, [_vp, C.POINTER(_vp), _i, _vp, _vp, _sz]),
     ("psm_download_maps", _i, [_vp, _vp, _vp, _sz]),
     ("psm_lr_check", _i, [_vp, _vp, _vp, _sz]),
+    ("psm_fill_invalid", _i, [_vp, _vp, _vp, _sz]),
     ("psm_download_volume", _i, [_vp, _i, _i, _i, _vp]),
     ("psm_upload_volume", _i, [_vp, _i, _i, _i, _vp]),
     ("psm_filter_stage_a", _i, [_vp, _i]),

@@ -52,7 +52,7 @@ struct psm_ctx {
     uint8_t *valid = nullptr;           // [2][H][W]
     uint8_t *p4[2] = {nullptr, nullptr};  // PSM_U8 only: {c0,c1,c2,grad} words
 
-    bool have_images = false, have_g1 = false, have_cost = false, have_maps = false;
+    bool have_images = false, have_g1 = false, have_cost = false, have_maps = false, have_valid = false;
 
     // options
     int opt_async = 0, opt_variant = 0, opt_profile = 0;
@@ -489,6 +489,7 @@ int psm_disp_select(psm_ctx *c, uint8_t *lmap, uint8_t *rmap, size_t stride)
     const double t0 = now_us();
     if (wta_launch(c, nullptr, c->maps)) return 1;
     c->have_maps = true;
+    c->have_valid = false;
     if (copy_maps_out(c, c->maps, lmap, rmap, stride)) return 1;
     return end_stage(c, PSM_STAGE_DISPSEL, t0);
 }
@@ -583,8 +584,29 @@ int psm_lr_check(psm_ctx *c, uint8_t *lvalid, uint8_t *rvalid, size_t stride)
         launch_lr_check(c->stream, c->maps, c->maps + HW, c->W, c->H, c->valid, c->valid + HW);
     }
     if (check_launch(c, "lr_check")) return 1;
+    c->have_valid = true;
     if (copy_maps_out(c, c->valid, lvalid, rvalid, stride)) return 1;
     return end_stage(c, PSM_STAGE_PP, t0);
+}
+
+int psm_fill_invalid(psm_ctx *c, uint8_t *lmap, uint8_t *rmap, size_t stride)
+{
+    if (!c) return 1;
+    if (!c->have_maps || !c->have_valid) return fail(c, "psm_fill_invalid: needs disparity maps and psm_lr_check");
+    if (bind(c)) return 1;
+    const double t0 = now_us();
+    const size_t HW = (size_t)c->W * c->H;
+    {
+        Prof p(c, PSM_K_LRC);
+        launch_fill_inv(c->stream, c->maps, c->valid, c->W, c->H);
+        launch_fill_inv(c->stream, c->maps + HW, c->valid + HW, c->W, c->H);
+    }
+    if (check_launch(c, "fill_inv")) return 1;
+    c->have_valid = false;   // the maps changed; validity refers to the unfilled maps
+    if (copy_maps_out(c, c->maps, lmap, rmap, stride)) return 1;
+    if (!c->opt_async) PSM_HIP(c, hipStreamSynchronize(c->stream));
+    c->stage_us[PSM_STAGE_PP] += now_us() - t0;
+    return 0;
 }
 
 static int check_slices(psm_ctx *c, const char *who, int side, int d0, int d1)

@@ -53,6 +53,9 @@ void launch_merge(hipStream_t s, const long long *keys_all, size_t rank_stride, 
 void launch_lr_check(hipStream_t s, const uint8_t *l, const uint8_t *r, int W, int H, uint8_t *lv,
                      uint8_t *rv);
 
+// fill invalid pixels of one map in place (valid: 0/1 per pixel)
+void launch_fill_inv(hipStream_t s, uint8_t *dis, const uint8_t *valid, int W, int H);
+
 // ---- 8-bit char mode ----
 void launch_prep_u8(hipStream_t s, const uint8_t *src, size_t pitch, int W, int H, uint8_t *planes4);
 void launch_cvc_u8(hipStream_t s, const uint8_t *base4, const uint8_t *other4, uint8_t *vol, int W, int H,

@@ -1328,6 +1328,76 @@ __global__ __launch_bounds__(256) void k_lr_check(const uint8_t *__restrict__ l,
     rv[(size_t)y * W + x] = (rDep == lDep && rDep >= 2) ? 1 : 0;
 }
 
+// ------------------------------------------------------------------------------------------
+// PP fillInv (src/PP.cpp:52-143): every invalid pixel takes the smaller disparity of its nearest
+// valid neighbours to the left and to the right in the same row (only valid pixels are read, so the
+// result does not depend on the order).  One workgroup per row; the nearest-valid indices are a
+// max-scan / min-scan over the row, done blockwise in LDS with a running carry.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_fill_inv(uint8_t *__restrict__ dis, const uint8_t *__restrict__ valid, int W)
+{
+    __shared__ int sc[256];
+    __shared__ int carry;
+    const int y = blockIdx.x, t = threadIdx.x;
+    uint8_t *d = dis + (size_t)y * W;
+    const uint8_t *v = valid + (size_t)y * W;
+    extern __shared__ int dyn[];          // left[W] | right[W]
+    int *left = dyn, *right = dyn + W;
+    // nearest valid index <= x  (-1: none)
+    if (t == 0) carry = -1;
+    __syncthreads();
+    for (int x0 = 0; x0 < W; x0 += 256) {
+        const int x = x0 + t;
+        int val = (x < W && v[x]) ? x : -1;
+        sc[t] = val;
+        __syncthreads();
+        for (int o = 1; o < 256; o <<= 1) {
+            int other = t >= o ? sc[t - o] : -1;
+            __syncthreads();
+            sc[t] = max(sc[t], other);
+            __syncthreads();
+        }
+        const int c = carry;
+        if (x < W) left[x] = max(sc[t], c);
+        __syncthreads();
+        if (t == 255) carry = max(sc[255], c);
+        __syncthreads();
+    }
+    // nearest valid index >= x  (W: none)
+    if (t == 0) carry = W;
+    __syncthreads();
+    for (int x0 = ((W - 1) / 256) * 256; x0 >= 0; x0 -= 256) {
+        const int x = x0 + t;
+        int val = (x < W && v[x]) ? x : W;
+        sc[t] = val;
+        __syncthreads();
+        for (int o = 1; o < 256; o <<= 1) {
+            int other = t + o < 256 ? sc[t + o] : W;
+            __syncthreads();
+            sc[t] = min(sc[t], other);
+            __syncthreads();
+        }
+        const int c = carry;
+        if (x < W) right[x] = min(sc[t], c);
+        __syncthreads();
+        if (t == 0) carry = min(sc[0], c);
+        __syncthreads();
+    }
+    for (int x = t; x < W; x += 256) {
+        if (v[x]) continue;
+        const int l = left[x], r = right[x];
+        const bool lf = l >= 0, rf = r < W;
+        if (lf && rf) d[x] = d[l] <= d[r] ? d[l] : d[r];
+        else if (lf) d[x] = d[l];
+        else if (rf) d[x] = d[r];
+    }
+}
+
+void launch_fill_inv(hipStream_t s, uint8_t *dis, const uint8_t *valid, int W, int H)
+{
+    hipLaunchKernelGGL(k_fill_inv, dim3(H), dim3(256), 2 * (size_t)W * sizeof(int), s, dis, valid, W);
+}
+
 void launch_lr_check(hipStream_t s, const uint8_t *l, const uint8_t *r, int W, int H, uint8_t *lv, uint8_t *rv)
 {
     hipLaunchKernelGGL(k_lr_check, dim3((W + 255) / 256, H), dim3(256), 0, s, l, r, W, H, lv, rv);

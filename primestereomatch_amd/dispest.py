@@ -130,6 +130,12 @@ class DispEst:
                  "LRCheck_GPU")
         return 0
 
+    def FillInv_GPU(self) -> int:
+        """PP fillInv (src/PP.cpp:52-143) on the device; updates lDisMap / rDisMap."""
+        self._ck(self._lib.psm_fill_invalid(self._h, _ptr(self.lDisMap), _ptr(self.rDisMap), self.wid),
+                 "FillInv_GPU")
+        return 0
+
     def set_option(self, option: int, value: int):
         self._ck(self._lib.psm_set_option(self._h, int(option), int(value)), "set_option")
 

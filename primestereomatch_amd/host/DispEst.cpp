@@ -103,6 +103,12 @@ int DispEst::PostProcess_GPU()
     return hipUtil::api().lr_check(ctx[0], lValid.data, rValid.data, lValid.step);
 }
 
+int DispEst::FillInvalid_GPU()
+{
+    if (ctx.empty()) return 1;
+    return hipUtil::api().fill_invalid(ctx[0], lDisMap.data, rDisMap.data, lDisMap.step);
+}
+
 double DispEst::stageTimeUs(int stage) const
 {
     double us = 0;

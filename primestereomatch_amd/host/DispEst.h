@@ -70,6 +70,8 @@ public:
     // out of scope here; this one runs the device left-right check
     // (src/PP.cpp:17-50) and leaves the maps untouched.
     int PostProcess_GPU();
+    // fillInv (src/PP.cpp:52-143) on the device: fills the pixels PostProcess_GPU marked invalid
+    int FillInvalid_GPU();
 
     bool ok() const { return !ctx.empty(); }
     double stageTimeUs(int stage) const;

@@ -36,11 +36,14 @@ def _worker(rank, world, port, D, H, W, q):
             keys[side] = pack_keys(c, d)
         local = torch.from_numpy(keys.reshape(-1))
         gathered = torch.empty(world * local.numel(), dtype=torch.int64)
-        dist.all_gather_into_tensor(gathered, local)            # the one exchange step
+        dist.all_gather_into_tensor(gathered, local)            # exchange flavour 1: all-gather + min
         best = gathered.view(world, -1).min(dim=0).values.numpy()
         maps = unpack_disp(best).reshape(2, H, W)
+        reduced = local.clone()
+        dist.all_reduce(reduced, op=dist.ReduceOp.MIN)          # exchange flavour 2: all-reduce(min)
+        maps2 = unpack_disp(reduced.numpy()).reshape(2, H, W)
         ref = np.stack([O.wta(vol[0]), O.wta(vol[1])])
-        q.put((rank, bool(np.array_equal(maps, ref))))
+        q.put((rank, bool(np.array_equal(maps, ref)) and bool(np.array_equal(maps2, ref))))
     finally:
         dist.destroy_process_group()
 

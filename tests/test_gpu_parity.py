@@ -279,6 +279,11 @@ def test_lr_check_on_device(psm, oracle, golden):
         lv, rv = oracle.lr_check(de.lDisMap, de.rDisMap)
         assert np.array_equal(de.lValid, lv) and np.array_equal(de.rValid, rv)
         assert 0.3 < lv.mean() < 1.0
+        lraw, rraw = de.lDisMap.copy(), de.rDisMap.copy()
+        de.FillInv_GPU()                                   # PP fillInv (src/PP.cpp:52-143)
+        assert np.array_equal(de.lDisMap, oracle.fill_inv(lraw, lv))
+        assert np.array_equal(de.rDisMap, oracle.fill_inv(rraw, rv))
+        assert not np.array_equal(de.lDisMap, lraw)
 
 
 # ------------------------------------------------------------------------------------------
@@ -454,3 +459,29 @@ def test_tuning_flags_do_not_change_results(psm, oracle, flags):
         de.DispSelect_GPU()
         assert np.array_equal(de.download_volume(0), ref["lvol"]) and np.array_equal(de.download_volume(1), ref["rvol"])
         assert np.array_equal(de.lDisMap, ref["ldisp"]) and np.array_equal(de.rDisMap, ref["rdisp"])
+
+
+@pytest.mark.parametrize("name", ["cones", "teddy"])
+def test_harness_reproduces_reference_metric(psm, oracle, golden, name):
+    """Headless StereoMatch::compute counterpart: four timed stages + %BP vs ground truth."""
+    from primestereomatch_amd import harness
+    pair = golden(f"{name}_pair.npz")
+    man = json.load(open(os.path.join(GOLDEN, "manifest.json")))[name.capitalize()]
+    out = harness.compute(pair["l_bgr"], pair["r_bgr"], 64, gt=pair["gt_l"], mask=pair["occl"], scale_factor=4)
+    assert out["bad_pixels"] == man["bad_pixels_thr4_nonocc"]
+    bad, avg = oracle.eval_bad_pixels(out["lDisMap"], pair["gt_l"], pair["occl"], 64, 4, 4)
+    assert bad == out["bad_pixels"] and abs(avg - out["avg_err"]) < 1e-4
+    assert out["cvf_ms"] > 0 and out["dispsel_ms"] > 0
+
+
+def test_fill_invalid_synthetic_width(psm, oracle):
+    from primestereomatch_amd import synth
+    l, r, _ = synth.make_pair(300, 40, 24, 9)
+    with psm.DispEst(l, r, 24) as de:
+        de.CostConst_GPU(); de.CostFilter_GPU(); de.DispSelect_GPU(); de.LRCheck_GPU()
+        lv, rv = de.lValid.copy(), de.rValid.copy()
+        lraw, rraw = de.lDisMap.copy(), de.rDisMap.copy()
+        de.FillInv_GPU()
+        assert np.array_equal(de.lDisMap, oracle.fill_inv(lraw, lv)) and np.array_equal(de.rDisMap, oracle.fill_inv(rraw, rv))
+        with pytest.raises(Exception):
+            de.FillInv_GPU()        # validity refers to the unfilled maps: needs a new LRCheck_GPU
