@@ -53,6 +53,11 @@ struct psm_ctx {
     uint8_t *p4[2] = {nullptr, nullptr};  // PSM_U8 only: {c0,c1,c2,grad} words
 
     bool have_images = false, have_g1 = false, have_cost = false, have_maps = false, have_valid = false;
+    // raw_rows[side]: which rows of the unfiltered cost volume exist in memory.  psm_cost_construct may
+    // leave the volume virtual (RAW_NONE): the fused filter builds the costs on the fly from the g1
+    // planes.  Anything else that reads the volume materialises it first (materialize()).
+    enum { RAW_ALL = 0, RAW_NONE = 1, RAW_BANDS = 2 };
+    int raw_rows[2] = {RAW_ALL, RAW_ALL};
 
     // options
     int opt_async = 0, opt_variant = 0, opt_profile = 0;
@@ -182,6 +187,24 @@ int run_prep(psm_ctx *c)
     if (check_launch(c, "prep")) return 1;
     c->have_g1 = true;
     return 0;
+}
+
+// build the (float) cost slices of `side` for rows [ybeg, yend)
+void launch_cvc_rows(psm_ctx *c, int side, int ybeg, int yend)
+{
+    Prof p(c, PSM_K_CVC);
+    // buildCV_right is called with the images swapped (src/DispEst.cpp:217,260)
+    launch_cvc(c->stream, c->g[side].g1, c->g[1 - side].g1, (float *)c->vol[side], c->W, c->H, c->d0, c->Dloc, side,
+               c->march.flags, ybeg, yend);
+}
+
+// make sure the whole unfiltered volume of `side` is in memory
+int materialize(psm_ctx *c, int side)
+{
+    if (c->dtype != PSM_F32 || c->raw_rows[side] == psm_ctx::RAW_ALL) return 0;
+    launch_cvc_rows(c, side, 0, c->H);
+    c->raw_rows[side] = psm_ctx::RAW_ALL;
+    return check_launch(c, "cvc (materialize)");
 }
 
 int flush_timers(psm_ctx *c)
@@ -360,13 +383,19 @@ int psm_cost_construct(psm_ctx *c)
     if (bind(c)) return 1;
     const double t0 = now_us();
     if (run_prep(c)) return 1;  // CVC::preprocess belongs to this stage (src/DispEst.cpp:232-233)
+    // Lazy cost volume: when the fused filter will consume the costs (float mode, marching kernels,
+    // fusion not disabled) they are built inside that kernel and never written to HBM.
+    const bool lazy = c->dtype == PSM_F32 && c->opt_variant == 0 && !(c->march.flags & (16 | 32 | 128)) && c->H >= 8;
     for (int s = 0; s < 2; ++s) {
-        Prof p(c, PSM_K_CVC);
-        // buildCV_right is called with the images swapped (src/DispEst.cpp:217,260)
-        if (c->dtype == PSM_U8)
+        if (c->dtype == PSM_U8) {
+            Prof p(c, PSM_K_CVC);
             launch_cvc_u8(c->stream, c->p4[s], c->p4[1 - s], (uint8_t *)c->vol[s], c->W, c->H, c->d0, c->Dloc, s);
-        else
-            launch_cvc(c->stream, c->g[s].g1, c->g[1 - s].g1, (float *)c->vol[s], c->W, c->H, c->d0, c->Dloc, s, c->march.flags);
+        } else if (lazy) {
+            c->raw_rows[s] = psm_ctx::RAW_NONE;
+        } else {
+            launch_cvc_rows(c, s, 0, c->H);
+            c->raw_rows[s] = psm_ctx::RAW_ALL;
+        }
     }
     if (check_launch(c, "cvc")) return 1;
     c->have_cost = true;
@@ -388,8 +417,14 @@ static int filter_side(psm_ctx *c, int side, bool stage_b)
         fv = c->fvol;
         launch_u8_to_f32(c->stream, (const uint8_t *)c->vol[side], fv, V);
     }
-    const bool fused = stage_b && c->dtype == PSM_F32 && c->opt_variant == 0 && !(c->march.flags & 16);
+    const bool fused = stage_b && c->dtype == PSM_F32 && c->opt_variant == 0 && !(c->march.flags & 16) && H >= 8;
+    if (!fused && materialize(c, side)) return 1;
     if (fused) {
+        const int cvc_mode = c->raw_rows[side] == psm_ctx::RAW_ALL ? 0 : 1 + side;
+        if (cvc_mode != 0) {   // the band kernels read cost rows 0..10 and H-11..H-1 from memory
+            if (H >= 22) { launch_cvc_rows(c, side, 0, 11); launch_cvc_rows(c, side, H - 11, H); }
+            else launch_cvc_rows(c, side, 0, H);
+        }
         // rows 4 .. H-4 in one pass (p -> q); the border rows, whose second box filter reflects
         // model rows, go through the two-stage kernels on thin bands (7 model rows, 4+3 outputs)
         float *out = c->spare;
@@ -409,10 +444,11 @@ static int filter_side(psm_ctx *c, int side, bool stage_b)
         }
         {
             Prof p(c, PSM_K_CVF_F);
-            launch_cvf_fused(c->stream, c->march, fv, out, c->g[side], W, H, c->Dloc, 4, H - 3);
+            launch_cvf_fused(c->stream, c->march, fv, out, c->g[side], W, H, c->Dloc, 4, H - 3, c->g[1 - side].g1, c->d0, cvc_mode);
         }
         c->spare = fv;          // ping-pong: the filtered volume becomes vol[side]
         c->vol[side] = out;
+        c->raw_rows[side] = psm_ctx::RAW_ALL;   // vol[side] now holds real (filtered) data
         return check_launch(c, "cvf (fused)");
     }
     {
@@ -487,6 +523,7 @@ int psm_disp_select(psm_ctx *c, uint8_t *lmap, uint8_t *rmap, size_t stride)
     if (!c->have_cost) return fail(c, "psm_disp_select: no cost volume");
     if (bind(c)) return 1;
     const double t0 = now_us();
+    if (materialize(c, 0) || materialize(c, 1)) return 1;
     if (wta_launch(c, nullptr, c->maps)) return 1;
     c->have_maps = true;
     c->have_valid = false;
@@ -500,6 +537,7 @@ int psm_disp_select_partial(psm_ctx *c, void *dev_keys)
     if (!c->have_cost) return fail(c, "psm_disp_select_partial: no cost volume");
     if (bind(c)) return 1;
     const double t0 = now_us();
+    if (materialize(c, 0) || materialize(c, 1)) return 1;
     if (wta_launch(c, dev_keys ? (long long *)dev_keys : c->keys, nullptr)) return 1;
     return end_stage(c, PSM_STAGE_DISPSEL, t0);
 }
@@ -621,6 +659,8 @@ int psm_download_volume(psm_ctx *c, int side, int d0, int d1, void *host)
     if (!c || !host) return 1;
     if (check_slices(c, "psm_download_volume", side, d0, d1)) return 1;
     if (bind(c)) return 1;
+    if (!c->have_cost) return fail(c, "psm_download_volume: no cost volume");
+    if (materialize(c, side)) return 1;
     const size_t S = (size_t)c->W * c->H * velem(c);
     PSM_HIP(c, hipMemcpyAsync(host, (const char *)c->vol[side] + (size_t)(d0 - c->d0) * S, (size_t)(d1 - d0) * S, hipMemcpyDeviceToHost, c->stream));
     PSM_HIP(c, hipStreamSynchronize(c->stream));
@@ -632,11 +672,13 @@ int psm_upload_volume(psm_ctx *c, int side, int d0, int d1, const void *host)
     if (!c || !host) return 1;
     if (check_slices(c, "psm_upload_volume", side, d0, d1)) return 1;
     if (bind(c)) return 1;
+    if (c->have_cost && c->have_g1 && materialize(c, side)) return 1;   // a partial upload must not leave virtual slices
     const size_t S = (size_t)c->W * c->H * velem(c);
     PSM_HIP(c, hipMemcpyAsync((char *)c->vol[side] + (size_t)(d0 - c->d0) * S, host, (size_t)(d1 - d0) * S, hipMemcpyHostToDevice, c->stream));
     PSM_HIP(c, hipStreamSynchronize(c->stream));
     c->have_cost = true;
     c->have_maps = false;
+    c->raw_rows[side] = psm_ctx::RAW_ALL;
     return 0;
 }
 
@@ -680,6 +722,7 @@ int psm_box8_volume(psm_ctx *c, int side, float *host)
     if (c->dtype != PSM_F32) return fail(c, "psm_box8_volume: float mode only");
     if (!c->have_cost) return fail(c, "psm_box8_volume: no cost volume");
     if (bind(c)) return 1;
+    if (materialize(c, side)) return 1;
     {
         Prof p(c, PSM_K_BOX);
         launch_box8(c->stream, c->opt_variant, c->march, (const float *)c->vol[side], (float *)c->ab, c->W, c->H, c->Dloc);

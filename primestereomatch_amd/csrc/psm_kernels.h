@@ -31,7 +31,7 @@ void launch_prep(hipStream_t s, const void *src, size_t pitch, int depth_f32, in
 void launch_guidance(hipStream_t s, Guidance g, double *hs9, int W, int H);
 // cost volume slices [d_begin, d_begin+Dloc) of one side.  base: g1 of the side's own image.
 void launch_cvc(hipStream_t s, const float4 *g1_base, const float4 *g1_other, float *vol, int W, int H,
-                int d_begin, int Dloc, int right, int flags);
+                int d_begin, int Dloc, int right, int flags, int ybeg, int yend);
 // guided filter halves.  variant 0 = marching, 1 = direct per-voxel.
 // [ybeg, yend): output rows of this launch (the arithmetic always refers to the full H-row planes)
 void launch_cvf_a(hipStream_t s, int variant, March m, const float *vol, float4 *ab, Guidance g, int W,
@@ -39,8 +39,9 @@ void launch_cvf_a(hipStream_t s, int variant, March m, const float *vol, float4 
 void launch_cvf_b(hipStream_t s, int variant, March m, const float4 *ab, float *vol, Guidance g, int W,
                   int H, int Dloc, int ybeg, int yend);
 // fused stage A+B: vin -> vout (distinct buffers), output rows [ybeg, yend) within [4, H-3)
+// cvc_mode 0: read the cost slices from vin; 1/2: build the left/right costs on the fly from the g1 planes
 void launch_cvf_fused(hipStream_t s, March m, const float *vin, float *vout, Guidance g, int W, int H, int Dloc,
-                      int ybeg, int yend);
+                      int ybeg, int yend, const float4 *g1_other, int d_begin, int cvc_mode);
 // plain 8x8 box filter of every slice (the north-star kernel in isolation)
 void launch_box8(hipStream_t s, int variant, March m, const float *vol, float *out, int W, int H, int Dloc);
 // WTA over local slices -> packed keys (keys != NULL) and/or final map (map != NULL)

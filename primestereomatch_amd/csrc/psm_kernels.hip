@@ -277,9 +277,9 @@ __device__ __forceinline__ float cost_border(float4 a)
 constexpr int CVC_DC = 8;
 template <bool RIGHT>
 __global__ __launch_bounds__(256) void k_cvc(const float4 *__restrict__ base, const float4 *__restrict__ other,
-                                            float *__restrict__ vol, int W, int H, int d_begin, int Dloc)
+                                            float *__restrict__ vol, int W, int H, int d_begin, int Dloc, int y0)
 {
-    int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y + y0;
     int dl0 = blockIdx.z * CVC_DC;
     if (x >= W) return;
     const size_t HW = (size_t)H * W;
@@ -306,9 +306,9 @@ __global__ __launch_bounds__(256) void k_cvc(const float4 *__restrict__ base, co
 // k_cvc read as many bytes as it wrote).  Needs W % 4 == 0.
 template <bool RIGHT>
 __global__ __launch_bounds__(256) void k_cvc4(const float4 *__restrict__ base, const float4 *__restrict__ other,
-                                             float *__restrict__ vol, int W, int H, int d_begin, int Dloc)
+                                             float *__restrict__ vol, int W, int H, int d_begin, int Dloc, int y0)
 {
-    int x = (blockIdx.x * blockDim.x + threadIdx.x) * 4, y = blockIdx.y;
+    int x = (blockIdx.x * blockDim.x + threadIdx.x) * 4, y = blockIdx.y + y0;
     int dl0 = blockIdx.z * CVC_DC;
     if (x >= W) return;
     const size_t HW = (size_t)H * W;
@@ -345,11 +345,11 @@ __global__ __launch_bounds__(256) void k_cvc4(const float4 *__restrict__ base, c
 // dword store (which made the L2 fill every line from HBM first).  Needs W % 4 == 0.
 template <bool RIGHT>
 __global__ __launch_bounds__(256) void k_cvc_t(const float4 *__restrict__ base, const float4 *__restrict__ other,
-                                              float *__restrict__ vol, int W, int H, int d_begin, int Dloc)
+                                              float *__restrict__ vol, int W, int H, int d_begin, int Dloc, int y0)
 {
     __shared__ __attribute__((aligned(16))) float lds[4][CVC_DC][64];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y + y0;
     const int dl0 = blockIdx.z * CVC_DC;
     const int xc = min(x, W - 1);
     const size_t HW = (size_t)H * W;
@@ -380,29 +380,21 @@ __global__ __launch_bounds__(256) void k_cvc_t(const float4 *__restrict__ base, 
 }
 
 void launch_cvc(hipStream_t s, const float4 *g1_base, const float4 *g1_other, float *vol, int W, int H,
-                int d_begin, int Dloc, int right, int flags)
+                int d_begin, int Dloc, int right, int flags, int ybeg, int yend)
 {
-    if (!(flags & 64) && !(flags & 8) && (W & 3) == 0) {
-        dim3 grid((W + 255) / 256, H, (Dloc + CVC_DC - 1) / CVC_DC);
-        if (right)
-            hipLaunchKernelGGL(k_cvc_t<true>, grid, dim3(256), 0, s, g1_base, g1_other, vol, W, H, d_begin, Dloc);
-        else
-            hipLaunchKernelGGL(k_cvc_t<false>, grid, dim3(256), 0, s, g1_base, g1_other, vol, W, H, d_begin, Dloc);
-        return;
+    if (yend <= ybeg) return;
+    const int rows = yend - ybeg;
+    const int nz = (Dloc + CVC_DC - 1) / CVC_DC;
+#define PSM_LAUNCH_CVC(KERNEL, GX)                                                                              \
+    {                                                                                                           \
+        dim3 grid(GX, rows, nz);                                                                                \
+        if (right) hipLaunchKernelGGL(KERNEL<true>, grid, dim3(256), 0, s, g1_base, g1_other, vol, W, H, d_begin, Dloc, ybeg); \
+        else hipLaunchKernelGGL(KERNEL<false>, grid, dim3(256), 0, s, g1_base, g1_other, vol, W, H, d_begin, Dloc, ybeg);      \
     }
-    if ((flags & 8) && (W & 3) == 0) {
-        dim3 grid((W / 4 + 255) / 256, H, (Dloc + CVC_DC - 1) / CVC_DC);
-        if (right)
-            hipLaunchKernelGGL(k_cvc4<true>, grid, dim3(256), 0, s, g1_base, g1_other, vol, W, H, d_begin, Dloc);
-        else
-            hipLaunchKernelGGL(k_cvc4<false>, grid, dim3(256), 0, s, g1_base, g1_other, vol, W, H, d_begin, Dloc);
-        return;
-    }
-    dim3 grid((W + 255) / 256, H, (Dloc + CVC_DC - 1) / CVC_DC);
-    if (right)
-        hipLaunchKernelGGL(k_cvc<true>, grid, dim3(256), 0, s, g1_base, g1_other, vol, W, H, d_begin, Dloc);
-    else
-        hipLaunchKernelGGL(k_cvc<false>, grid, dim3(256), 0, s, g1_base, g1_other, vol, W, H, d_begin, Dloc);
+    if (!(flags & 64) && !(flags & 8) && (W & 3) == 0) PSM_LAUNCH_CVC(k_cvc_t, (W + 255) / 256)
+    else if ((flags & 8) && (W & 3) == 0) PSM_LAUNCH_CVC(k_cvc4, (W / 4 + 255) / 256)
+    else PSM_LAUNCH_CVC(k_cvc, (W + 255) / 256)
+#undef PSM_LAUNCH_CVC
 }
 
 // ------------------------------------------------------------------------------------------
@@ -822,12 +814,16 @@ constexpr int PC_NA = 1, PC_NB = 1, PC_OUT_A = 39, PC_OUT_B = 32, PC_COLS = 32;
 constexpr int PC_MCOLS = PC_NA * PC_OUT_A;   // model columns per workgroup (>= PC_COLS + 7)
 static_assert(PC_MCOLS >= PC_COLS + 7 && (PC_COLS % 4) == 0 && PC_OUT_A <= 57 && PC_OUT_B <= 57, "bad producer/consumer layout");
 
-template <bool VEC4>
+// CVC = 0: the cost slice is read from `vin`.  CVC = 1 (left volume) / 2 (right volume): the cost volume
+// is never materialised - the producer waves evaluate myCostGrd (src/CVC.cpp:18-39) for their input
+// column on the fly from the two g1 planes (`G1` = this side's image, `Gother` = the other one), exactly
+// as k_cvc does; saves the 4 B/voxel write of CostConst and the 4 B/voxel read here.
+template <bool VEC4, int CVC>
 __global__ __launch_bounds__(64 * (PC_NA + PC_NB)) PSM_PC_ATTR void k_cvf_pc(const float *__restrict__ vin, float *__restrict__ vout,
                                                const float4 *__restrict__ G1, const float4 *__restrict__ G2,
                                                const float4 *__restrict__ G3, const float2 *__restrict__ G4,
                                                int W, int H, int Dloc, int ngroups, int nsegs, int seg_rows,
-                                               int ybeg, int yend)
+                                               int ybeg, int yend, const float4 *__restrict__ Gother, int d_begin)
 {
     __shared__ __attribute__((aligned(16))) float4 ring[2][4][PC_MCOLS];   // model rows, two batches
     __shared__ __attribute__((aligned(16))) float qbuf[2][4][PC_COLS];     // output rows, two batches
@@ -862,8 +858,14 @@ __global__ __launch_bounds__(64 * (PC_NA + PC_NB)) PSM_PC_ATTR void k_cvf_pc(con
         const int xac = xa < 0 ? 0 : (xa > W - 1 ? W - 1 : xa);
         const bool mvalid = lane < PC_OUT_A;
         const float *vd = vin + (size_t)d * HW;
+        const int dg = d_begin + d;                   // global disparity of this slice
+        // buildCV_left: partner x-d while x >= d; buildCV_right: partner x+d while x < W-d (src/CVC.cpp:135-146,165-176)
+        const bool inb = CVC == 2 ? (ci < W - dg) : (ci >= dg);
+        const int cpart = CVC == 2 ? min(ci + dg, W - 1) : max(ci - dg, 0);
+        const bool any_border = CVC != 0 && __builtin_amdgcn_ballot_w64(!inb) != 0;
         VTree t0 = {}, t1 = {}, t2 = {}, t3 = {};
         float pin[PC_SLOTS];
+        float4 oth[PC_SLOTS];
         float4 gin[PC_SLOTS], o2[PC_SLOTS], o3[PC_SLOTS];
         float2 o4[PC_SLOTS];
 #define PSM_ISSUE_PA(SLOT, STEP)                                                        \
@@ -877,7 +879,8 @@ __global__ __launch_bounds__(64 * (PC_NA + PC_NB)) PSM_PC_ATTR void k_cvf_pc(con
             pin[SLOT] = f_; gin[SLOT] = make_float4(f_, f_ * 2, f_ * 3, 0.f);           \
             o2[SLOT] = make_float4(f_, f_, f_, 1.f); o3[SLOT] = make_float4(f_, f_, 1.f, f_); o4[SLOT] = make_float2(f_, 1.f); \
         } else {                                                                        \
-            pin[SLOT] = vd[off_];                                                       \
+            if (CVC == 0) pin[SLOT] = vd[off_];                                         \
+            else oth[SLOT] = Gother[off_ - ci + cpart];                                 \
             gin[SLOT] = G1[off_];                                                       \
             o2[SLOT] = G2[oa_];                                                         \
             o3[SLOT] = G3[oa_];                                                         \
@@ -898,7 +901,12 @@ __global__ __launch_bounds__(64 * (PC_NA + PC_NB)) PSM_PC_ATTR void k_cvf_pc(con
 #define PSM_STEP_PA(K)                                                                              \
     {                                                                                               \
         PSM_ISSUE_PA((K + PSM_PC_P) & (PC_SLOTS - 1), i + K + PSM_PC_P)                             \
-        const float p = pin[K & (PC_SLOTS - 1)];                                                    \
+        float p;                                                                                    \
+        if (CVC == 0) p = pin[K & (PC_SLOTS - 1)];                                                  \
+        else {                                                                                      \
+            p = cost_pair(gin[K & (PC_SLOTS - 1)], oth[K & (PC_SLOTS - 1)]);                        \
+            if (any_border) { const float cb_ = cost_border(gin[K & (PC_SLOTS - 1)]); p = inb ? p : cb_; } \
+        }                                                                                           \
         if (PSM_PC_ABL & 4) { if (mvalid) dst[K * PC_MCOLS] = make_float4(p, gin[K & (PC_SLOTS - 1)].x, o2[K & (PC_SLOTS - 1)].x + o3[K & (PC_SLOTS - 1)].x, o4[K & (PC_SLOTS - 1)].x); } else { \
         double h0 = hsum8(p, i1, i2, i4);                                                           \
         double h1 = hsum8(__fmul_rn(gin[K & (PC_SLOTS - 1)].x, p), i1, i2, i4);                     \
@@ -1198,7 +1206,7 @@ void launch_cvf_b(hipStream_t s, int variant, March m, const float4 *ab, float *
 }
 
 void launch_cvf_fused(hipStream_t s, March m, const float *vin, float *vout, Guidance gd, int W, int H, int Dloc,
-                      int ybeg, int yend)
+                      int ybeg, int yend, const float4 *g1_other, int d_begin, int cvc_mode)
 {
     if (yend <= ybeg) return;
     const int rows = yend - ybeg;
@@ -1218,12 +1226,16 @@ void launch_cvf_fused(hipStream_t s, March m, const float *vin, float *vout, Gui
     if (!(m.flags & 32)) {
         const int ngroups = (W + PC_COLS - 1) / PC_COLS;
         const int nblocks = ngroups * Dloc * nsegs;
-        if ((W & 3) == 0)
-            hipLaunchKernelGGL(k_cvf_pc<true>, dim3(nblocks), dim3(64 * (PC_NA + PC_NB)), 0, s, vin, vout, (const float4 *)gd.g1, (const float4 *)gd.g2,
-                               (const float4 *)gd.g3, (const float2 *)gd.g4, W, H, Dloc, ngroups, nsegs, seg_rows, ybeg, yend);
-        else
-            hipLaunchKernelGGL(k_cvf_pc<false>, dim3(nblocks), dim3(64 * (PC_NA + PC_NB)), 0, s, vin, vout, (const float4 *)gd.g1, (const float4 *)gd.g2,
-                               (const float4 *)gd.g3, (const float2 *)gd.g4, W, H, Dloc, ngroups, nsegs, seg_rows, ybeg, yend);
+        const dim3 blk(64 * (PC_NA + PC_NB));
+#define PSM_LAUNCH_PC(V4, CV)                                                                                              \
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_cvf_pc<V4, CV>), dim3(nblocks), blk, 0, s, vin, vout, (const float4 *)gd.g1,      \
+                       (const float4 *)gd.g2, (const float4 *)gd.g3, (const float2 *)gd.g4, W, H, Dloc, ngroups, nsegs,   \
+                       seg_rows, ybeg, yend, g1_other, d_begin)
+        const bool v4 = (W & 3) == 0;
+        if (cvc_mode == 1) { if (v4) PSM_LAUNCH_PC(true, 1); else PSM_LAUNCH_PC(false, 1); }
+        else if (cvc_mode == 2) { if (v4) PSM_LAUNCH_PC(true, 2); else PSM_LAUNCH_PC(false, 2); }
+        else { if (v4) PSM_LAUNCH_PC(true, 0); else PSM_LAUNCH_PC(false, 0); }
+#undef PSM_LAUNCH_PC
         return;
     }
     const int ngroups = (W + XF_COLS - 1) / XF_COLS;

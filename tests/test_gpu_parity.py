@@ -441,7 +441,7 @@ def test_cpp_dispest_demo(psm, oracle, golden, tmp_path, mode, float_input):
     assert np.array_equal(lv, oracle.lr_check(ld, rd)[0])
 
 
-@pytest.mark.parametrize("flags", [0, 8, 64, 32, 16, 16 + 2, 16 + 8 + 4])
+@pytest.mark.parametrize("flags", [0, 128, 128 + 8, 128 + 64, 32, 16, 16 + 2, 16 + 8 + 4])
 def test_tuning_flags_do_not_change_results(psm, oracle, flags):
     """PSM_OPT_FLAGS only changes store policy / block traversal / CVC store width."""
     from primestereomatch_amd import capi, synth
@@ -485,3 +485,28 @@ def test_fill_invalid_synthetic_width(psm, oracle):
         assert np.array_equal(de.lDisMap, oracle.fill_inv(lraw, lv)) and np.array_equal(de.rDisMap, oracle.fill_inv(rraw, rv))
         with pytest.raises(Exception):
             de.FillInv_GPU()        # validity refers to the unfilled maps: needs a new LRCheck_GPU
+
+
+@pytest.mark.parametrize("W,H,D", [(96, 40, 9), (200, 33, 20), (100, 22, 5), (61, 21, 4), (450, 60, 70)])
+def test_lazy_cost_volume_equals_materialised(psm, oracle, W, H, D):
+    """Default path: CostConst leaves the volumes virtual and the fused filter builds the costs on the fly
+    (border columns x<d / x>=W-d included); flag 128 writes them first.  Same bits either way."""
+    from primestereomatch_amd import capi
+    l, r = rand_pair(H, W, 21)
+    outs = []
+    for flags in (0, 128):
+        with psm.DispEst(l, r, D) as de:
+            de.set_option(capi.PSM_OPT_FLAGS, flags)
+            de.CostConst_GPU(); de.CostFilter_GPU(); de.DispSelect_GPU()
+            outs.append((de.download_volume(0), de.download_volume(1), de.lDisMap.copy(), de.rDisMap.copy()))
+    ref = oracle.pipeline_f32(l, r, D, threads=4, want_volumes=True)
+    for o in outs:
+        assert np.array_equal(o[0], ref["lvol"]) and np.array_equal(o[1], ref["rvol"])
+        assert np.array_equal(o[2], ref["ldisp"]) and np.array_equal(o[3], ref["rdisp"])
+    # reading the raw volume after a lazy CostConst materialises it
+    with psm.DispEst(l, r, D) as de:
+        de.CostConst_GPU()
+        raw = oracle.pipeline_f32(l, r, D, threads=4, want_raw=True)
+        assert np.array_equal(de.download_volume(1), raw["raw_r"])
+        de.DispSelect_GPU()                      # WTA on the unfiltered volumes
+        assert np.array_equal(de.lDisMap, oracle.wta(raw["raw_l"]))
