@@ -410,7 +410,7 @@ static int filter_side(psm_ctx *c, int side, bool stage_b)
     if (!c->have_g1 && run_prep(c)) return 1;  // volume came from psm_upload_volume
     {
         Prof p(c, PSM_K_GUIDE);
-        launch_guidance(c->stream, c->g[side], c->hs9, W, H);
+        launch_guidance(c->stream, c->g[side], c->hs9, W, H, (c->march.flags & 256) ? 1 : 0);
     }
     float *fv = (float *)c->vol[side];
     if (c->dtype == PSM_U8) {

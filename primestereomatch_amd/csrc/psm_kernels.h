@@ -28,7 +28,7 @@ struct March {       // geometry of the marching kernels
 // image -> g1 (planarise, scale, gray, x-gradient).  src: device copy of the interleaved image.
 void launch_prep(hipStream_t s, const void *src, size_t pitch, int depth_f32, int W, int H, float4 *g1);
 // g1 -> g2,g3,g4.  hs9: scratch, 9*H*W doubles.
-void launch_guidance(hipStream_t s, Guidance g, double *hs9, int W, int H);
+void launch_guidance(hipStream_t s, Guidance g, double *hs9, int W, int H, int two_pass);
 // cost volume slices [d_begin, d_begin+Dloc) of one side.  base: g1 of the side's own image.
 void launch_cvc(hipStream_t s, const float4 *g1_base, const float4 *g1_other, float *vol, int W, int H,
                 int d_begin, int Dloc, int right, int flags, int ybeg, int yend);
