@@ -55,6 +55,9 @@ def main():
                     help="N>1 exchange step: one all_reduce(MIN) of the packed keys (default; ~2x33 MB per rank "
                          "at 1080p whatever N) or one all_gather ((N-1)x33 MB per rank) + device-side minimum")
     ap.add_argument("--box-bench", action="store_true", help="also time the plain box-filter pass")
+    ap.add_argument("--shard-sim", type=int, default=0,
+                    help="diagnostic: time only rank 0's disparity shard of a G-rank job on this GPU (no exchange); "
+                         "the JSON line is then NOT the headline metric")
     args = ap.parse_args()
 
     N = args.gpus
@@ -83,6 +86,8 @@ def main():
     W, H, D, desc = CONFIGS[args.config]
     if use_dist:
         d0, d1 = D * rank // world, D * (rank + 1) // world
+    elif args.shard_sim > 1:
+        d0, d1 = 0, D // args.shard_sim
     else:
         d0, d1 = 0, D
     l, r, _ = synth.make_pair(W, H, D, seed=0)
@@ -118,6 +123,8 @@ def main():
             else:
                 dist.all_gather_into_tensor(keys_all, keys_local)     # the one exchange step (RCCL)
                 de.DispSelect_merge(keys_all.data_ptr(), world, download=False)
+        elif args.shard_sim > 1:
+            de.DispSelect_partial()
         else:
             de.DispSelect_device()
 
@@ -225,7 +232,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": desc, "W": W, "H": H, "D": D, "voxels_per_step": voxels_per_step,
                        "parallelism": "1 GPU" if world == 1 else f"D sharded over {world} ranks + 1 RCCL {args.exchange} of packed minima",
-                       "kernel_variant": args.variant},
+                       "kernel_variant": args.variant, "shard_sim": args.shard_sim},
             "roofline": roofline, "cpu_baseline": cpu, "kernels": kern,
         }
         if box:

@@ -420,31 +420,34 @@ static int filter_side(psm_ctx *c, int side, bool stage_b)
     const bool fused = stage_b && c->dtype == PSM_F32 && c->opt_variant == 0 && !(c->march.flags & 16) && H >= 8;
     if (!fused && materialize(c, side)) return 1;
     if (fused) {
-        const int cvc_mode = c->raw_rows[side] == psm_ctx::RAW_ALL ? 0 : 1 + side;
-        if (cvc_mode != 0) {   // the band kernels read cost rows 0..10 and H-11..H-1 from memory
-            if (H >= 22) { launch_cvc_rows(c, side, 0, 11); launch_cvc_rows(c, side, H - 11, H); }
-            else launch_cvc_rows(c, side, 0, H);
-        }
-        // rows 4 .. H-4 in one pass (p -> q); the border rows, whose second box filter reflects
-        // model rows, go through the two-stage kernels on thin bands (7 model rows, 4+3 outputs)
         float *out = c->spare;
-        {
-            Prof p(c, PSM_K_CVF_A);
-            if (H >= 14) {
-                launch_cvf_a(c->stream, 0, c->march, fv, c->ab, c->g[side], W, H, c->Dloc, 0, 7);
-                launch_cvf_a(c->stream, 0, c->march, fv, c->ab, c->g[side], W, H, c->Dloc, H - 7, H);
-            } else {
-                launch_cvf_a(c->stream, 0, c->march, fv, c->ab, c->g[side], W, H, c->Dloc, 0, H);
-            }
-        }
-        {
-            Prof p(c, PSM_K_CVF_B);
-            launch_cvf_b(c->stream, 0, c->march, c->ab, out, c->g[side], W, H, c->Dloc, 0, 4);
-            launch_cvf_b(c->stream, 0, c->march, c->ab, out, c->g[side], W, H, c->Dloc, H - 3 > 4 ? H - 3 : 4, H);
-        }
-        {
+        if (!(c->march.flags & 32)) {
+            // producer/consumer kernel: all rows in one launch; the cost slices may still be virtual
+            const int cvc_mode = c->raw_rows[side] == psm_ctx::RAW_ALL ? 0 : 1 + side;
             Prof p(c, PSM_K_CVF_F);
-            launch_cvf_fused(c->stream, c->march, fv, out, c->g[side], W, H, c->Dloc, 4, H - 3, c->g[1 - side].g1, c->d0, cvc_mode);
+            launch_cvf_fused(c->stream, c->march, fv, out, c->g[side], W, H, c->Dloc, 0, H, c->g[1 - side].g1, c->d0, cvc_mode);
+        } else {
+            // single-wave fused kernel: rows 4 .. H-4 only; the border rows, whose second box filter reflects
+            // model rows, go through the two-stage kernels on thin bands (7 model rows, 4+3 outputs)
+            if (materialize(c, side)) return 1;
+            {
+                Prof p(c, PSM_K_CVF_A);
+                if (H >= 14) {
+                    launch_cvf_a(c->stream, 0, c->march, fv, c->ab, c->g[side], W, H, c->Dloc, 0, 7);
+                    launch_cvf_a(c->stream, 0, c->march, fv, c->ab, c->g[side], W, H, c->Dloc, H - 7, H);
+                } else {
+                    launch_cvf_a(c->stream, 0, c->march, fv, c->ab, c->g[side], W, H, c->Dloc, 0, H);
+                }
+            }
+            {
+                Prof p(c, PSM_K_CVF_B);
+                launch_cvf_b(c->stream, 0, c->march, c->ab, out, c->g[side], W, H, c->Dloc, 0, 4);
+                launch_cvf_b(c->stream, 0, c->march, c->ab, out, c->g[side], W, H, c->Dloc, H - 3 > 4 ? H - 3 : 4, H);
+            }
+            {
+                Prof p(c, PSM_K_CVF_F);
+                launch_cvf_fused(c->stream, c->march, fv, out, c->g[side], W, H, c->Dloc, 4, H - 3, c->g[1 - side].g1, c->d0, 0);
+            }
         }
         c->spare = fv;          // ping-pong: the filtered volume becomes vol[side]
         c->vol[side] = out;

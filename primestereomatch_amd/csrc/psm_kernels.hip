@@ -868,7 +868,7 @@ __global__ __launch_bounds__(256) void k_cvf_fused(const float *__restrict__ vin
 #ifndef PSM_PC_P
 #define PSM_PC_P 1          // (measured: 1 -> 4.14 ms, 3 -> 4.37 ms at 1080p x 256)  load look-ahead of the producer waves in steps: 3 (4-slot ring) or 1 (2 slots)
 #endif
-constexpr int PC_SLOTS = PSM_PC_P + 1;
+constexpr int PC_RING = 4;   // batches of four model rows kept in LDS
 #ifndef PSM_PC_ABL
 #define PSM_PC_ABL 0   // experiments: 1 no global loads in A, 2 no B compute, 4 no A compute, 8 no barriers-between (invalid results)
 #endif
@@ -900,34 +900,34 @@ __global__ __launch_bounds__(64 * (PC_NA + PC_NB)) PSM_PC_ATTR void k_cvf_pc(con
                                                int W, int H, int Dloc, int ngroups, int nsegs, int seg_rows,
                                                int ybeg, int yend, const float4 *__restrict__ Gother, int d_begin)
 {
-    __shared__ __attribute__((aligned(16))) float4 ring[2][4][PC_MCOLS];   // model rows, two batches
+    // Model rows live in a ring of PC_RING batches of four rows; consumers run two batches behind the
+    // producers, so every model row the second box filter can ask for - including the REFLECT_101 rows at
+    // the top and bottom of the image, which are earlier/later rows of the same ring - is still present.
+    __shared__ __attribute__((aligned(16))) float4 ring[PC_RING][4][PC_MCOLS];
     __shared__ __attribute__((aligned(16))) float qbuf[2][4][PC_COLS];     // output rows, two batches
     int id = blockIdx.x;
     const int g = id % ngroups, rest = id / ngroups;
     const int d = rest % Dloc, seg = rest / Dloc;
     if (seg >= nsegs) return;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-#ifdef PSM_PC_SWAP
-    // alternate the roles of the wave slots from workgroup to workgroup so that, whatever the
-    // wave->SIMD placement is, producer and consumer waves mix on every SIMD
-    const int role = (blockIdx.x & 1) ? (wave + PC_NA) % (PC_NA + PC_NB) : wave;
-#else
-    const int role = wave;
-#endif
-    const bool is_a = role < PC_NA;
+    const bool is_a = wave < PC_NA;
     const int xg = g * PC_COLS;                       // first output column of the workgroup
     const int xm0 = xg - 4;                           // first model column of the workgroup
-    const int y0 = ybeg + seg * seg_rows, y1 = min(yend, y0 + seg_rows);
-    const int n = (y1 - y0) + 14;                     // steps (input rows)
-    const int nb = (n + 3) >> 2;                      // batches
-    const int ybase = y0 - 8;                         // input row of step 0
+    const int y0 = ybeg + seg * seg_rows, y1 = min(yend, y0 + seg_rows);   // output rows [y0, y1)
+    const int mstart = max(0, y0 - 4);                // model rows produced: mstart .. mend
+    const int mend = min(H - 1, y1 + 2);
+    const int nbA = (mend - mstart + 1 + 3) >> 2;     // producer batches
+    const int nf = (y1 - y0) + 7;                     // consumer feeds (model rows y0-4 .. y1+2, reflected)
+    const int nbB = (nf + 3) >> 2;                    // consumer batches
+    const int iters = nbB + 3;                        // barriers executed by every wave
     const int i1 = ((lane + 1) & 63) << 2, i2 = ((lane + 2) & 63) << 2, i4 = ((lane + 4) & 63) << 2;
     (void)i1;
     const size_t HW = (size_t)H * W;
 
     if (is_a) {
         // ---------------- producer: stage A ----------------
-        const int xa0 = xm0 + role * PC_OUT_A;        // first model column of this wave
+        // step s reads input row mstart-5+s; from step 8 on it yields model row mstart+(s-8)
+        const int xa0 = xm0 + wave * PC_OUT_A;        // first model column of this wave
         const int ci = r101c(xa0 - 4 + lane, W);      // input column of this lane
         const int xa = xa0 + lane;                    // model column of this lane
         const int xac = xa < 0 ? 0 : (xa > W - 1 ? W - 1 : xa);
@@ -939,129 +939,127 @@ __global__ __launch_bounds__(64 * (PC_NA + PC_NB)) PSM_PC_ATTR void k_cvf_pc(con
         const int cpart = CVC == 2 ? min(ci + dg, W - 1) : max(ci - dg, 0);
         const bool any_border = CVC != 0 && __builtin_amdgcn_ballot_w64(!inb) != 0;
         VTree t0 = {}, t1 = {}, t2 = {}, t3 = {};
-        float pin[PC_SLOTS];
-        float4 oth[PC_SLOTS];
-        float4 gin[PC_SLOTS], o2[PC_SLOTS], o3[PC_SLOTS];
-        float2 o4[PC_SLOTS];
+        float pin[2];
+        float4 oth[2], gin[2], o2[2], o3[2];
+        float2 o4[2];
 #define PSM_ISSUE_PA(SLOT, STEP)                                                        \
     {                                                                                   \
-        const size_t off_ = (size_t)r101c(ybase + (STEP), H) * W + ci;                  \
-        int ya_ = ybase + (STEP) - 3;                                                   \
+        const size_t off_ = (size_t)r101c(mstart - 5 + (STEP), H) * W + ci;             \
+        int ya_ = mstart - 8 + (STEP);                                                  \
         ya_ = ya_ < 0 ? 0 : (ya_ > H - 1 ? H - 1 : ya_);                                \
         const size_t oa_ = (size_t)ya_ * W + xac;                                       \
-        if (PSM_PC_ABL & 1) {                                                           \
-            const float f_ = (float)(lane + (STEP)) * 1e-3f;                            \
-            pin[SLOT] = f_; gin[SLOT] = make_float4(f_, f_ * 2, f_ * 3, 0.f);           \
-            o2[SLOT] = make_float4(f_, f_, f_, 1.f); o3[SLOT] = make_float4(f_, f_, 1.f, f_); o4[SLOT] = make_float2(f_, 1.f); \
-        } else {                                                                        \
-            if (CVC == 0) pin[SLOT] = vd[off_];                                         \
-            else oth[SLOT] = Gother[off_ - ci + cpart];                                 \
-            gin[SLOT] = G1[off_];                                                       \
-            o2[SLOT] = G2[oa_];                                                         \
-            o3[SLOT] = G3[oa_];                                                         \
-            o4[SLOT] = G4[oa_];                                                         \
-        }                                                                               \
+        if (CVC == 0) pin[SLOT] = vd[off_];                                             \
+        else oth[SLOT] = Gother[off_ - ci + cpart];                                     \
+        gin[SLOT] = G1[off_];                                                           \
+        o2[SLOT] = G2[oa_];                                                             \
+        o3[SLOT] = G3[oa_];                                                             \
+        o4[SLOT] = G4[oa_];                                                             \
     }
-        PSM_ISSUE_PA(0, 0) __builtin_amdgcn_sched_barrier(0);
-#if PSM_PC_P == 3
-        PSM_ISSUE_PA(1, 1) __builtin_amdgcn_sched_barrier(0);
-        PSM_ISSUE_PA(2, 2) __builtin_amdgcn_sched_barrier(0);
-#endif
-        // (loop bodies are kept free of conditionals around the tree updates: a conditional makes the
-        // trees loop-carried phis and the compiler then keeps two copies of all 56 state registers)
-        for (int b = 0; b < nb; ++b) {
-            {
-                const int i = b * 4;
-                float4 *dst = &ring[b & 1][0][role * PC_OUT_A + lane];
-#define PSM_STEP_PA(K)                                                                              \
+        // one step: consume the loads of step S (slot K&1), issue those of step S+1
+#define PSM_STEP_PA(K, S, DST)                                                                      \
     {                                                                                               \
-        PSM_ISSUE_PA((K + PSM_PC_P) & (PC_SLOTS - 1), i + K + PSM_PC_P)                             \
+        PSM_ISSUE_PA((K + 1) & 1, (S) + 1)                                                          \
         float p;                                                                                    \
-        if (CVC == 0) p = pin[K & (PC_SLOTS - 1)];                                                  \
+        if (CVC == 0) p = pin[K & 1];                                                               \
         else {                                                                                      \
-            p = cost_pair(gin[K & (PC_SLOTS - 1)], oth[K & (PC_SLOTS - 1)]);                        \
-            if (any_border) { const float cb_ = cost_border(gin[K & (PC_SLOTS - 1)]); p = inb ? p : cb_; } \
+            p = cost_pair(gin[K & 1], oth[K & 1]);                                                  \
+            if (any_border) { const float cb_ = cost_border(gin[K & 1]); p = inb ? p : cb_; }       \
         }                                                                                           \
-        if (PSM_PC_ABL & 4) { if (mvalid) dst[K * PC_MCOLS] = make_float4(p, gin[K & (PC_SLOTS - 1)].x, o2[K & (PC_SLOTS - 1)].x + o3[K & (PC_SLOTS - 1)].x, o4[K & (PC_SLOTS - 1)].x); } else { \
         double h0 = hsum8(p, i1, i2, i4);                                                           \
-        double h1 = hsum8(__fmul_rn(gin[K & (PC_SLOTS - 1)].x, p), i1, i2, i4);                     \
-        double h2 = hsum8(__fmul_rn(gin[K & (PC_SLOTS - 1)].y, p), i1, i2, i4);                     \
-        double h3 = hsum8(__fmul_rn(gin[K & (PC_SLOTS - 1)].z, p), i1, i2, i4);                     \
+        double h1 = hsum8(__fmul_rn(gin[K & 1].x, p), i1, i2, i4);                                  \
+        double h2 = hsum8(__fmul_rn(gin[K & 1].y, p), i1, i2, i4);                                  \
+        double h3 = hsum8(__fmul_rn(gin[K & 1].z, p), i1, i2, i4);                                  \
         double n0 = vstep<K>(t0, h0), n1 = vstep<K>(t1, h1), n2 = vstep<K>(t2, h2), n3 = vstep<K>(t3, h3); \
-        float4 r = solve_ab(box_out(n0), box_out(n1), box_out(n2), box_out(n3), o2[K & (PC_SLOTS - 1)], o3[K & (PC_SLOTS - 1)], o4[K & (PC_SLOTS - 1)]); \
-        if (mvalid) dst[K * PC_MCOLS] = r; }                                                        \
+        float4 r = solve_ab(box_out(n0), box_out(n1), box_out(n2), box_out(n3), o2[K & 1], o3[K & 1], o4[K & 1]); \
+        if ((DST) != nullptr && mvalid) (DST)[K * PC_MCOLS] = r;                                    \
         __builtin_amdgcn_sched_barrier(0);                                                          \
     }
-                PSM_STEP_PA(0) PSM_STEP_PA(1) PSM_STEP_PA(2) PSM_STEP_PA(3)
-#undef PSM_STEP_PA
-            }
+        PSM_ISSUE_PA(0, 0) __builtin_amdgcn_sched_barrier(0);
+        {   // warm-up: 8 rows fill the tree (loop bodies stay free of conditionals around the tree updates:
+            // a conditional turns the trees into loop-carried phis and doubles their registers)
+            float4 *const none = nullptr;
+            PSM_STEP_PA(0, 0, none) PSM_STEP_PA(1, 1, none) PSM_STEP_PA(2, 2, none) PSM_STEP_PA(3, 3, none)
+            PSM_STEP_PA(0, 4, none) PSM_STEP_PA(1, 5, none) PSM_STEP_PA(2, 6, none) PSM_STEP_PA(3, 7, none)
+        }
+        for (int b = 0; b < nbA; ++b) {
+            const int s0 = 8 + b * 4;
+            float4 *dst = &ring[b & (PC_RING - 1)][0][wave * PC_OUT_A + lane];
+            PSM_STEP_PA(0, s0, dst) PSM_STEP_PA(1, s0 + 1, dst) PSM_STEP_PA(2, s0 + 2, dst) PSM_STEP_PA(3, s0 + 3, dst)
             __syncthreads();
         }
-        __syncthreads();   // the consumers' last batch
-        __syncthreads();   // the consumers' last store
+        for (int b = nbA; b < iters; ++b) __syncthreads();
+#undef PSM_STEP_PA
 #undef PSM_ISSUE_PA
     } else {
         // ---------------- consumer: stage B ----------------
-        const int wb = role - PC_NA;
+        // feed j (j = 0 .. nf-1) is model row r101(y0-4+j); from feed 7 on the tree yields output row y0+j-7
+        const int wb = wave - PC_NA;
         const int bwidth = wb < PC_NB - 1 ? PC_OUT_B : PC_COLS - (PC_NB - 1) * PC_OUT_B;
         const int xb0 = xg + wb * PC_OUT_B;           // first output column of this wave
         const int xmod = xb0 - 4 + lane;              // model column this lane consumes
-        int mc = r101(xmod, W) - xm0;                 // REFLECT_101 of the model planes, as ring index
+        int mc = r101(xmod, W) - xm0;                 // REFLECT_101 of the model planes, as ring column
         mc = mc < 0 ? 0 : (mc > PC_MCOLS - 1 ? PC_MCOLS - 1 : mc);
         const int xb = xb0 + lane;                    // output column of this lane
         const int xbc = min(xb, W - 1);
         float *od = vout + (size_t)d * HW;
+        const int amax = 4 * nbA - 1;
         VTree t0 = {}, t1 = {}, t2 = {}, t3 = {};
         float o1x[4], o1y[4], o1z[4];                 // g1.xyz at (output row, output column), one batch ahead
-#define PSM_ISSUE_PB(SLOT, STEP)                                                        \
+#define PSM_ISSUE_PB(SLOT, J)                                                           \
     {                                                                                   \
-        int yb_ = ybase + (STEP) - 6;                                                   \
+        int yb_ = y0 + (J) - 7;                                                         \
         yb_ = yb_ < 0 ? 0 : (yb_ > H - 1 ? H - 1 : yb_);                                \
         const float4 g_ = G1[(size_t)yb_ * W + xbc];                                    \
         o1x[SLOT] = g_.x; o1y[SLOT] = g_.y; o1z[SLOT] = g_.z;                           \
     }
-        PSM_ISSUE_PB(0, 0) PSM_ISSUE_PB(1, 1) PSM_ISSUE_PB(2, 2) PSM_ISSUE_PB(3, 3)
-        // merged store of output batch `bs` (rows parked in qbuf[bs & 1] one iteration earlier)
-        auto store_batch = [&](int bs) {
-            const int i = bs * 4;
+        // ring address of the model row that feed J consumes (wave-uniform arithmetic)
+        auto model_of = [&](int J) -> const float4 * {
+            int a = r101(y0 - 4 + J, H) - mstart;
+            a = a < 0 ? 0 : (a > amax ? amax : a);
+            return &ring[(a >> 2) & (PC_RING - 1)][a & 3][mc];
+        };
+        // merged store of output batch `c` (rows parked in qbuf[c & 1] one iteration earlier)
+        auto store_batch = [&](int c) {
 #pragma unroll
             for (int k = 0; k < 4; ++k) {          // row k of the batch is stored by B wave k % PC_NB
-                const int step = i + k;
-                if (k % PC_NB == wb && step >= 14 && step < n) {
-                    float *row = od + (size_t)(ybase + step - 6) * W + xg;
-                    const float *src = &qbuf[bs & 1][k][0];
+                const int j = 4 * c + k;
+                const int yo = y0 + j - 7;
+                if (k % PC_NB == wb && j >= 7 && yo < y1) {
+                    float *row = od + (size_t)yo * W + xg;
+                    const float *src = &qbuf[c & 1][k][0];
                     if (VEC4) {
-                        const int c = lane * 4;
-                        if (lane < PC_COLS / 4 && xg + c < W)
-                            *reinterpret_cast<float4 *>(row + c) = *reinterpret_cast<const float4 *>(src + c);
+                        const int cc = lane * 4;
+                        if (lane < PC_COLS / 4 && xg + cc < W)
+                            *reinterpret_cast<float4 *>(row + cc) = *reinterpret_cast<const float4 *>(src + cc);
                     } else {
 #pragma unroll
-                        for (int c = lane; c < PC_COLS; c += 64)
-                            if (xg + c < W) row[c] = src[c];
+                        for (int cc = lane; cc < PC_COLS; cc += 64)
+                            if (xg + cc < W) row[cc] = src[cc];
                     }
                 }
             }
         };
-        __syncthreads();                               // iteration 0: producers fill batch 0
-        for (int b = 1; b <= nb; ++b) {                // iteration b: consume model batch b-1
-            if (b >= 2) store_batch(b - 2);
+        PSM_ISSUE_PB(0, 0) PSM_ISSUE_PB(1, 1) PSM_ISSUE_PB(2, 2) PSM_ISSUE_PB(3, 3)
+        __syncthreads();                               // iteration 0
+        __syncthreads();                               // iteration 1
+        for (int b = 2; b <= nbB + 1; ++b) {           // iteration b: consume feed batch c = b-2
+            const int c = b - 2;
+            if (c >= 1) store_batch(c - 1);
             {
-                const int i = (b - 1) * 4;
-                const float4 *src = &ring[(b - 1) & 1][0][mc];
-                float4 a_cur = src[0], a_nxt;
+                const int j0 = 4 * c;
+                float4 a_cur = *model_of(j0), a_nxt;
                 float qv[4];
 #define PSM_STEP_PB(K)                                                                              \
     {                                                                                               \
-        if (K < 3) a_nxt = src[(K + 1) * PC_MCOLS];   /* model row of the next step, one step ahead */ \
-        if (PSM_PC_ABL & 2) { qv[K] = a_cur.x + a_cur.y + a_cur.z + a_cur.w + o1x[K]; } else {     \
+        if (K < 3) a_nxt = *model_of(j0 + K + 1);     /* model row of the next feed, one step ahead */ \
         double h0 = hsum8(a_cur.x, i1, i2, i4);                                                     \
         double h1 = hsum8(a_cur.y, i1, i2, i4);                                                     \
         double h2 = hsum8(a_cur.z, i1, i2, i4);                                                     \
         double h3 = hsum8(a_cur.w, i1, i2, i4);                                                     \
         double n0 = vstep<K>(t0, h0), n1 = vstep<K>(t1, h1), n2 = vstep<K>(t2, h2), n3 = vstep<K>(t3, h3); \
         qv[K] = __fadd_rn(__fadd_rn(__fadd_rn(box_out(n3), __fmul_rn(box_out(n0), o1x[K])),        \
-                                    __fmul_rn(box_out(n1), o1y[K])), __fmul_rn(box_out(n2), o1z[K])); } \
-        PSM_ISSUE_PB(K, i + K + 4)                                                                  \
+                                    __fmul_rn(box_out(n1), o1y[K])), __fmul_rn(box_out(n2), o1z[K])); \
+        PSM_ISSUE_PB(K, j0 + K + 4)                                                                 \
         a_cur = a_nxt;                                                                              \
         __builtin_amdgcn_sched_barrier(0);                                                          \
     }
@@ -1069,11 +1067,11 @@ __global__ __launch_bounds__(64 * (PC_NA + PC_NB)) PSM_PC_ATTR void k_cvf_pc(con
 #undef PSM_STEP_PB
 #pragma unroll
                 for (int k = 0; k < 4; ++k)
-                    if (lane < bwidth) qbuf[(b - 1) & 1][k][wb * PC_OUT_B + lane] = qv[k];
+                    if (lane < bwidth) qbuf[c & 1][k][wb * PC_OUT_B + lane] = qv[k];
             }
             __syncthreads();
         }
-        if (nb >= 1) store_batch(nb - 1);              // iteration nb+1
+        store_batch(nbB - 1);                          // iteration nbB+2
         __syncthreads();
 #undef PSM_ISSUE_PB
     }
