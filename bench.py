@@ -51,10 +51,13 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-d", type=int, default=24, help="disparities in the CPU-baseline sample")
     ap.add_argument("--force-dist", action="store_true", help="use the torch.distributed path even for N=1")
-    ap.add_argument("--exchange", default="allreduce", choices=["allreduce", "allgather"],
+    ap.add_argument("--exchange", default="allreduce", choices=["allreduce", "allgather", "none"],
                     help="N>1 exchange step: one all_reduce(MIN) of the packed keys (default; ~2x33 MB per rank "
                          "at 1080p whatever N) or one all_gather ((N-1)x33 MB per rank) + device-side minimum")
     ap.add_argument("--box-bench", action="store_true", help="also time the plain box-filter pass")
+    ap.add_argument("--no-overlap", action="store_true",
+                    help="N>1: exchange both sides after both filters instead of overlapping the left exchange "
+                         "with the right filter")
     ap.add_argument("--shard-sim", type=int, default=0,
                     help="diagnostic: time only rank 0's disparity shard of a G-rank job on this GPU (no exchange); "
                          "the JSON line is then NOT the headline metric")
@@ -114,10 +117,25 @@ def main():
 
     def step():
         de.CostConst_GPU()
+        if use_dist and args.exchange == "allreduce" and not args.no_overlap:
+            # left volume: filter, local minima, start its exchange (RCCL runs on the process group's own
+            # stream, ordered after everything issued so far); the right volume is filtered meanwhile
+            HWk = H * W
+            de.CostFilter_side(0)
+            de.DispSelect_partial_side(0, keys_local.data_ptr())
+            work = dist.all_reduce(keys_local[:HWk], op=dist.ReduceOp.MIN, async_op=True)
+            de.CostFilter_side(1)
+            de.DispSelect_partial_side(1, keys_local.data_ptr() + 8 * HWk)
+            dist.all_reduce(keys_local[HWk:], op=dist.ReduceOp.MIN)
+            work.wait()
+            de.DispSelect_merge(keys_local.data_ptr(), 1, download=False)
+            return
         de.CostFilter_GPU()
         if use_dist:
             de.DispSelect_partial(keys_local.data_ptr())
-            if args.exchange == "allreduce":
+            if args.exchange == "none":       # diagnostic only: cost of the torch collective call itself
+                de.DispSelect_merge(keys_local.data_ptr(), 1, download=False)
+            elif args.exchange == "allreduce":
                 dist.all_reduce(keys_local, op=dist.ReduceOp.MIN)     # the one exchange step (RCCL)
                 de.DispSelect_merge(keys_local.data_ptr(), 1, download=False)
             else:

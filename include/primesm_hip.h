@@ -109,6 +109,11 @@ int psm_cost_construct(psm_ctx *ctx);
  * GuidedFilter_cv (src/CVF.cpp:44-165).  Filters both volumes in place. */
 int psm_cost_filter(psm_ctx *ctx);
 
+/* One half of psm_cost_filter: preprocess + filter of volume `side` only (the reference runs the two
+ * halves back to back, src/DispEst.cpp:302-305).  Lets a sharded host start exchanging the left
+ * minima while the right volume is still being filtered. */
+int psm_cost_filter_side(psm_ctx *ctx, int side);
+
 /* DispEst::DispSelect_GPU (src/DispEst.cpp:323-328) == DispSel_cl::CVSelect
  * (src/DispSel_cl.cpp:69-140) with DispSel::CVSelect arithmetic (src/DispSel.cpp:83-109).
  * lmap/rmap: H rows of W bytes, row pitch `stride` (cv::Mat lDisMap/rDisMap, CV_8UC1).
@@ -123,6 +128,8 @@ int psm_disp_select(psm_ctx *ctx, uint8_t *lmap, uint8_t *rmap, size_t stride);
  * dev_keys: DEVICE pointer to 2*H*W int64 (e.g. a torch tensor handed to RCCL), or NULL to
  * use the context's own buffer (psm_partial_keys). */
 int psm_disp_select_partial(psm_ctx *ctx, void *dev_keys);
+/* The same for one side only: dev_keys_side = DEVICE pointer to H*W int64 (NULL: the context's buffer). */
+int psm_disp_select_partial_side(psm_ctx *ctx, int side, void *dev_keys_side);
 /* Device pointer / size of the context's own key buffer. */
 int psm_partial_keys(psm_ctx *ctx, void **dev_keys, size_t *bytes);
 /* Sharded DispSel, step 2: dev_keys_all = DEVICE pointer to nranks consecutive key buffers

@@ -36,7 +36,9 @@ SYMBOLS = [
     ("psm_upload_pair", _i, [_vp, _vp, _vp, _i, _sz, _i]),
     ("psm_cost_construct", _i, [_vp]),
     ("psm_cost_filter", _i, [_vp]),
+    ("psm_cost_filter_side", _i, [_vp, _i]),
     ("psm_disp_select", _i, [_vp, _vp, _vp, _sz]),
+    ("psm_disp_select_partial_side", _i, [_vp, _i, _vp]),
     ("psm_disp_select_partial", _i, [_vp, _vp]),
     ("psm_partial_keys", _i, [_vp, C.POINTER(_vp), C.POINTER(_sz)]),
     ("psm_disp_merge", _i, [_vp, _vp, _i, _vp, _vp, _sz]),

@@ -482,6 +482,21 @@ int psm_cost_filter(psm_ctx *c)
     return end_stage(c, PSM_STAGE_CVF, t0);
 }
 
+int psm_cost_filter_side(psm_ctx *c, int side)
+{
+    if (!c) return 1;
+    if (side != PSM_LEFT && side != PSM_RIGHT) return fail(c, "psm_cost_filter_side: bad side %d", side);
+    if (!c->have_cost) return fail(c, "psm_cost_filter_side: no cost volume");
+    if (!c->have_images) return fail(c, "psm_cost_filter_side: no image pair uploaded (guidance)");
+    if (bind(c)) return 1;
+    const double t0 = now_us();
+    if (filter_side(c, side, true)) return 1;
+    c->have_maps = false;
+    if (!c->opt_async) PSM_HIP(c, hipStreamSynchronize(c->stream));
+    c->stage_us[PSM_STAGE_CVF] = (side == PSM_LEFT ? 0.0 : c->stage_us[PSM_STAGE_CVF]) + (now_us() - t0);
+    return 0;
+}
+
 int psm_filter_stage_a(psm_ctx *c, int side)
 {
     if (!c) return 1;
@@ -543,6 +558,29 @@ int psm_disp_select_partial(psm_ctx *c, void *dev_keys)
     if (materialize(c, 0) || materialize(c, 1)) return 1;
     if (wta_launch(c, dev_keys ? (long long *)dev_keys : c->keys, nullptr)) return 1;
     return end_stage(c, PSM_STAGE_DISPSEL, t0);
+}
+
+int psm_disp_select_partial_side(psm_ctx *c, int side, void *dev_keys_side)
+{
+    if (!c) return 1;
+    if (side != PSM_LEFT && side != PSM_RIGHT) return fail(c, "psm_disp_select_partial_side: bad side %d", side);
+    if (!c->have_cost) return fail(c, "psm_disp_select_partial_side: no cost volume");
+    if (bind(c)) return 1;
+    const double t0 = now_us();
+    if (materialize(c, side)) return 1;
+    const size_t HW = (size_t)c->W * c->H;
+    long long *keys = dev_keys_side ? (long long *)dev_keys_side : c->keys + side * HW;
+    {
+        Prof p(c, PSM_K_WTA);
+        if (c->dtype == PSM_U8)
+            launch_wta_u8(c->stream, (const uint8_t *)c->vol[side], c->W, c->H, c->d0, c->Dloc, keys, nullptr);
+        else
+            launch_wta(c->stream, (const float *)c->vol[side], c->W, c->H, c->d0, c->Dloc, keys, nullptr);
+    }
+    if (check_launch(c, "wta")) return 1;
+    if (!c->opt_async) PSM_HIP(c, hipStreamSynchronize(c->stream));
+    c->stage_us[PSM_STAGE_DISPSEL] = (side == PSM_LEFT ? 0.0 : c->stage_us[PSM_STAGE_DISPSEL]) + (now_us() - t0);
+    return 0;
 }
 
 int psm_partial_keys(psm_ctx *c, void **dev_keys, size_t *bytes)

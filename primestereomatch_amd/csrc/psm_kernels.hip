@@ -251,7 +251,6 @@ __global__ __launch_bounds__(256) void k_guide_v(const double *hs9, int W, int H
 // with nine sliding trees (I0,I1,I2 and the six products) - the same machinery as the volume kernels.
 // Replaces 149 MB of fp64 scratch traffic per side; matters because this work does not shrink when the
 // disparity range is sharded over GPUs.
-constexpr int GUIDE_SEG = 64;
 struct GuideM { float m[9]; };
 __device__ __forceinline__ void guide_finish(const float *m, float4 &g2, float4 &g3, float2 &g4)
 {   // identical arithmetic to k_guide_v (src/CVF.cpp:58-68,120-147)
@@ -281,7 +280,7 @@ __device__ __forceinline__ void guide_finish(const float *m, float4 &g2, float4 
     g4 = make_float2(A12, A22);
 }
 
-__global__ __launch_bounds__(64) void k_guide_march(const float4 *__restrict__ g1, int W, int H, int nstrips,
+__global__ __launch_bounds__(64) void k_guide_march(const float4 *__restrict__ g1, int W, int H, int nstrips, int seg_rows,
                                                    float4 *__restrict__ g2, float4 *__restrict__ g3, float2 *__restrict__ g4)
 {
     const int strip = blockIdx.x % nstrips, seg = blockIdx.x / nstrips;
@@ -289,7 +288,7 @@ __global__ __launch_bounds__(64) void k_guide_march(const float4 *__restrict__ g
     const int x0 = strip * 56;
     const int cs = r101c(x0 - 4 + lane, W), xo = x0 + lane;
     const bool ovalid = lane < 56 && xo < W;
-    const int y0 = seg * GUIDE_SEG, y1 = min(H, y0 + GUIDE_SEG);
+    const int y0 = seg * seg_rows, y1 = min(H, y0 + seg_rows);
     const int n = (y1 - y0) + 7, ybase = y0 - 4;
     const int i1 = ((lane + 1) & 63) << 2, i2 = ((lane + 2) & 63) << 2, i4 = ((lane + 4) & 63) << 2;
     (void)i1;
@@ -320,8 +319,12 @@ __global__ __launch_bounds__(64) void k_guide_march(const float4 *__restrict__ g
 void launch_guidance(hipStream_t s, Guidance g, double *hs9, int W, int H, int two_pass)
 {
     if (!two_pass) {
-        const int nstrips = (W + 55) / 56, nsegs = (H + GUIDE_SEG - 1) / GUIDE_SEG;
-        hipLaunchKernelGGL(k_guide_march, dim3(nstrips * nsegs), dim3(64), 0, s, (const float4 *)g.g1, W, H, nstrips, g.g2, g.g3, g.g4);
+        // one wave per (strip, segment): aim for ~2000 waves (two per SIMD at 178 VGPRs), 16..64 rows each
+        const int nstrips = (W + 55) / 56;
+        int seg_rows = (int)(((long)H * nstrips + 2047) / 2048);
+        seg_rows = seg_rows < 16 ? 16 : (seg_rows > 64 ? 64 : seg_rows);
+        const int nsegs = (H + seg_rows - 1) / seg_rows;
+        hipLaunchKernelGGL(k_guide_march, dim3(nstrips * nsegs), dim3(64), 0, s, (const float4 *)g.g1, W, H, nstrips, seg_rows, g.g2, g.g3, g.g4);
         return;
     }
     dim3 grid((W + 255) / 256, H);

@@ -149,6 +149,13 @@ class DispEst:
         self._ck(self._lib.psm_disp_select_partial(self._h, C.c_void_p(dev_keys_ptr or 0)),
                  "DispSelect_partial")
 
+    def CostFilter_side(self, side: int):
+        self._ck(self._lib.psm_cost_filter_side(self._h, int(side)), "CostFilter_side")
+
+    def DispSelect_partial_side(self, side: int, dev_keys_ptr: int | None = None):
+        self._ck(self._lib.psm_disp_select_partial_side(self._h, int(side), C.c_void_p(dev_keys_ptr or 0)),
+                 "DispSelect_partial_side")
+
     def partial_keys(self):
         p, n = C.c_void_p(), C.c_size_t()
         self._ck(self._lib.psm_partial_keys(self._h, C.byref(p), C.byref(n)), "partial_keys")

@@ -21,6 +21,8 @@ timeout 600 python bench.py --config c5 --steps 4 --warmup 1 --no-cpu-baseline >
 timeout 300 python bench.py --flags 16 --no-cpu-baseline > $OUT/bench_c4_twostage.json 2>> $OUT/bench_var.err
 echo "== torch.distributed path on 1 GPU (RCCL all-gather, world_size 1)"
 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 1 --force-dist --steps 5 --warmup 2 --no-cpu-baseline > $OUT/bench_dist1.json 2> $OUT/bench_dist1.err
+timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29534 bench.py --gpus 1 --force-dist --exchange allgather --steps 5 --warmup 2 --no-cpu-baseline > $OUT/bench_dist1_allgather.json 2>> $OUT/bench_dist1.err
+timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29535 bench.py --gpus 1 --force-dist --no-overlap --steps 5 --warmup 2 --no-cpu-baseline > $OUT/bench_dist1_nooverlap.json 2>> $OUT/bench_dist1.err
 python - <<PY
 import json,glob
 for f in sorted(glob.glob("$OUT/bench_*.json")):

@@ -510,3 +510,23 @@ def test_lazy_cost_volume_equals_materialised(psm, oracle, W, H, D):
         assert np.array_equal(de.download_volume(1), raw["raw_r"])
         de.DispSelect_GPU()                      # WTA on the unfiltered volumes
         assert np.array_equal(de.lDisMap, oracle.wta(raw["raw_l"]))
+
+
+def test_per_side_calls_equal_whole_stage_calls(psm, oracle):
+    """psm_cost_filter_side / psm_disp_select_partial_side (used to overlap the exchange of the left
+    minima with the right filter) produce the same maps as the whole-stage calls."""
+    from primestereomatch_amd import synth
+    H, W, D = 70, 120, 14
+    l, r, _ = synth.make_pair(W, H, D, 6)
+    ref = oracle.pipeline_f32(l, r, D, threads=4)
+    shards = [psm.DispEst(l, r, D, d_range=(0, 6)), psm.DispEst(l, r, D, d_range=(6, 14))]
+    try:
+        for s in shards:
+            s.CostConst_GPU()
+            s.CostFilter_side(0); s.DispSelect_partial_side(0)
+            s.CostFilter_side(1); s.DispSelect_partial_side(1)
+        shards[0].DispSelect_merge_ctx(shards)
+        assert np.array_equal(shards[0].lDisMap, ref["ldisp"]) and np.array_equal(shards[0].rDisMap, ref["rdisp"])
+    finally:
+        for s in shards:
+            s.close()
