@@ -908,10 +908,18 @@ __global__ __launch_bounds__(64 * (PC_NA + PC_NB)) PSM_PC_ATTR void k_cvf_pc(con
     // the top and bottom of the image, which are earlier/later rows of the same ring - is still present.
     __shared__ __attribute__((aligned(16))) float4 ring[PC_RING][4][PC_MCOLS];
     __shared__ __attribute__((aligned(16))) float qbuf[2][4][PC_COLS];     // output rows, two batches
+    // Workgroup -> (column group, segment, slice).  Blocks are observed to go round-robin over the 8 XCDs
+    // (block b -> XCD b%8): every XCD owns a contiguous range of (group, segment) pairs and walks the
+    // slices of one pair back to back, so the guidance rows its resident workgroups are reading (few
+    // pairs, neighbouring rows, many slices) fit its 4 MB L2 instead of coming from the MALL.  Speed only.
     int id = blockIdx.x;
-    const int g = id % ngroups, rest = id / ngroups;
-    const int d = rest % Dloc, seg = rest / Dloc;
-    if (seg >= nsegs) return;
+    const int npairs = ngroups * nsegs;               // (column group, segment) pairs
+    const int ppx = (npairs + 7) >> 3;                // pairs per XCD (the launcher makes npairs % 8 == 0 if it can)
+    const int xcd = id & 7, jj = id >> 3;
+    const int d = jj % Dloc, pl = jj / Dloc;          // slices fastest within an XCD
+    const int pair = xcd * ppx + pl;
+    if (pl >= ppx || pair >= npairs) return;
+    const int g = pair % ngroups, seg = pair / ngroups;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const bool is_a = wave < PC_NA;
     const int xg = g * PC_COLS;                       // first output column of the workgroup
@@ -930,6 +938,9 @@ __global__ __launch_bounds__(64 * (PC_NA + PC_NB)) PSM_PC_ATTR void k_cvf_pc(con
     if (is_a) {
         // ---------------- producer: stage A ----------------
         // step s reads input row mstart-5+s; from step 8 on it yields model row mstart+(s-8)
+#ifdef PSM_PC_PRIO
+        __builtin_amdgcn_s_setprio(PSM_PC_PRIO);      // the producers are the barrier-critical role
+#endif
         const int xa0 = xm0 + wave * PC_OUT_A;        // first model column of this wave
         const int ci = r101c(xa0 - 4 + lane, W);      // input column of this lane
         const int xa = xa0 + lane;                    // model column of this lane
@@ -996,6 +1007,9 @@ __global__ __launch_bounds__(64 * (PC_NA + PC_NB)) PSM_PC_ATTR void k_cvf_pc(con
     } else {
         // ---------------- consumer: stage B ----------------
         // feed j (j = 0 .. nf-1) is model row r101(y0-4+j); from feed 7 on the tree yields output row y0+j-7
+#ifdef PSM_PC_PRIO_B
+        __builtin_amdgcn_s_setprio(PSM_PC_PRIO_B);
+#endif
         const int wb = wave - PC_NA;
         const int bwidth = wb < PC_NB - 1 ? PC_OUT_B : PC_COLS - (PC_NB - 1) * PC_OUT_B;
         const int xb0 = xg + wb * PC_OUT_B;           // first output column of this wave
@@ -1295,13 +1309,18 @@ void launch_cvf_fused(hipStream_t s, March m, const float *vin, float *vout, Gui
         const int kmin = (4096 + per_seg - 1) / per_seg, kmax = rows / 64 > 1 ? rows / 64 : 1;
         if (k < kmin) k = kmin;
         if (k > kmax) k = kmax;
+        if (!(m.flags & 32)) {   // balanced XCD ownership: (groups x segments) a multiple of 8 if a nearby k allows it
+            const int ng = (W + PC_COLS - 1) / PC_COLS;
+            for (int kk = k; kk <= k + 3 && kk <= kmax; ++kk)
+                if ((ng * kk) % 8 == 0) { k = kk; break; }
+        }
         seg_rows = (rows + k - 1) / k;
     }
     if (seg_rows > rows) seg_rows = rows;
     const int nsegs = (rows + seg_rows - 1) / seg_rows;
     if (!(m.flags & 32)) {
         const int ngroups = (W + PC_COLS - 1) / PC_COLS;
-        const int nblocks = ngroups * Dloc * nsegs;
+        const int nblocks = 8 * ((ngroups * nsegs + 7) / 8) * Dloc;
         const dim3 blk(64 * (PC_NA + PC_NB));
 #define PSM_LAUNCH_PC(V4, CV)                                                                                              \
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_cvf_pc<V4, CV>), dim3(nblocks), blk, 0, s, vin, vout, (const float4 *)gd.g1,      \
