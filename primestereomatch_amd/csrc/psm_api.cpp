@@ -189,6 +189,25 @@ int run_prep(psm_ctx *c)
     return 0;
 }
 
+// The 16 B/voxel (a0,a1,a2,b) scratch is only needed by the two-stage filter, the single-wave fused
+// kernel's border bands, psm_filter_stage_a and psm_box8_volume: allocate it on first use.
+int ensure_ab(psm_ctx *c)
+{
+    if (c->ab) return 0;
+    const size_t V = (size_t)c->W * c->H * c->Dloc;
+    PSM_HIP(c, hipMalloc((void **)&c->ab, V * sizeof(float4)));
+    return 0;
+}
+
+// second float volume for the fused filter when it has to READ a materialised cost volume (out of place)
+int ensure_spare(psm_ctx *c)
+{
+    if (c->spare) return 0;
+    const size_t V = (size_t)c->W * c->H * c->Dloc;
+    PSM_HIP(c, hipMalloc((void **)&c->spare, V * sizeof(float)));
+    return 0;
+}
+
 // build the (float) cost slices of `side` for rows [ybeg, yend)
 void launch_cvc_rows(psm_ctx *c, int side, int ybeg, int yend)
 {
@@ -271,9 +290,7 @@ int psm_create_shard(psm_ctx **out, int width, int height, int max_disp, int d_b
         if (e == hipSuccess && dtype == PSM_U8) e = hipMalloc((void **)&c->p4[s], HW * 4);
     }
     if (e == hipSuccess) e = hipMalloc((void **)&c->hs9, 9 * HW * sizeof(double));
-    if (e == hipSuccess) e = hipMalloc((void **)&c->ab, V * sizeof(float4));
     if (e == hipSuccess && dtype == PSM_U8) e = hipMalloc((void **)&c->fvol, V * sizeof(float));
-    if (e == hipSuccess && dtype == PSM_F32) e = hipMalloc((void **)&c->spare, V * sizeof(float));
     if (e == hipSuccess) e = hipMalloc((void **)&c->keys, 2 * HW * sizeof(long long));
     if (e == hipSuccess) e = hipMalloc((void **)&c->maps, 2 * HW);
     if (e == hipSuccess) e = hipMalloc((void **)&c->valid, 2 * HW);
@@ -420,16 +437,26 @@ static int filter_side(psm_ctx *c, int side, bool stage_b)
     const bool fused = stage_b && c->dtype == PSM_F32 && c->opt_variant == 0 && !(c->march.flags & 16) && H >= 8;
     if (!fused && materialize(c, side)) return 1;
     if (fused) {
+        if (!(c->march.flags & 32) && c->raw_rows[side] != psm_ctx::RAW_ALL) {
+            // producer/consumer kernel on a virtual cost volume: nothing is read from vol[side], so the
+            // filtered volume is written straight into it
+            {
+                Prof p(c, PSM_K_CVF_F);
+                launch_cvf_fused(c->stream, c->march, nullptr, fv, c->g[side], W, H, c->Dloc, 0, H, c->g[1 - side].g1, c->d0, 1 + side);
+            }
+            c->raw_rows[side] = psm_ctx::RAW_ALL;   // vol[side] now holds real (filtered) data
+            return check_launch(c, "cvf (fused, lazy costs)");
+        }
+        if (ensure_spare(c)) return 1;
         float *out = c->spare;
         if (!(c->march.flags & 32)) {
-            // producer/consumer kernel: all rows in one launch; the cost slices may still be virtual
-            const int cvc_mode = c->raw_rows[side] == psm_ctx::RAW_ALL ? 0 : 1 + side;
+            // producer/consumer kernel reading a materialised cost volume: out of place, all rows in one launch
             Prof p(c, PSM_K_CVF_F);
-            launch_cvf_fused(c->stream, c->march, fv, out, c->g[side], W, H, c->Dloc, 0, H, c->g[1 - side].g1, c->d0, cvc_mode);
+            launch_cvf_fused(c->stream, c->march, fv, out, c->g[side], W, H, c->Dloc, 0, H, c->g[1 - side].g1, c->d0, 0);
         } else {
             // single-wave fused kernel: rows 4 .. H-4 only; the border rows, whose second box filter reflects
             // model rows, go through the two-stage kernels on thin bands (7 model rows, 4+3 outputs)
-            if (materialize(c, side)) return 1;
+            if (materialize(c, side) || ensure_ab(c)) return 1;
             {
                 Prof p(c, PSM_K_CVF_A);
                 if (H >= 14) {
@@ -454,6 +481,7 @@ static int filter_side(psm_ctx *c, int side, bool stage_b)
         c->raw_rows[side] = psm_ctx::RAW_ALL;   // vol[side] now holds real (filtered) data
         return check_launch(c, "cvf (fused)");
     }
+    if (ensure_ab(c)) return 1;
     {
         Prof p(c, PSM_K_CVF_A);
         launch_cvf_a(c->stream, c->opt_variant, c->march, fv, c->ab, c->g[side], W, H, c->Dloc, 0, H);
@@ -728,6 +756,7 @@ int psm_download_ab(psm_ctx *c, int d0, int d1, float *host)
     if (!c || !host) return 1;
     if (check_slices(c, "psm_download_ab", 0, d0, d1)) return 1;
     if (bind(c)) return 1;
+    if (!c->ab) return fail(c, "psm_download_ab: no stage-A result (call psm_filter_stage_a first)");
     const size_t S = (size_t)c->W * c->H * sizeof(float4);
     PSM_HIP(c, hipMemcpyAsync(host, (const char *)c->ab + (size_t)(d0 - c->d0) * S, (size_t)(d1 - d0) * S, hipMemcpyDeviceToHost, c->stream));
     PSM_HIP(c, hipStreamSynchronize(c->stream));
@@ -763,7 +792,7 @@ int psm_box8_volume(psm_ctx *c, int side, float *host)
     if (c->dtype != PSM_F32) return fail(c, "psm_box8_volume: float mode only");
     if (!c->have_cost) return fail(c, "psm_box8_volume: no cost volume");
     if (bind(c)) return 1;
-    if (materialize(c, side)) return 1;
+    if (materialize(c, side) || ensure_ab(c)) return 1;
     {
         Prof p(c, PSM_K_BOX);
         launch_box8(c->stream, c->opt_variant, c->march, (const float *)c->vol[side], (float *)c->ab, c->W, c->H, c->Dloc);
