@@ -55,6 +55,9 @@ def main():
                     help="N>1 exchange step: one all_reduce(MIN) of the packed keys (default; ~2x33 MB per rank "
                          "at 1080p whatever N) or one all_gather ((N-1)x33 MB per rank) + device-side minimum")
     ap.add_argument("--box-bench", action="store_true", help="also time the plain box-filter pass")
+    ap.add_argument("--fgf", type=int, default=0, choices=[0, 2, 4, 8],
+                    help="diagnostic: aggregate with the Fast Guided Filter variant (CostFilter_FGF) at this subsample "
+                         "rate instead of the full guided filter; not the north-star metric")
     ap.add_argument("--no-overlap", action="store_true",
                     help="N>1: exchange both sides after both filters instead of overlapping the left exchange "
                          "with the right filter")
@@ -115,8 +118,15 @@ def main():
         torch.cuda.set_stream(side_stream)
         de.set_stream(side_stream.cuda_stream)
 
+    if args.fgf:
+        de.setSubsampleRate(args.fgf)
+
     def step():
         de.CostConst_GPU()
+        if args.fgf:
+            de.CostFilter_FGF_GPU()
+            de.DispSelect_device()
+            return
         if use_dist and args.exchange == "allreduce" and not args.no_overlap:
             # left volume: filter, local minima, start its exchange (RCCL runs on the process group's own
             # stream, ordered after everything issued so far); the right volume is filtered meanwhile
@@ -180,7 +190,7 @@ def main():
     sync()
     names = {capi.PSM_K_PREP: "prep", capi.PSM_K_CVC: "cvc", capi.PSM_K_GUIDE: "guidance", capi.PSM_K_CVF_F: "cvf_fused",
              capi.PSM_K_CVF_A: "cvf_a", capi.PSM_K_CVF_B: "cvf_b", capi.PSM_K_WTA: "wta",
-             capi.PSM_K_MERGE: "merge"}
+             capi.PSM_K_MERGE: "merge", capi.PSM_K_FGF: "cvf_fgf"}
     kern = {}
     for k, nm in names.items():
         tot, n = de.kernel_time_ms(k)
@@ -188,7 +198,9 @@ def main():
             kern[nm] = {"avg_ms": tot / n, "launches_per_step": n / prof_steps}
     de.set_option(capi.PSM_OPT_PROFILE, 0)
     vox_per_launch = float(W) * H * (d1 - d0)   # one launch = all local slices of one side
-    dom = max(("cvf_fused", "cvf_a", "cvf_b"), key=lambda k: kern.get(k, {"avg_ms": 0})["avg_ms"])
+    if args.fgf:   # per launch pair (setup + model + smooth + apply of one side): cost read at 1/s^2, model planes, q write
+        ALG_BYTES["cvf_fgf"] = 4.0 + 68.0 / (args.fgf * args.fgf)
+    dom = max(("cvf_fgf",) if args.fgf else ("cvf_fused", "cvf_a", "cvf_b"), key=lambda k: kern.get(k, {"avg_ms": 0})["avg_ms"])
     dom_ms = kern[dom]["avg_ms"]
     achieved = ALG_BYTES[dom] * vox_per_launch / (dom_ms * 1e-3) / 1e9
     roofline = {"bound": "hbm", "kernel": "k_" + dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
@@ -244,7 +256,8 @@ def main():
 
     if rank == 0:
         out = {
-            "metric": "cost-volume voxels/s (CVC+CVF+WTA)", "value": value, "unit": "voxels/s",
+            "metric": "cost-volume voxels/s (CVC+CVF+WTA)" if not args.fgf else f"cost-volume voxels/s (CVC+CVF_FGF s={args.fgf}+WTA)",
+            "value": value, "unit": "voxels/s",
             "n_gpus": N, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",

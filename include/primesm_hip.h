@@ -43,7 +43,7 @@ enum { PSM_STAGE_CVC = 0, PSM_STAGE_CVF = 1, PSM_STAGE_DISPSEL = 2, PSM_STAGE_PP
        PSM_STAGE_COUNT = 4 };
 /* kernels whose device time can be queried with psm_kernel_time_ms() */
 enum { PSM_K_PREP = 0, PSM_K_CVC = 1, PSM_K_GUIDE = 2, PSM_K_CVF_A = 3, PSM_K_CVF_B = 4,
-       PSM_K_WTA = 5, PSM_K_MERGE = 6, PSM_K_BOX = 7, PSM_K_LRC = 8, PSM_K_CVF_F = 9, PSM_K_COUNT = 10 };
+       PSM_K_WTA = 5, PSM_K_MERGE = 6, PSM_K_BOX = 7, PSM_K_LRC = 8, PSM_K_CVF_F = 9, PSM_K_FGF = 10, PSM_K_COUNT = 11 };
 /* options for psm_set_option */
 enum {
     PSM_OPT_ASYNC = 0,          /* 1: stage calls only enqueue; use psm_synchronize()        */
@@ -113,6 +113,13 @@ int psm_cost_filter(psm_ctx *ctx);
  * halves back to back, src/DispEst.cpp:302-305).  Lets a sharded host start exchanging the left
  * minima while the right volume is still being filtered. */
 int psm_cost_filter_side(psm_ctx *ctx, int side);
+
+/* DispEst::CostFilter_FGF (src/DispEst.cpp:281-296): the Fast Guided Filter variant of the aggregation,
+ * FastGuidedFilterColor(I, GIF_R_WIN, GIF_EPS, subsample_rate) per slice (src/fastguidedfilter.cpp:124-209),
+ * left then right volume, in place.  subsample_rate in {2, 4, 8} (the reference's default is 4,
+ * src/DispEst.cpp:19); PSM_F32 contexts only; width/subsample_rate and height/subsample_rate must exceed
+ * the blur radius 8/subsample_rate.  The reference has this on the CPU only ('m' mode has no FGF kernel). */
+int psm_cost_filter_fgf(psm_ctx *ctx, int subsample_rate);
 
 /* DispEst::DispSelect_GPU (src/DispEst.cpp:323-328) == DispSel_cl::CVSelect
  * (src/DispSel_cl.cpp:69-140) with DispSel::CVSelect arithmetic (src/DispSel.cpp:83-109).

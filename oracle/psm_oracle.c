@@ -265,6 +265,167 @@ void psmo_guided_filter(const float *rgb, const float *mean, const float *var, i
 }
 
 /* ------------------------------------------------------------------------------- */
+/* CVF, Fast Guided Filter variant (src/fastguidedfilter.cpp)                       */
+/* ------------------------------------------------------------------------------- */
+
+/* cv::blur(src, dst, Size(k,k)): normalised box, anchor centre, BORDER_REFLECT_101 */
+static void blur_k(const float *src, int H, int W, int k, float *dst, double *hs)
+{
+    const int r = k / 2;
+    const double scale = 1.0 / (k * k);
+    for (int y = 0; y < H; ++y)
+        for (int x = 0; x < W; ++x) {
+            double a = 0.0;
+            for (int i = -r; i <= r; ++i) a += (double)src[(size_t)y * W + r101(x + i, W)];
+            hs[(size_t)y * W + x] = a;
+        }
+    for (int y = 0; y < H; ++y)
+        for (int x = 0; x < W; ++x) {
+            double a = 0.0;
+            for (int j = -r; j <= r; ++j) a += hs[(size_t)r101(y + j, H) * W + x];
+            dst[(size_t)y * W + x] = (float)(a * scale);
+        }
+}
+
+/* cv::resize(src, dst, Size(W/s, H/s), 0, 0, INTER_NN) index maps */
+static void nn_maps(int H, int W, int s, int *yofs, int *xofs)
+{
+    const int hs = H / s, ws = W / s;
+    const double ifx = 1. / ((double)ws / W), ify = 1. / ((double)hs / H);
+    for (int x = 0; x < ws; ++x) { int sx = (int)floor(x * ifx); xofs[x] = sx < W - 1 ? sx : W - 1; }
+    for (int y = 0; y < hs; ++y) { int sy = (int)floor(y * ify); yofs[y] = sy < H - 1 ? sy : H - 1; }
+}
+
+/* cv::resize(..., INTER_LINEAR) coefficient tables for one axis (CV_32F, 1 channel) */
+static void lin_maps(int ssize, int dsize, int *ofs, float *w1)
+{
+    const double scale = (double)ssize / dsize;
+    for (int d = 0; d < dsize; ++d) {
+        float f = (float)((d + 0.5) * scale - 0.5);
+        int sx = (int)floorf(f);
+        f -= sx;
+        if (sx < 0) { f = 0.f; sx = 0; }
+        if (sx >= ssize - 1) { f = 0.f; sx = ssize - 1; }
+        ofs[d] = sx;
+        w1[d] = f;
+    }
+}
+
+void psmo_fgf_setup(const float *img, int H, int W, int s, float *setup)
+{
+    const int hs = H / s, ws = W / s, k = 2 * (8 / s) + 1; /* FastGuidedFilter(I, GIF_R_WIN, ...): 2*(r/s)+1 */
+    const size_t n = (size_t)hs * ws;
+    int *yofs = (int *)malloc(hs * sizeof(int)), *xofs = (int *)malloc(ws * sizeof(int));
+    float *tmp = (float *)malloc(n * sizeof(float)), *var = (float *)malloc(6 * n * sizeof(float));
+    double *hsum = (double *)malloc(n * sizeof(double));
+    float *I = setup, *mean = setup + 3 * n, *inv = setup + 6 * n;
+    const float eps = PSMO_GIF_EPS; /* double eps added to a CV_32F Mat: the work type is float */
+    nn_maps(H, W, s, yofs, xofs);
+    for (int c = 0; c < 3; ++c)
+        for (int y = 0; y < hs; ++y)
+            for (int x = 0; x < ws; ++x) I[c * n + (size_t)y * ws + x] = img[((size_t)yofs[y] * W + xofs[x]) * 3 + c];
+    for (int c = 0; c < 3; ++c) blur_k(I + c * n, hs, ws, k, mean + c * n, hsum);
+    /* var_I_cc' = boxfilter(Ic.mul(Ic')) - mean_c.mul(mean_c') (+ eps on the diagonal), src/fastguidedfilter.cpp:150-155 */
+    int vi = 0;
+    for (int c = 0; c < 3; ++c)
+        for (int cp = c; cp < 3; ++cp) {
+            for (size_t i = 0; i < n; ++i) tmp[i] = I[c * n + i] * I[cp * n + i];
+            blur_k(tmp, hs, ws, k, var + vi * n, hsum);
+            for (size_t i = 0; i < n; ++i) {
+                float m = mean[c * n + i] * mean[cp * n + i];
+                float v = var[vi * n + i] - m;
+                if (c == cp) v = v + eps;
+                var[vi * n + i] = v;
+            }
+            ++vi;
+        }
+    /* var order: rr rg rb gg gb bb = 0..5;  src/fastguidedfilter.cpp:158-172 */
+    for (size_t i = 0; i < n; ++i) {
+        float rr = var[0 * n + i], rg = var[1 * n + i], rb = var[2 * n + i], gg = var[3 * n + i], gb = var[4 * n + i],
+              bb = var[5 * n + i];
+        float irr = gg * bb - gb * gb;
+        float irg = gb * rb - rg * bb;
+        float irb = rg * gb - gg * rb;
+        float igg = rr * bb - rb * rb;
+        float igb = rb * rg - rr * gb;
+        float ibb = rr * gg - rg * rg;
+        float covDet = (irr * rr + irg * rg) + irb * rb;
+        inv[0 * n + i] = irr / covDet;
+        inv[1 * n + i] = irg / covDet;
+        inv[2 * n + i] = irb / covDet;
+        inv[3 * n + i] = igg / covDet;
+        inv[4 * n + i] = igb / covDet;
+        inv[5 * n + i] = ibb / covDet;
+    }
+    free(yofs); free(xofs); free(tmp); free(var); free(hsum);
+}
+
+static void fgf_filter_ws(const float *img, const float *setup, int H, int W, int s, float *p, float *ws_f, double *hsum,
+                          int *imaps, float *fmaps)
+{
+    const int hs = H / s, wsm = W / s, k = 2 * (8 / s) + 1;
+    const size_t n = (size_t)hs * wsm;
+    const float *I = setup, *mean = setup + 3 * n, *inv = setup + 6 * n;
+    float *ps = ws_f, *tmp = ws_f + n, *mp = ws_f + 2 * n, *mIp = ws_f + 3 * n /* 3n */, *a = ws_f + 6 * n /* 3n */,
+          *b = ws_f + 9 * n, *ma = ws_f + 10 * n /* 3n */, *mb = ws_f + 13 * n;
+    int *yofs = imaps, *xofs = imaps + hs, *lxo = imaps + hs + wsm, *lyo = lxo + W;
+    float *lxw = fmaps, *lyw = fmaps + W;
+    nn_maps(H, W, s, yofs, xofs);
+    lin_maps(wsm, W, lxo, lxw);
+    lin_maps(hs, H, lyo, lyw);
+    for (int y = 0; y < hs; ++y)
+        for (int x = 0; x < wsm; ++x) ps[(size_t)y * wsm + x] = p[(size_t)yofs[y] * W + xofs[x]];
+    blur_k(ps, hs, wsm, k, mp, hsum);
+    for (int c = 0; c < 3; ++c) {
+        for (size_t i = 0; i < n; ++i) tmp[i] = I[c * n + i] * ps[i];
+        blur_k(tmp, hs, wsm, k, mIp + c * n, hsum);
+    }
+    for (size_t i = 0; i < n; ++i) {
+        /* src/fastguidedfilter.cpp:184-194 */
+        float cr = mIp[0 * n + i] - mean[0 * n + i] * mp[i];
+        float cg = mIp[1 * n + i] - mean[1 * n + i] * mp[i];
+        float cb = mIp[2 * n + i] - mean[2 * n + i] * mp[i];
+        float ar = (inv[0 * n + i] * cr + inv[1 * n + i] * cg) + inv[2 * n + i] * cb;
+        float ag = (inv[1 * n + i] * cr + inv[3 * n + i] * cg) + inv[4 * n + i] * cb;
+        float ab = (inv[2 * n + i] * cr + inv[4 * n + i] * cg) + inv[5 * n + i] * cb;
+        a[0 * n + i] = ar; a[1 * n + i] = ag; a[2 * n + i] = ab;
+        b[i] = ((mp[i] - ar * mean[0 * n + i]) - ag * mean[1 * n + i]) - ab * mean[2 * n + i];
+    }
+    for (int c = 0; c < 3; ++c) blur_k(a + c * n, hs, wsm, k, ma + c * n, hsum);
+    blur_k(b, hs, wsm, k, mb, hsum);
+    /* src/fastguidedfilter.cpp:196-204: bilinear upsampling of mean_a_*, mean_b, then the linear model */
+    for (int y = 0; y < H; ++y) {
+        const int sy = lyo[y], sy1 = sy + 1 < hs ? sy + 1 : hs - 1;
+        const float fy = lyw[y], b0 = 1.f - fy, b1 = fy;
+        for (int x = 0; x < W; ++x) {
+            const int sx = lxo[x], sx1 = sx + 1 < wsm ? sx + 1 : wsm - 1;
+            const float fx = lxw[x], a0 = 1.f - fx, a1 = fx;
+            float up[4];
+            for (int c = 0; c < 4; ++c) {
+                const float *src = c < 3 ? ma + c * n : mb;
+                float r0 = src[(size_t)sy * wsm + sx] * a0 + src[(size_t)sy * wsm + sx1] * a1;
+                float r1 = src[(size_t)sy1 * wsm + sx] * a0 + src[(size_t)sy1 * wsm + sx1] * a1;
+                up[c] = r0 * b0 + r1 * b1;
+            }
+            const float *px = img + ((size_t)y * W + x) * 3;
+            p[(size_t)y * W + x] = ((up[0] * px[0] + up[1] * px[1]) + up[2] * px[2]) + up[3];
+        }
+    }
+}
+
+void psmo_fgf_filter(const float *img, const float *setup, int H, int W, int s, float *p)
+{
+    const int hs = H / s, wsm = W / s;
+    const size_t n = (size_t)hs * wsm;
+    float *ws_f = (float *)malloc(14 * n * sizeof(float));
+    double *hsum = (double *)malloc(n * sizeof(double));
+    int *imaps = (int *)malloc((hs + wsm + W + H) * sizeof(int));
+    float *fmaps = (float *)malloc((W + H) * sizeof(float));
+    fgf_filter_ws(img, setup, H, W, s, p, ws_f, hsum, imaps, fmaps);
+    free(ws_f); free(hsum); free(imaps); free(fmaps);
+}
+
+/* ------------------------------------------------------------------------------- */
 /* DispSel                                                                          */
 /* ------------------------------------------------------------------------------- */
 
@@ -487,6 +648,75 @@ done:
     if (!lvol) free(lv);
     if (!rvol) free(rv);
     free(guide); free(ws); free(hs); free(jobs); free(btd); free(ftd);
+    return rc;
+}
+
+typedef struct {
+    const float *img, *setup;
+    int H, W, s;
+    float *costVol;
+} fgf_TD;
+
+static void *fgf_thread(void *arg)
+{
+    fgf_TD *t = (fgf_TD *)arg;
+    psmo_fgf_filter(t->img, t->setup, t->H, t->W, t->s, t->costVol);
+    return NULL;
+}
+
+/* CostConst() -> CostFilter_FGF() -> DispSelect_CPU(): the snapshot's live CPU branch (src/StereoMatch.cpp:207-224) */
+int psmo_pipeline_fgf(const uint8_t *l_bgr, const uint8_t *r_bgr, int H, int W, int D, int threads, int s,
+                      uint8_t *ldisp, uint8_t *rdisp, float *lvol, float *rvol, psmo_times *times)
+{
+    if (!l_bgr || !r_bgr || H < 8 || W < 8 || D < 1 || D > 256 || threads < 1 || (s != 2 && s != 4 && s != 8)) return -1;
+    if (H / s < 2 * (8 / s) + 1 || W / s < 2 * (8 / s) + 1) return -1;
+    const size_t N = (size_t)H * W, n = (size_t)(H / s) * (W / s);
+    int rc = -1;
+    float *lImg = (float *)malloc(N * 3 * sizeof(float)), *rImg = (float *)malloc(N * 3 * sizeof(float));
+    float *lG = (float *)malloc(N * sizeof(float)), *rG = (float *)malloc(N * sizeof(float));
+    float *lv = lvol ? lvol : (float *)malloc(N * D * sizeof(float));
+    float *rv = rvol ? rvol : (float *)malloc(N * D * sizeof(float));
+    float *setup = (float *)malloc(12 * n * sizeof(float));
+    job *jobs = (job *)malloc((size_t)D * sizeof(job));
+    buildCV_TD *btd = (buildCV_TD *)malloc((size_t)D * sizeof(buildCV_TD));
+    fgf_TD *ftd = (fgf_TD *)malloc((size_t)D * sizeof(fgf_TD));
+    if (!lImg || !rImg || !lG || !rG || !lv || !rv || !setup || !jobs || !btd || !ftd) goto done;
+    psmo_u8_to_f32(l_bgr, N * 3, lImg);
+    psmo_u8_to_f32(r_bgr, N * 3, rImg);
+    double t0 = now_ms();
+    psmo_cvc_preprocess(lImg, H, W, lG);
+    psmo_cvc_preprocess(rImg, H, W, rG);
+    for (int d = 0; d < D; ++d) {
+        btd[d] = (buildCV_TD){lImg, rImg, lG, rG, H, W, d, 0, lv + (size_t)d * N};
+        jobs[d] = (job){buildCV_thread, &btd[d]};
+    }
+    run_blocked(jobs, D, threads);
+    for (int d = 0; d < D; ++d) {
+        btd[d] = (buildCV_TD){rImg, lImg, rG, lG, H, W, d, 1, rv + (size_t)d * N};
+        jobs[d] = (job){buildCV_thread, &btd[d]};
+    }
+    run_blocked(jobs, D, threads);
+    double t1 = now_ms();
+    for (int side = 0; side < 2; ++side) {
+        const float *img = side ? rImg : lImg;
+        psmo_fgf_setup(img, H, W, s, setup);
+        for (int d = 0; d < D; ++d) {
+            ftd[d] = (fgf_TD){img, setup, H, W, s, (side ? rv : lv) + (size_t)d * N};
+            jobs[d] = (job){fgf_thread, &ftd[d]};
+        }
+        run_blocked(jobs, D, threads);
+    }
+    double t2 = now_ms();
+    wta_parallel(lv, D, H, W, ldisp, threads);
+    wta_parallel(rv, D, H, W, rdisp, threads);
+    double t3 = now_ms();
+    if (times) { times->cvc_ms = t1 - t0; times->cvf_ms = t2 - t1; times->dispsel_ms = t3 - t2; }
+    rc = 0;
+done:
+    free(lImg); free(rImg); free(lG); free(rG);
+    if (!lvol) free(lv);
+    if (!rvol) free(rv);
+    free(setup); free(jobs); free(btd); free(ftd);
     return rc;
 }
 

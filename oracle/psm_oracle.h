@@ -74,6 +74,20 @@ void psmo_cvf_preprocess(const float *img, int H, int W, float *rgb, float *mean
 void psmo_guided_filter(const float *rgb, const float *mean, const float *var, int H, int W,
                         float *p, float *ab);
 
+/* ---- CVF, Fast Guided Filter variant ("next" row: what the snapshot's live CPU branch runs) ------- */
+/* src/fastguidedfilter.cpp (FastGuidedFilterColor) as used by DispEst::CostFilter_FGF
+ * (src/DispEst.cpp:281-296): r = GIF_R_WIN = 8, eps = GIF_EPS, s = subsample_rate (2, 4 or 8).
+ * OpenCV pieces restated canonically:
+ *   cv::resize(..., INTER_NN):     dst(y,x) = src(min(floor(y*ify),H-1), min(floor(x*ifx),W-1)), ifx = 1/((W/s)/(double)W)
+ *   cv::blur(I, Size(k,k)), k = 2*(r/s)+1: taps -k/2..+k/2, REFLECT_101, fp64 sums (x taps left to right,
+ *                                  then y taps top to bottom), (float)(sum * (1.0/(k*k)))
+ *   cv::resize(..., INTER_LINEAR): fx = (float)((dx+0.5)*scale-0.5), sx = floor(fx), fx -= sx, clamped at both
+ *                                  ends; row pass S[sx]*(1.f-fx) + S[sx+1]*fx, then column pass, fp32, no FMA.
+ * setup: 12 planes of (H/s)*(W/s) floats: I0,I1,I2 (subsampled), mean0..2, invrr,invrg,invrb,invgg,invgb,invbb. */
+void psmo_fgf_setup(const float *img, int H, int W, int s, float *setup);
+/* filters one slice in place (FastGuidedFilterColor::filterSingleChannel + the NN subsampling of p) */
+void psmo_fgf_filter(const float *img, const float *setup, int H, int W, int s, float *p);
+
 /* ---- DispSel: winner takes all --------------------------------------------------- */
 
 /* src/DispSel.cpp:83-109 DispSel::CVSelect on a dense [D][H][W] volume. */
@@ -100,6 +114,11 @@ typedef struct {
 int psmo_pipeline_f32(const uint8_t *l_bgr, const uint8_t *r_bgr, int H, int W, int D, int threads,
                       uint8_t *ldisp, uint8_t *rdisp, float *lvol, float *rvol, float *raw_l,
                       float *raw_r, psmo_times *times);
+
+/* CostConst() -> CostFilter_FGF() -> DispSelect_CPU(): the snapshot's live CPU branch
+ * (src/StereoMatch.cpp:207-224), s = subsample_rate in {2,4,8}. */
+int psmo_pipeline_fgf(const uint8_t *l_bgr, const uint8_t *r_bgr, int H, int W, int D, int threads, int s,
+                      uint8_t *ldisp, uint8_t *rdisp, float *lvol, float *rvol, psmo_times *times);
 
 /* ---- 8-bit char mode (build-defined; the reference has no CPU 8-bit path) -------- */
 /* Contract (DESIGN.md "8-bit mode"): u8 planar colour, u8 gray/gradient, u8 cost volume

@@ -203,3 +203,38 @@ def eval_bad_pixels(disp, gt, mask, maxDis, scale_factor, error_threshold=4):
     bad = lib().psmo_eval_bad_pixels(_p(d), _p(g), _p(m), H, W, int(maxDis), int(scale_factor),
                                      int(error_threshold), C.byref(avg))
     return int(bad), float(avg.value)
+
+
+def fgf_setup(img_f32, s):
+    img = _f32(img_f32)
+    H, W, _ = img.shape
+    out = np.empty((12, H // s, W // s), np.float32)
+    lib().psmo_fgf_setup(_p(img), H, W, int(s), _p(out))
+    return out
+
+
+def fgf_filter(img_f32, setup, p, s):
+    img, setup = _f32(img_f32), _f32(setup)
+    q = _f32(p).copy()
+    H, W = q.shape
+    lib().psmo_fgf_filter(_p(img), _p(setup), H, W, int(s), _p(q))
+    return q
+
+
+def pipeline_fgf(l_bgr, r_bgr, D, s=4, threads=8, want_volumes=False):
+    l, r = _u8(l_bgr), _u8(r_bgr)
+    H, W, _ = l.shape
+    ld = np.empty((H, W), np.uint8)
+    rd = np.empty((H, W), np.uint8)
+    lv = np.empty((D, H, W), np.float32) if want_volumes else None
+    rv = np.empty((D, H, W), np.float32) if want_volumes else None
+    t = Times()
+    lib().psmo_pipeline_fgf.restype = C.c_int
+    rc = lib().psmo_pipeline_fgf(_p(l), _p(r), H, W, int(D), int(threads), int(s), _p(ld), _p(rd), _p(lv), _p(rv),
+                                 C.byref(t))
+    if rc != 0:
+        raise ValueError("psmo_pipeline_fgf rejected the arguments (rc=%d)" % rc)
+    out = {"ldisp": ld, "rdisp": rd, "cvc_ms": t.cvc_ms, "cvf_ms": t.cvf_ms, "dispsel_ms": t.dispsel_ms}
+    if want_volumes:
+        out["lvol"], out["rvol"] = lv, rv
+    return out

@@ -51,6 +51,8 @@ struct psm_ctx {
     uint8_t *maps = nullptr;            // [2][H][W]
     uint8_t *valid = nullptr;           // [2][H][W]
     uint8_t *p4[2] = {nullptr, nullptr};  // PSM_U8 only: {c0,c1,c2,grad} words
+    void *fgf = nullptr;                // psm_cost_filter_fgf scratch (small planes), fgf_bytes long
+    size_t fgf_bytes = 0;
 
     bool have_images = false, have_g1 = false, have_cost = false, have_maps = false, have_valid = false;
     // raw_rows[side]: which rows of the unfiltered cost volume exist in memory.  psm_cost_construct may
@@ -166,6 +168,7 @@ void free_all(psm_ctx *c)
     (void)hipFree(c->gather);
     (void)hipFree(c->maps);
     (void)hipFree(c->valid);
+    (void)hipFree(c->fgf);
     for (auto &t : c->timers)
         for (auto &p : t.pending) {
             (void)hipEventDestroy(p.first);
@@ -523,6 +526,42 @@ int psm_cost_filter_side(psm_ctx *c, int side)
     if (!c->opt_async) PSM_HIP(c, hipStreamSynchronize(c->stream));
     c->stage_us[PSM_STAGE_CVF] = (side == PSM_LEFT ? 0.0 : c->stage_us[PSM_STAGE_CVF]) + (now_us() - t0);
     return 0;
+}
+
+int psm_cost_filter_fgf(psm_ctx *c, int sub)
+{
+    if (!c) return 1;
+    if (c->dtype != PSM_F32) return fail(c, "psm_cost_filter_fgf: float contexts only");
+    if (sub != 2 && sub != 4 && sub != 8) return fail(c, "psm_cost_filter_fgf: subsample_rate %d not in {2,4,8}", sub);
+    if (!c->have_cost) return fail(c, "psm_cost_filter_fgf: no cost volume (call psm_cost_construct or psm_upload_volume)");
+    if (!c->have_images) return fail(c, "psm_cost_filter_fgf: no image pair uploaded (guidance)");
+    const int ws = c->W / sub, hs = c->H / sub, rad = 8 / sub;
+    if (ws <= rad || hs <= rad) return fail(c, "psm_cost_filter_fgf: %dx%d too small for subsample_rate %d", c->W, c->H, sub);
+    if (bind(c)) return 1;
+    const double t0 = now_us();
+    if (!c->have_g1 && run_prep(c)) return 1;
+    // small planes: ism, msm, v1 (float4), v2 (float2) per pixel; ab, mab (float4) per small voxel
+    const size_t n = (size_t)ws * hs, need = n * (3 * sizeof(float4) + sizeof(float2)) + 2 * n * c->Dloc * sizeof(float4);
+    if (c->fgf_bytes < need) {
+        PSM_HIP(c, hipStreamSynchronize(c->stream));
+        (void)hipFree(c->fgf);
+        c->fgf = nullptr;
+        c->fgf_bytes = 0;
+        PSM_HIP(c, hipMalloc(&c->fgf, need));
+        c->fgf_bytes = need;
+    }
+    float4 *ism = (float4 *)c->fgf, *msm = ism + n, *v1 = msm + n, *ab = v1 + n, *mab = ab + n * c->Dloc;
+    float2 *v2 = (float2 *)(mab + n * c->Dloc);
+    // left volume with the left image as guidance, then the right one (src/DispEst.cpp:283-295)
+    for (int side = 0; side < 2; ++side) {
+        if (materialize(c, side)) return 1;
+        Prof p(c, PSM_K_FGF);
+        launch_fgf_setup(c->stream, c->g[side].g1, c->W, c->H, sub, ism, msm, v1, v2);
+        launch_fgf_filter(c->stream, (float *)c->vol[side], c->g[side].g1, c->W, c->H, c->Dloc, sub, ism, msm, v1, v2, ab, mab);
+    }
+    if (check_launch(c, "cvf (fast guided filter)")) return 1;
+    c->have_maps = false;
+    return end_stage(c, PSM_STAGE_CVF, t0);
 }
 
 int psm_filter_stage_a(psm_ctx *c, int side)

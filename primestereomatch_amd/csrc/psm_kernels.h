@@ -57,6 +57,13 @@ void launch_lr_check(hipStream_t s, const uint8_t *l, const uint8_t *r, int W, i
 // fill invalid pixels of one map in place (valid: 0/1 per pixel)
 void launch_fill_inv(hipStream_t s, uint8_t *dis, const uint8_t *valid, int W, int H);
 
+// ---- Fast Guided Filter variant (psm_fgf.hip); sub = subsample rate, small planes are (H/sub) x (W/sub) ----
+// g1 -> subsampled guidance ism, its means msm and the inverse covariance planes v1 = {irr,irg,irb,igg}, v2 = {igb,ibb}
+void launch_fgf_setup(hipStream_t s, const float4 *g1, int W, int H, int sub, float4 *ism, float4 *msm, float4 *v1, float2 *v2);
+// filters Dloc slices of vol in place; ab/mab: scratch, Dloc*(H/sub)*(W/sub) float4 each
+void launch_fgf_filter(hipStream_t s, float *vol, const float4 *g1, int W, int H, int Dloc, int sub, const float4 *ism,
+                       const float4 *msm, const float4 *v1, const float2 *v2, float4 *ab, float4 *mab);
+
 // ---- 8-bit char mode ----
 void launch_prep_u8(hipStream_t s, const uint8_t *src, size_t pitch, int W, int H, uint8_t *planes4);
 void launch_cvc_u8(hipStream_t s, const uint8_t *base4, const uint8_t *other4, uint8_t *vol, int W, int H,

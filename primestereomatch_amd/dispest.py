@@ -118,6 +118,12 @@ class DispEst:
         self._ck(self._lib.psm_cost_filter(self._h), "CostFilter_GPU")
         return 0
 
+    def CostFilter_FGF_GPU(self) -> int:
+        """DispEst::CostFilter_FGF (src/DispEst.cpp:281-296) on the device: FastGuidedFilterColor with
+        r = GIF_R_WIN, eps = GIF_EPS and s = subsample_rate (setSubsampleRate; default 4)."""
+        self._ck(self._lib.psm_cost_filter_fgf(self._h, int(self.subsample_rate)), "CostFilter_FGF_GPU")
+        return 0
+
     def DispSelect_GPU(self) -> int:
         self._ck(self._lib.psm_disp_select(self._h, _ptr(self.lDisMap), _ptr(self.rDisMap), self.wid),
                  "DispSelect_GPU")

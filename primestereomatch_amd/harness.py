@@ -30,8 +30,10 @@ def error_vs_ground_truth(lDisMap, gt, mask, maxDis, scale_factor, error_thresho
 
 
 def compute(l_bgr, r_bgr, maxDis=64, gt=None, mask=None, scale_factor=4, error_threshold=4, threads=8,
-            dtype="f32", post_process=True, verbose=False):
-    """One frame of STEREO_GIF on the accelerator path.  l_bgr/r_bgr: H x W x 3 uint8 (imread order)."""
+            dtype="f32", post_process=True, verbose=False, subsample_rate=0):
+    """One frame of STEREO_GIF on the accelerator path.  l_bgr/r_bgr: H x W x 3 uint8 (imread order).
+    subsample_rate 0: full guided filter (CostFilter_GPU, the reference's 'm' branch); 2/4/8: the Fast Guided
+    Filter variant (CostFilter_FGF, the snapshot's live branch, src/StereoMatch.cpp:213) on the device."""
     out = {}
     lFrame = np.ascontiguousarray(l_bgr)
     rFrame = np.ascontiguousarray(r_bgr)
@@ -42,9 +44,12 @@ def compute(l_bgr, r_bgr, maxDis=64, gt=None, mask=None, scale_factor=4, error_t
     with DispEst(lFrame, rFrame, maxDis, threads, True, dtype=dtype) as SMDE:
         SMDE.setInputImages(lFrame, rFrame)
         SMDE.setThreads(threads)
-        SMDE.setSubsampleRate(4)
+        SMDE.setSubsampleRate(subsample_rate or 4)
         SMDE.CostConst_GPU()
-        SMDE.CostFilter_GPU()
+        if subsample_rate:
+            SMDE.CostFilter_FGF_GPU()
+        else:
+            SMDE.CostFilter_GPU()
         SMDE.DispSelect_GPU()
         if post_process:
             SMDE.LRCheck_GPU()

@@ -86,6 +86,14 @@ int DispEst::CostFilter_GPU()
     return rc;
 }
 
+int DispEst::CostFilter_FGF_GPU()
+{
+    if (ctx.empty()) return 1;
+    int rc = 0;
+    for (psm_ctx *c : ctx) rc |= hipUtil::api().cost_filter_fgf(c, (int)subsample_rate);
+    return rc;
+}
+
 int DispEst::DispSelect_GPU()
 {
     if (ctx.empty()) return 1;

@@ -65,6 +65,7 @@ public:
 
     int CostConst_GPU();
     int CostFilter_GPU();
+    int CostFilter_FGF_GPU();  // DispEst::CostFilter_FGF (src/DispEst.cpp:281-296) on the device, s = subsample_rate
     int DispSelect_GPU();
     // The reference's PostProcess_GPU runs the CPU JointWMF (src/DispEst.cpp:338-344), which is
     // out of scope here; this one runs the device left-right check

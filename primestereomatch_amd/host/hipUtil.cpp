@@ -41,6 +41,7 @@ bool hipUtil::load(const char *path)
               bind(g_api.destroy, "psm_destroy") && bind(g_api.last_error, "psm_last_error") &&
               bind(g_api.set_option, "psm_set_option") && bind(g_api.upload_pair, "psm_upload_pair") &&
               bind(g_api.cost_construct, "psm_cost_construct") && bind(g_api.cost_filter, "psm_cost_filter") &&
+              bind(g_api.cost_filter_fgf, "psm_cost_filter_fgf") &&
               bind(g_api.disp_select, "psm_disp_select") && bind(g_api.disp_select_partial, "psm_disp_select_partial") &&
               bind(g_api.disp_merge_ctx, "psm_disp_merge_ctx") && bind(g_api.lr_check, "psm_lr_check") && bind(g_api.fill_invalid, "psm_fill_invalid") &&
               bind(g_api.stage_time_us, "psm_stage_time_us");

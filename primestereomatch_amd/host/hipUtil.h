@@ -21,6 +21,7 @@ struct HipApi {
     int (*upload_pair)(psm_ctx *, const void *, const void *, int, size_t, int) = nullptr;
     int (*cost_construct)(psm_ctx *) = nullptr;
     int (*cost_filter)(psm_ctx *) = nullptr;
+    int (*cost_filter_fgf)(psm_ctx *, int) = nullptr;
     int (*disp_select)(psm_ctx *, uint8_t *, uint8_t *, size_t) = nullptr;
     int (*disp_select_partial)(psm_ctx *, void *) = nullptr;
     int (*disp_merge_ctx)(psm_ctx *, psm_ctx *const *, int, uint8_t *, uint8_t *, size_t) = nullptr;

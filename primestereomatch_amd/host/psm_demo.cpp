@@ -1,6 +1,7 @@
 // psm_demo - headless counterpart of the reference's StereoMatch::compute accelerator branch
 // (src/StereoMatch.cpp:193-262): raw B,G,R uint8 pair in, four timed stages, raw uint8 maps out.
-//   psm_demo <left.raw> <right.raw> <W> <H> <maxDis> <out_prefix> [ndev] [f32|u8] [float_input]
+//   psm_demo <left.raw> <right.raw> <W> <H> <maxDis> <out_prefix> [ndev] [f32|u8] [float_input] [fgf_rate]
+// fgf_rate 0 (default): CostFilter_GPU; 2/4/8: CostFilter_FGF_GPU with that subsample rate
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -29,7 +30,7 @@ static bool dump(const std::string &path, const unsigned char *p, size_t n)
 int main(int argc, char **argv)
 {
     if (argc < 7) {
-        fprintf(stderr, "usage: %s left.raw right.raw W H maxDis out_prefix [ndev] [f32|u8] [float_input]\n", argv[0]);
+        fprintf(stderr, "usage: %s left.raw right.raw W H maxDis out_prefix [ndev] [f32|u8] [float_input] [fgf_rate]\n", argv[0]);
         return 2;
     }
     const int W = atoi(argv[3]), H = atoi(argv[4]), D = atoi(argv[5]);
@@ -37,6 +38,7 @@ int main(int argc, char **argv)
     const int ndev = argc > 7 ? atoi(argv[7]) : 1;
     const int dtype = (argc > 8 && !strcmp(argv[8], "u8")) ? PSM_U8 : PSM_F32;
     const bool float_input = argc > 9 && atoi(argv[9]) != 0;
+    const int fgf_rate = argc > 10 ? atoi(argv[10]) : 0;
     std::vector<unsigned char> lraw, rraw;
     if (!slurp(argv[1], lraw, (size_t)W * H * 3) || !slurp(argv[2], rraw, (size_t)W * H * 3)) {
         fprintf(stderr, "psm_demo: cannot read the input pair\n");
@@ -64,10 +66,10 @@ int main(int argc, char **argv)
     if (!SMDE.ok()) return 4;
     SMDE.setInputImages(l, r);
     SMDE.setThreads(8);
-    SMDE.setSubsampleRate(4);
+    SMDE.setSubsampleRate(fgf_rate ? fgf_rate : 4);
     int rc = 0;
     rc |= SMDE.CostConst_GPU();
-    rc |= SMDE.CostFilter_GPU();
+    rc |= fgf_rate ? SMDE.CostFilter_FGF_GPU() : SMDE.CostFilter_GPU();
     rc |= SMDE.DispSelect_GPU();
     rc |= SMDE.PostProcess_GPU();
     if (rc) return 5;

@@ -68,6 +68,19 @@ def main():
         manifest[name]["bad_pixels_thr4_nonocc"] = bad
         manifest[name]["avg_err"] = avg
         print(name, l.shape, "bad(thr4,nonocc)=%.2f%%" % (100.0 * bad / gt_l.size), "avg", avg)
+        # Fast Guided Filter variant (CostFilter_FGF), the three subsample rates the reference sweeps
+        fgf = {}
+        manifest[name]["fgf"] = {}
+        for s in (2, 4, 8):
+            rf = O.pipeline_fgf(l, r, D, s=s, threads=8, want_volumes=True)
+            fgf[f"ldisp_s{s}"], fgf[f"rdisp_s{s}"] = rf["ldisp"], rf["rdisp"]
+            if s == 4:
+                fgf["lvol_d17_s4"] = rf["lvol"][17]
+            badf, avgf = O.eval_bad_pixels(rf["ldisp"], gt_l, occl, D, 4, 4)
+            manifest[name]["fgf"][str(s)] = {"sha256": {k: sha(rf[k]) for k in ("ldisp", "rdisp", "lvol", "rvol")},
+                                            "bad_pixels_thr4_nonocc": badf, "avg_err": avgf}
+            print(name, "fgf s=%d bad=%.2f%%" % (s, 100.0 * badf / gt_l.size))
+        np.savez_compressed(os.path.join(OUT, f"{name.lower()}_oracle_fgf.npz"), **fgf)
     with open(os.path.join(OUT, "manifest.json"), "w") as f:
         json.dump(manifest, f, indent=1, sort_keys=True)
 
