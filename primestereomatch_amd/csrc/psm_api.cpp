@@ -554,10 +554,13 @@ int psm_cost_filter_fgf(psm_ctx *c, int sub)
     float2 *v2 = (float2 *)(mab + n * c->Dloc);
     // left volume with the left image as guidance, then the right one (src/DispEst.cpp:283-295)
     for (int side = 0; side < 2; ++side) {
-        if (materialize(c, side)) return 1;
+        // a virtual (lazy) cost volume stays virtual: the filter samples 1/sub^2 of it straight from the g1 planes
+        const int mode = c->raw_rows[side] == psm_ctx::RAW_ALL ? 0 : 1 + side;
         Prof p(c, PSM_K_FGF);
         launch_fgf_setup(c->stream, c->g[side].g1, c->W, c->H, sub, ism, msm, v1, v2);
-        launch_fgf_filter(c->stream, (float *)c->vol[side], c->g[side].g1, c->W, c->H, c->Dloc, sub, ism, msm, v1, v2, ab, mab);
+        launch_fgf_filter(c->stream, (float *)c->vol[side], c->g[side].g1, c->g[1 - side].g1, c->W, c->H, c->Dloc, c->d0, sub, mode,
+                          msm, v1, v2, ab, mab);
+        c->raw_rows[side] = psm_ctx::RAW_ALL;   // vol[side] now holds real (filtered) data
     }
     if (check_launch(c, "cvf (fast guided filter)")) return 1;
     c->have_maps = false;

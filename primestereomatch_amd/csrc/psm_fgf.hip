@@ -10,10 +10,19 @@
 //                  bottom), (float)(sum * (1.0/(k*k)))
 //   INTER_LINEAR:  fx = (float)((dx+0.5)*scale-0.5); sx = floor(fx); fx -= sx; clamped at both ends;
 //                  row pass S[sx]*(1-fx) + S[sx+1]*fx, then column pass, fp32, no FMA
-// Work split: the subsampled planes are 1/s^2 of the pixels, so the three small-image kernels below are
-// plain per-pixel (direct) kernels; the only full-resolution kernel is the upsample + linear model, which
-// reads each filtered slice nowhere and writes it once (4 B/voxel).
+// Kernels (DESIGN.md "Fast Guided Filter row"):
+//   k_fgf_small_img / k_fgf_setup   per image, small grid, direct k x k windows (d-invariant, ~10 us)
+//   k_fgf_model<K, MODE>            per slice, small grid: one wave marches down 64 subsampled columns; the row of
+//                                   (p, I0 p, I1 p, I2 p) goes through LDS for the k horizontal taps, the k row sums
+//                                   live in a register ring for the vertical taps.  MODE 1/2 builds the matching
+//                                   cost of the sampled pixel from the g1 planes, so the FGF path never needs the
+//                                   full-resolution cost volume in memory (it samples 1/s^2 of it).
+//   k_fgf_smooth<K>                 same marching scheme on the (a_r,a_g,a_b,b) planes
+//   k_fgf_apply4                    full resolution: 4 pixels x 4 rows per thread, guidance in registers across a
+//                                   chunk of slices, horizontally interpolated rows cached across the rows that
+//                                   share them, one 16-byte store per lane and row (whole 128-byte lines)
 #include "psm_kernels.h"
+#include "psm_cost.h"
 
 namespace psm {
 
@@ -105,81 +114,120 @@ __global__ __launch_bounds__(256) void k_fgf_setup(const float4 *__restrict__ is
     v2[o] = make_float2(__fdiv_rn(igb, det), __fdiv_rn(ibb, det));
 }
 
-// ---- per slice, small grid: means of p and I*p -> linear model (a_r,a_g,a_b,b) ---------------------
-template <int K>
-__global__ __launch_bounds__(256) void k_fgf_model(const float *__restrict__ vol, int W, int H, int ws, int hs,
-                                                  const float4 *__restrict__ ism, const float4 *__restrict__ msm,
-                                                  const float4 *__restrict__ v1, const float2 *__restrict__ v2,
-                                                  float4 *__restrict__ ab)
+// ---- separable k x k mean of four planes (one float4 per pixel), marching down the rows -------------
+// One 64-lane workgroup owns OUTW = 64 - 2R output columns (+R halo lanes each side, reflected) of one slice and
+// the rows [ybeg, yend).  Summation order = cv::blur's: x taps left to right (fp64), then y taps top to bottom.
+template <int K, class Load, class Finish>
+__device__ __forceinline__ void blur4_march(int ws, int hs, int strip, int ybeg, int yend, float4 *lds, Load load, Finish finish)
 {
-    int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y, d = blockIdx.z;
-    if (x >= ws) return;
-    constexpr int R = K / 2;
+    constexpr int R = K / 2, OUTW = 64 - 2 * R;
+    const int lane = threadIdx.x;
+    const int x = strip * OUTW - R + lane;
+    const int xc = r101s(x, ws);
+    const bool out_lane = lane >= R && lane < 64 - R && x < ws;
     const double scale = 1.0 / (K * K);
-    const float *vd = vol + (size_t)d * H * W;
-    int sxs[K];
+    int tap[K];
 #pragma unroll
-    for (int i = 0; i < K; ++i) sxs[i] = r101s(x - R + i, ws);
-    double acc[4] = {0, 0, 0, 0};
-    for (int j = -R; j <= R; ++j) {
-        const int ys = r101s(y + j, hs);
-        const float *prow = vd + (size_t)nn_src(ys, hs, H) * W;
-        const float4 *irow = ism + (size_t)ys * ws;
-        double h[4] = {0, 0, 0, 0};
-#pragma unroll
-        for (int i = 0; i < K; ++i) {
-            const float p = prow[nn_src(sxs[i], ws, W)];
-            const float4 g = irow[sxs[i]];
-            h[0] = __dadd_rn(h[0], (double)p);
-            h[1] = __dadd_rn(h[1], (double)__fmul_rn(g.x, p));
-            h[2] = __dadd_rn(h[2], (double)__fmul_rn(g.y, p));
-            h[3] = __dadd_rn(h[3], (double)__fmul_rn(g.z, p));
-        }
-#pragma unroll
-        for (int c = 0; c < 4; ++c) acc[c] = __dadd_rn(acc[c], h[c]);
+    for (int i = 0; i < K; ++i) {
+        int l = lane - R + i;
+        tap[i] = l < 0 ? 0 : (l > 63 ? 63 : l);
     }
-    const float mp = (float)(acc[0] * scale), mr = (float)(acc[1] * scale), mg = (float)(acc[2] * scale),
-                mb = (float)(acc[3] * scale);
-    const size_t o = (size_t)y * ws + x;
-    const float4 m = msm[o], a = v1[o];
-    const float2 b2 = v2[o];
-    // src/fastguidedfilter.cpp:184-194
-    float cr = __fsub_rn(mr, __fmul_rn(m.x, mp));
-    float cg = __fsub_rn(mg, __fmul_rn(m.y, mp));
-    float cb = __fsub_rn(mb, __fmul_rn(m.z, mp));
-    float ar = __fadd_rn(__fadd_rn(__fmul_rn(a.x, cr), __fmul_rn(a.y, cg)), __fmul_rn(a.z, cb));
-    float ag = __fadd_rn(__fadd_rn(__fmul_rn(a.y, cr), __fmul_rn(a.w, cg)), __fmul_rn(b2.x, cb));
-    float abl = __fadd_rn(__fadd_rn(__fmul_rn(a.z, cr), __fmul_rn(b2.x, cg)), __fmul_rn(b2.y, cb));
-    float bq = __fsub_rn(__fsub_rn(__fsub_rn(mp, __fmul_rn(ar, m.x)), __fmul_rn(ag, m.y)), __fmul_rn(abl, m.z));
-    ab[(size_t)d * hs * ws + o] = make_float4(ar, ag, abl, bq);
+    double ring[K][4];
+#pragma unroll
+    for (int u = 0; u < K; ++u) ring[u][0] = ring[u][1] = ring[u][2] = ring[u][3] = 0.0;
+    int par = 0;
+    for (int yy0 = ybeg - R; yy0 < yend + R; yy0 += K) {
+#pragma unroll
+        for (int u = 0; u < K; ++u) {
+            const int yy = yy0 + u;
+            if (yy < yend + R) {  // uniform over the workgroup
+                lds[par * 64 + lane] = load(r101s(yy, hs), xc);
+                __syncthreads();
+                double h0 = 0.0, h1 = 0.0, h2 = 0.0, h3 = 0.0;
+#pragma unroll
+                for (int i = 0; i < K; ++i) {
+                    const float4 t = lds[par * 64 + tap[i]];
+                    h0 = __dadd_rn(h0, (double)t.x);
+                    h1 = __dadd_rn(h1, (double)t.y);
+                    h2 = __dadd_rn(h2, (double)t.z);
+                    h3 = __dadd_rn(h3, (double)t.w);
+                }
+                ring[u][0] = h0; ring[u][1] = h1; ring[u][2] = h2; ring[u][3] = h3;
+                par ^= 1;
+                if (yy >= ybeg + R) {  // rows yy-2R .. yy are in the ring, oldest in slot u+1
+                    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+#pragma unroll
+                    for (int j = 1; j <= K; ++j) {
+                        const int sl = (u + j) % K;
+                        a0 = __dadd_rn(a0, ring[sl][0]);
+                        a1 = __dadd_rn(a1, ring[sl][1]);
+                        a2 = __dadd_rn(a2, ring[sl][2]);
+                        a3 = __dadd_rn(a3, ring[sl][3]);
+                    }
+                    if (out_lane)
+                        finish(yy - R, x, make_float4((float)(a0 * scale), (float)(a1 * scale), (float)(a2 * scale), (float)(a3 * scale)));
+                }
+            }
+        }
+    }
+}
+
+// ---- per slice, small grid: means of p and I*p -> linear model (a_r,a_g,a_b,b) ---------------------
+// MODE 0: p from the cost volume in memory; 1 / 2: p = left / right matching cost of the sampled pixel, built
+// from the g1 planes (CVC::buildCV_left/right arithmetic, src/CVC.cpp:122-179)
+template <int K, int MODE>
+__global__ __launch_bounds__(64) void k_fgf_model(const float *__restrict__ vol, int W, int H, int ws, int hs, int nstrips,
+                                                 int seg, const float4 *__restrict__ g1, const float4 *__restrict__ g1_other,
+                                                 int d_begin, const float4 *__restrict__ msm, const float4 *__restrict__ v1,
+                                                 const float2 *__restrict__ v2, float4 *__restrict__ ab)
+{
+    __shared__ float4 lds[2 * 64];
+    const int strip = blockIdx.x % nstrips, sgi = blockIdx.x / nstrips, d = blockIdx.y;
+    const int ybeg = sgi * seg, yend = ybeg + seg < hs ? ybeg + seg : hs;
+    const float *vd = vol + (size_t)d * H * W;
+    const int D = d_begin + d;
+    int Xc = -1;  // full-resolution column of this lane's subsampled column (fixed for the whole march)
+    auto load = [&](int ys, int xs) -> float4 {
+        if (Xc < 0) Xc = nn_src(xs, ws, W);
+        const size_t o = (size_t)nn_src(ys, hs, H) * W;
+        const float4 g = g1[o + Xc];
+        float p;
+        if (MODE == 0) p = vd[o + Xc];
+        else if (MODE == 1) p = Xc >= D ? cost_pair(g, g1_other[o + Xc - D]) : cost_border(g);
+        else p = Xc < W - D ? cost_pair(g, g1_other[o + Xc + D]) : cost_border(g);
+        return make_float4(p, __fmul_rn(g.x, p), __fmul_rn(g.y, p), __fmul_rn(g.z, p));
+    };
+    auto finish = [&](int y, int x, float4 mean) {
+        const float mp = mean.x, mr = mean.y, mg = mean.z, mb = mean.w;
+        const size_t o = (size_t)y * ws + x;
+        const float4 m = msm[o], a = v1[o];
+        const float2 b2 = v2[o];
+        // src/fastguidedfilter.cpp:184-194
+        float cr = __fsub_rn(mr, __fmul_rn(m.x, mp));
+        float cg = __fsub_rn(mg, __fmul_rn(m.y, mp));
+        float cb = __fsub_rn(mb, __fmul_rn(m.z, mp));
+        float ar = __fadd_rn(__fadd_rn(__fmul_rn(a.x, cr), __fmul_rn(a.y, cg)), __fmul_rn(a.z, cb));
+        float ag = __fadd_rn(__fadd_rn(__fmul_rn(a.y, cr), __fmul_rn(a.w, cg)), __fmul_rn(b2.x, cb));
+        float abl = __fadd_rn(__fadd_rn(__fmul_rn(a.z, cr), __fmul_rn(b2.x, cg)), __fmul_rn(b2.y, cb));
+        float bq = __fsub_rn(__fsub_rn(__fsub_rn(mp, __fmul_rn(ar, m.x)), __fmul_rn(ag, m.y)), __fmul_rn(abl, m.z));
+        ab[(size_t)d * hs * ws + o] = make_float4(ar, ag, abl, bq);
+    };
+    blur4_march<K>(ws, hs, strip, ybeg, yend, lds, load, finish);
 }
 
 // ---- per slice, small grid: k x k means of the model planes ----------------------------------------
 template <int K>
-__global__ __launch_bounds__(256) void k_fgf_smooth(const float4 *__restrict__ ab, int ws, int hs, float4 *__restrict__ mab)
+__global__ __launch_bounds__(64) void k_fgf_smooth(const float4 *__restrict__ ab, int ws, int hs, int nstrips, int seg,
+                                                  float4 *__restrict__ mab)
 {
-    int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y, d = blockIdx.z;
-    if (x >= ws) return;
-    constexpr int R = K / 2;
-    const double scale = 1.0 / (K * K);
+    __shared__ float4 lds[2 * 64];
+    const int strip = blockIdx.x % nstrips, sgi = blockIdx.x / nstrips, d = blockIdx.y;
+    const int ybeg = sgi * seg, yend = ybeg + seg < hs ? ybeg + seg : hs;
     const float4 *ad = ab + (size_t)d * hs * ws;
-    double acc[4] = {0, 0, 0, 0};
-    for (int j = -R; j <= R; ++j) {
-        const float4 *row = ad + (size_t)r101s(y + j, hs) * ws;
-        double h[4] = {0, 0, 0, 0};
-#pragma unroll
-        for (int i = -R; i <= R; ++i) {
-            const float4 v = row[r101s(x + i, ws)];
-            h[0] = __dadd_rn(h[0], (double)v.x);
-            h[1] = __dadd_rn(h[1], (double)v.y);
-            h[2] = __dadd_rn(h[2], (double)v.z);
-            h[3] = __dadd_rn(h[3], (double)v.w);
-        }
-#pragma unroll
-        for (int c = 0; c < 4; ++c) acc[c] = __dadd_rn(acc[c], h[c]);
-    }
-    mab[(size_t)d * hs * ws + (size_t)y * ws + x] =
-        make_float4((float)(acc[0] * scale), (float)(acc[1] * scale), (float)(acc[2] * scale), (float)(acc[3] * scale));
+    float4 *md = mab + (size_t)d * hs * ws;
+    auto load = [&](int ys, int xs) -> float4 { return ad[(size_t)ys * ws + xs]; };
+    auto finish = [&](int y, int x, float4 mean) { md[(size_t)y * ws + x] = mean; };
+    blur4_march<K>(ws, hs, strip, ybeg, yend, lds, load, finish);
 }
 
 // ---- full resolution: bilinear upsampling of the four smoothed planes + the linear model -----------
@@ -207,6 +255,108 @@ __global__ __launch_bounds__(256) void k_fgf_apply(const float4 *__restrict__ ma
         __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(ur, g.x), __fmul_rn(ug, g.y)), __fmul_rn(ub, g.z)), uq);
 }
 
+
+// 4 pixels x RB rows per thread, looping over a chunk of slices with the guidance in registers (W % 4 == 0).
+// The interpolation arithmetic is written on 4-vectors (components of one model pixel) so that it compiles to
+// packed fp32 multiplies/adds (v_pk_mul_f32 / v_pk_add_f32): same IEEE roundings, half the VALU issue slots.
+typedef float f4v __attribute__((ext_vector_type(4)));
+typedef float f2v __attribute__((ext_vector_type(2)));
+// Software pipeline: the model rows of slice d+1 are requested before the outputs of slice d are stored.  A wave's
+// vector memory operations retire through one in-order counter, so a load issued after a store cannot be waited
+// for before that store has reached memory; issued in this order the loads only ever wait for stores that are a
+// whole iteration old.
+// Row blocks start at y = RB*by - yshift: with yshift = (s/2) % RB the RB rows of a block share one pair of model
+// rows whenever H is a multiple of s, so a block needs exactly two interpolated model rows per slice (the generic
+// "next pair" step below stays for the other sizes).
+template <int RB>
+__global__ __launch_bounds__(256) void k_fgf_apply4(const f4v *__restrict__ mab, int ws, int hs, const f4v *__restrict__ g1,
+                                                   int W, int H, float *__restrict__ vol, int Dloc, int dchunk, int yshift)
+{
+    const int x0 = (blockIdx.x * 256 + threadIdx.x) * 4, y0 = (int)blockIdx.y * RB - yshift;
+    if (x0 >= W) return;
+    const int dbeg = blockIdx.z * dchunk, dend = dbeg + dchunk < Dloc ? dbeg + dchunk : Dloc;
+    unsigned oa[4], ob[4];   // byte offsets of the two model columns of each pixel within a model row
+    float a0[4], a1[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        int ca;
+        lin_src(x0 + j, ws, W, ca, a1[j]);
+        oa[j] = (unsigned)ca * 16u;
+        ob[j] = (unsigned)(ca + 1 < ws ? ca + 1 : ws - 1) * 16u;
+        a0[j] = __fsub_rn(1.f, a1[j]);
+    }
+    f2v gxy[RB][4];
+    float gz[RB][4];
+    int sy[RB], sy1[RB];
+    float b0[RB], b1[RB];
+#pragma unroll
+    for (int r = 0; r < RB; ++r) {
+        int y = y0 + r;
+        y = y < 0 ? 0 : (y < H ? y : H - 1);   // rows outside the image are skipped below; clamped here to stay in range
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const f4v g = g1[(size_t)y * W + x0 + j];
+            gxy[r][j] = g.xy;
+            gz[r][j] = g.z;
+        }
+        lin_src(y, hs, H, sy[r], b1[r]);
+        sy1[r] = sy[r] + 1 < hs ? sy[r] + 1 : hs - 1;
+        b0[r] = __fsub_rn(1.f, b1[r]);
+    }
+    const size_t HW = (size_t)H * W;
+    f4v Ra[8], Rb[8];   // raw model columns {S[sx], S[sx+1]} of the 4 pixels, rows sy[0] and sy1[0]
+    auto request = [&](int d, int row, f4v *R) {
+        size_t roff = (((size_t)d * hs + row) * ws) * sizeof(f4v);   // uniform base + 32-bit lane offsets
+        asm volatile("" : "+s"(roff));   // keep it one scalar base: no per-load 64-bit induction pointers
+        const char *mr = (const char *)mab + roff;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            R[2 * j] = *(const f4v *)(mr + oa[j]);
+            R[2 * j + 1] = *(const f4v *)(mr + ob[j]);
+        }
+    };
+    auto hrow = [&](const f4v *R, f4v *U) {  // row pass of cv::resize INTER_LINEAR: S[sx]*(1-fx) + S[sx+1]*fx
+#pragma unroll
+        for (int j = 0; j < 4; ++j) U[j] = R[2 * j] * a0[j] + R[2 * j + 1] * a1[j];
+    };
+    request(dbeg, sy[0], Ra);
+    request(dbeg, sy1[0], Rb);
+    for (int d = dbeg; d < dend; ++d) {
+        f4v Ua[4], Ub[4];
+        hrow(Ra, Ua);
+        hrow(Rb, Ub);
+        __builtin_amdgcn_sched_barrier(0);
+        if (d + 1 < dend) {
+            request(d + 1, sy[0], Ra);
+            request(d + 1, sy1[0], Rb);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        f4v o[RB];
+#pragma unroll
+        for (int r = 0; r < RB; ++r) {
+            // consecutive image rows use the same pair of model rows or the next one (uniform over the block):
+            // sy advances by 0 or 1 per row and the new sy is the old sy1
+            if (r > 0 && sy[r] != sy[r - 1]) {
+                f4v Rc[8];
+                request(d, sy1[r], Rc);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) Ua[j] = Ub[j];
+                hrow(Rc, Ub);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const f4v u = Ua[j] * b0[r] + Ub[j] * b1[r];      // column pass
+                const f2v m = u.xy * gxy[r][j];
+                // src/fastguidedfilter.cpp:204: mean_a_r.mul(I_r) + mean_a_g.mul(I_g) + mean_a_b.mul(I_b) + mean_b
+                o[r][j] = __fadd_rn(__fadd_rn(__fadd_rn(m.x, m.y), __fmul_rn(u.z, gz[r][j])), u.w);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < RB; ++r)
+            if (y0 + r >= 0 && y0 + r < H) *(f4v *)(vol + (size_t)d * HW + (size_t)(y0 + r) * W + x0) = o[r];
+    }
+}
+
 }  // namespace
 
 // FgfScratch: small planes of one side (allocated by the API layer)
@@ -220,23 +370,40 @@ void launch_fgf_setup(hipStream_t s, const float4 *g1, int W, int H, int sub, fl
     else hipLaunchKernelGGL(k_fgf_setup<9>, grid, dim3(256), 0, s, (const float4 *)ism, ws, hs, msm, v1, v2);
 }
 
-void launch_fgf_filter(hipStream_t s, float *vol, const float4 *g1, int W, int H, int Dloc, int sub, const float4 *ism,
-                       const float4 *msm, const float4 *v1, const float2 *v2, float4 *ab, float4 *mab)
+void launch_fgf_filter(hipStream_t s, float *vol, const float4 *g1, const float4 *g1_other, int W, int H, int Dloc, int d_begin,
+                       int sub, int cvc_mode, const float4 *msm, const float4 *v1, const float2 *v2, float4 *ab, float4 *mab)
 {
     const int ws = W / sub, hs = H / sub, k = 2 * (8 / sub) + 1;
-    dim3 gs((ws + 255) / 256, hs, Dloc);
-    if (k == 3) {
-        hipLaunchKernelGGL(k_fgf_model<3>, gs, dim3(256), 0, s, (const float *)vol, W, H, ws, hs, ism, msm, v1, v2, ab);
-        hipLaunchKernelGGL(k_fgf_smooth<3>, gs, dim3(256), 0, s, (const float4 *)ab, ws, hs, mab);
-    } else if (k == 5) {
-        hipLaunchKernelGGL(k_fgf_model<5>, gs, dim3(256), 0, s, (const float *)vol, W, H, ws, hs, ism, msm, v1, v2, ab);
-        hipLaunchKernelGGL(k_fgf_smooth<5>, gs, dim3(256), 0, s, (const float4 *)ab, ws, hs, mab);
+    const int nstrips = (ws + (64 - 2 * (k / 2)) - 1) / (64 - 2 * (k / 2));
+    // rows per marching segment: enough workgroups to fill the chip, at least 4 k rows each
+    int nsegs = (8192 + nstrips * Dloc - 1) / (nstrips * Dloc);
+    int seg = (hs + nsegs - 1) / nsegs;
+    if (seg < 4 * k) seg = 4 * k;
+    if (seg > hs) seg = hs;
+    nsegs = (hs + seg - 1) / seg;
+    dim3 gs(nstrips * nsegs, Dloc);
+#define PSM_FGF_MODEL(KK, MM) hipLaunchKernelGGL((k_fgf_model<KK, MM>), gs, dim3(64), 0, s, (const float *)vol, W, H, ws, hs, nstrips, seg, \
+                                                 g1, g1_other, d_begin, msm, v1, v2, ab)
+#define PSM_FGF_K(KK)                                                                                           \
+    do {                                                                                                        \
+        if (cvc_mode == 0) PSM_FGF_MODEL(KK, 0); else if (cvc_mode == 1) PSM_FGF_MODEL(KK, 1); else PSM_FGF_MODEL(KK, 2); \
+        hipLaunchKernelGGL(k_fgf_smooth<KK>, gs, dim3(64), 0, s, (const float4 *)ab, ws, hs, nstrips, seg, mab);  \
+    } while (0)
+    if (k == 3) PSM_FGF_K(3); else if (k == 5) PSM_FGF_K(5); else PSM_FGF_K(9);
+#undef PSM_FGF_K
+#undef PSM_FGF_MODEL
+    if (W % 4 == 0) {
+        const int dchunk = Dloc < 32 ? Dloc : 32;
+                const int rb = sub == 2 ? 2 : 4, yshift = (sub / 2) % rb;
+        dim3 gf((W / 4 + 255) / 256, (H + yshift + rb - 1) / rb, (Dloc + dchunk - 1) / dchunk);
+        if (rb == 2)
+            hipLaunchKernelGGL(k_fgf_apply4<2>, gf, dim3(256), 0, s, (const f4v *)mab, ws, hs, (const f4v *)g1, W, H, vol, Dloc, dchunk, yshift);
+        else
+            hipLaunchKernelGGL(k_fgf_apply4<4>, gf, dim3(256), 0, s, (const f4v *)mab, ws, hs, (const f4v *)g1, W, H, vol, Dloc, dchunk, yshift);
     } else {
-        hipLaunchKernelGGL(k_fgf_model<9>, gs, dim3(256), 0, s, (const float *)vol, W, H, ws, hs, ism, msm, v1, v2, ab);
-        hipLaunchKernelGGL(k_fgf_smooth<9>, gs, dim3(256), 0, s, (const float4 *)ab, ws, hs, mab);
+        dim3 gf((W + 255) / 256, H, Dloc);
+        hipLaunchKernelGGL(k_fgf_apply, gf, dim3(256), 0, s, (const float4 *)mab, ws, hs, g1, W, H, vol);
     }
-    dim3 gf((W + 255) / 256, H, Dloc);
-    hipLaunchKernelGGL(k_fgf_apply, gf, dim3(256), 0, s, (const float4 *)mab, ws, hs, g1, W, H, vol);
 }
 
 }  // namespace psm

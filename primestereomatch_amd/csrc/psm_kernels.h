@@ -60,9 +60,11 @@ void launch_fill_inv(hipStream_t s, uint8_t *dis, const uint8_t *valid, int W, i
 // ---- Fast Guided Filter variant (psm_fgf.hip); sub = subsample rate, small planes are (H/sub) x (W/sub) ----
 // g1 -> subsampled guidance ism, its means msm and the inverse covariance planes v1 = {irr,irg,irb,igg}, v2 = {igb,ibb}
 void launch_fgf_setup(hipStream_t s, const float4 *g1, int W, int H, int sub, float4 *ism, float4 *msm, float4 *v1, float2 *v2);
-// filters Dloc slices of vol in place; ab/mab: scratch, Dloc*(H/sub)*(W/sub) float4 each
-void launch_fgf_filter(hipStream_t s, float *vol, const float4 *g1, int W, int H, int Dloc, int sub, const float4 *ism,
-                       const float4 *msm, const float4 *v1, const float2 *v2, float4 *ab, float4 *mab);
+// filters Dloc slices of vol in place; ab/mab: scratch, Dloc*(H/sub)*(W/sub) float4 each.  cvc_mode 0: the cost
+// slices are read from vol; 1/2: the left/right costs of the sampled pixels are built from the g1 planes (vol is
+// only written)
+void launch_fgf_filter(hipStream_t s, float *vol, const float4 *g1, const float4 *g1_other, int W, int H, int Dloc, int d_begin,
+                       int sub, int cvc_mode, const float4 *msm, const float4 *v1, const float2 *v2, float4 *ab, float4 *mab);
 
 // ---- 8-bit char mode ----
 void launch_prep_u8(hipStream_t s, const uint8_t *src, size_t pitch, int W, int H, uint8_t *planes4);

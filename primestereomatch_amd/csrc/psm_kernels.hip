@@ -18,6 +18,7 @@
 // workgroup process different slices of the same pixels so the d-invariant guidance is served
 // from L1/L2.  MFMA is not used: nothing here is a dense contraction.
 #include "psm_kernels.h"
+#include "psm_cost.h"
 
 namespace psm {
 
@@ -337,21 +338,6 @@ void launch_guidance(hipStream_t s, Guidance g, double *hs9, int W, int H, int t
 // consecutive disparities; lanes run along x so every store is a coalesced row segment and the
 // partner-image reads of neighbouring lanes / iterations overlap in L1.
 // ------------------------------------------------------------------------------------------
-__device__ __forceinline__ float cost_pair(float4 a, float4 b)
-{  // myCostGrd(lC, rC, lG, rG), src/CVC.cpp:18-27
-    float clr = __fadd_rn(__fadd_rn(fabsf(__fsub_rn(a.x, b.x)), fabsf(__fsub_rn(a.y, b.y))), fabsf(__fsub_rn(a.z, b.z)));
-    float grd = fabsf(__fsub_rn(a.w, b.w));
-    return __fadd_rn(__fmul_rn(0.9f, clr), __fmul_rn(__fsub_rn(1.0f, 0.9f), grd));
-}
-__device__ __forceinline__ float cost_border(float4 a)
-{  // myCostGrd(lC, lG), src/CVC.cpp:30-39: BC_32F is the double 1.0 -> double differences/sum
-    double s = __dadd_rn(__dadd_rn(fabs(__dsub_rn((double)a.x, 1.0)), fabs(__dsub_rn((double)a.y, 1.0))),
-                         fabs(__dsub_rn((double)a.z, 1.0)));
-    float clr = (float)s;
-    float grd = (float)fabs(__dsub_rn((double)a.w, 1.0));
-    return __fadd_rn(__fmul_rn(0.9f, clr), __fmul_rn(__fsub_rn(1.0f, 0.9f), grd));
-}
-
 constexpr int CVC_DC = 8;
 template <bool RIGHT>
 __global__ __launch_bounds__(256) void k_cvc(const float4 *__restrict__ base, const float4 *__restrict__ other,
