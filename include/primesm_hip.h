@@ -55,7 +55,9 @@ enum {
                                    kernels; 16 = two-stage guided filter instead of the fused one; 32 =
                                    single-wave fused filter; 128 = psm_cost_construct always writes the cost
                                    volumes (default: they stay virtual and the fused filter builds the costs
-                                   on the fly; any other reader materialises them first) */
+                                   on the fly; any other reader materialises them first); 256 = two-pass
+                                   guidance kernels; 512 = two-columns-per-lane variant of the fused filter
+                                   (widths that are multiples of 4).  No flag changes any result. */
 };
 
 /* Number of usable HIP devices; 0 if none.  Replaces openCLdevicepoll()

@@ -51,6 +51,8 @@ struct psm_ctx {
     uint8_t *maps = nullptr;            // [2][H][W]
     uint8_t *valid = nullptr;           // [2][H][W]
     uint8_t *p4[2] = {nullptr, nullptr};  // PSM_U8 only: {c0,c1,c2,grad} words
+    float *soa[2] = {nullptr, nullptr};   // planar copies of g1..g4 (14 planes) for the two-columns-per-lane filter
+    int soa_state[2] = {0, 0};            // 0 nothing, 1 g1 planes, 2 all planes (of the current image pair)
     void *fgf = nullptr;                // psm_cost_filter_fgf scratch (small planes), fgf_bytes long
     size_t fgf_bytes = 0;
 
@@ -159,6 +161,7 @@ void free_all(psm_ctx *c)
         (void)hipFree(c->g[s].g4);
         (void)hipFree(c->vol[s]);
         (void)hipFree(c->p4[s]);
+        (void)hipFree(c->soa[s]);
     }
     (void)hipFree(c->hs9);
     (void)hipFree(c->fvol);
@@ -188,6 +191,7 @@ int run_prep(psm_ctx *c)
         if (c->dtype == PSM_U8) launch_prep_u8(c->stream, (const uint8_t *)c->raw[s], row, c->W, c->H, c->p4[s]);
     }
     if (check_launch(c, "prep")) return 1;
+    c->soa_state[0] = c->soa_state[1] = 0;
     c->have_g1 = true;
     return 0;
 }
@@ -200,6 +204,16 @@ int ensure_ab(psm_ctx *c)
     const size_t V = (size_t)c->W * c->H * c->Dloc;
     PSM_HIP(c, hipMalloc((void **)&c->ab, V * sizeof(float4)));
     return 0;
+}
+
+// planar guidance of `side` for k_cvf_pc2: level 1 = g1 planes, 2 = all 14 planes (needs launch_guidance(side) done)
+int ensure_soa(psm_ctx *c, int side, int level)
+{
+    if (!c->soa[side]) PSM_HIP(c, hipMalloc((void **)&c->soa[side], (size_t)14 * c->W * c->H * sizeof(float)));
+    if (c->soa_state[side] >= level) return 0;
+    launch_soa(c->stream, c->g[side], c->W, c->H, c->soa[side], level == 1);
+    c->soa_state[side] = level;
+    return check_launch(c, "soa");
 }
 
 // second float volume for the fused filter when it has to READ a materialised cost volume (out of place)
@@ -439,6 +453,32 @@ static int filter_side(psm_ctx *c, int side, bool stage_b)
     }
     const bool fused = stage_b && c->dtype == PSM_F32 && c->opt_variant == 0 && !(c->march.flags & 16) && H >= 8;
     if (!fused && materialize(c, side)) return 1;
+    // flag 512: the two-columns-per-lane form of the producer/consumer kernel (k_cvf_pc2: 31 % fewer VALU
+    // instructions per voxel but only two waves per SIMD; measured slower, kept as a tested variant - DESIGN.md 4.2)
+    const bool pc2 = fused && (c->march.flags & 512) && !(c->march.flags & 32) && (W & 3) == 0 && W >= 8;
+    if (pc2) {
+        {
+            Prof p(c, PSM_K_GUIDE);
+            if (ensure_soa(c, side, 2) || ensure_soa(c, 1 - side, 1)) return 1;
+        }
+        const bool lazy = c->raw_rows[side] != psm_ctx::RAW_ALL;
+        float *out = fv;
+        if (!lazy) {
+            if (ensure_spare(c)) return 1;
+            out = c->spare;
+        }
+        {
+            Prof p(c, PSM_K_CVF_F);
+            launch_cvf_pc2(c->stream, lazy ? nullptr : fv, out, c->soa[side], c->soa[1 - side], W, H, c->Dloc, 0, H, c->d0,
+                           lazy ? 1 + side : 0, c->march.seg_rows);
+        }
+        if (!lazy) {
+            c->spare = fv;          // ping-pong: the filtered volume becomes vol[side]
+            c->vol[side] = out;
+        }
+        c->raw_rows[side] = psm_ctx::RAW_ALL;   // vol[side] now holds real (filtered) data
+        return check_launch(c, "cvf (fused, two columns per lane)");
+    }
     if (fused) {
         if (!(c->march.flags & 32) && c->raw_rows[side] != psm_ctx::RAW_ALL) {
             // producer/consumer kernel on a virtual cost volume: nothing is read from vol[side], so the

@@ -42,6 +42,11 @@ void launch_cvf_b(hipStream_t s, int variant, March m, const float4 *ab, float *
 // cvc_mode 0: read the cost slices from vin; 1/2: build the left/right costs on the fly from the g1 planes
 void launch_cvf_fused(hipStream_t s, March m, const float *vin, float *vout, Guidance g, int W, int H, int Dloc,
                       int ybeg, int yend, const float4 *g1_other, int d_begin, int cvc_mode);
+// two-columns-per-lane form of the fused filter (psm_pc2.hip); reads planar copies of the guidance (launch_soa:
+// 14 planes of H*W floats per side; only_g1: planes 0..3 only).  Needs W % 4 == 0.
+void launch_soa(hipStream_t s, Guidance g, int W, int H, float *soa, int only_g1);
+void launch_cvf_pc2(hipStream_t s, const float *vin, float *vout, const float *soa, const float *soa_other, int W, int H, int Dloc,
+                    int ybeg, int yend, int d_begin, int cvc_mode, int seg_rows);
 // plain 8x8 box filter of every slice (the north-star kernel in isolation)
 void launch_box8(hipStream_t s, int variant, March m, const float *vol, float *out, int W, int H, int Dloc);
 // WTA over local slices -> packed keys (keys != NULL) and/or final map (map != NULL)

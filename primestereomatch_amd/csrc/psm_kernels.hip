@@ -19,118 +19,9 @@
 // from L1/L2.  MFMA is not used: nothing here is a dense contraction.
 #include "psm_kernels.h"
 #include "psm_cost.h"
+#include "psm_dev.h"
 
 namespace psm {
-
-// ------------------------------------------------------------------------------------------
-// small device helpers
-// ------------------------------------------------------------------------------------------
-__device__ __forceinline__ int r101(int k, int n)
-{
-    k = k < 0 ? -k : k;
-    k = k >= n ? 2 * (n - 1) - k : k;
-    return k;
-}
-__device__ __forceinline__ int r101c(int k, int n)
-{  // reflect, then clamp (only matters for the unused overshoot rows/lanes)
-    k = r101(k, n);
-    return k < 0 ? 0 : (k > n - 1 ? n - 1 : k);
-}
-
-__device__ __forceinline__ double t8(double t0, double t1, double t2, double t3, double t4, double t5,
-                                     double t6, double t7)
-{
-    return __dadd_rn(__dadd_rn(__dadd_rn(t0, t1), __dadd_rn(t2, t3)),
-                     __dadd_rn(__dadd_rn(t4, t5), __dadd_rn(t6, t7)));
-}
-__device__ __forceinline__ float box_out(double s) { return (float)(s * 0.015625); }
-
-// gray of CVC::preprocess: cvtColor(CV_RGB2GRAY) on B,G,R data -> 0.299 multiplies c0
-__device__ __forceinline__ float gray_of(float c0, float c1, float c2)
-{
-    return __fadd_rn(__fadd_rn(__fmul_rn(c0, 0.299f), __fmul_rn(c1, 0.587f)), __fmul_rn(c2, 0.114f));
-}
-
-// cross-lane gather: lane l receives the value of lane (byte_idx/4)
-__device__ __forceinline__ float lane_get(float v, int byte_idx)
-{
-    return __int_as_float(__builtin_amdgcn_ds_bpermute(byte_idx, __float_as_int(v)));
-}
-__device__ __forceinline__ double lane_get(double v, int byte_idx)
-{
-    int lo = __builtin_amdgcn_ds_bpermute(byte_idx, __double2loint(v));
-    int hi = __builtin_amdgcn_ds_bpermute(byte_idx, __double2hiint(v));
-    return __hiloint2double(hi, lo);
-}
-
-// One-lane rotation of the whole wave in the VALU (DPP wave_rol:1: lane l <- lane l+1, lane 63 <-
-// lane 0; verified on gfx950).  No LDS round trip, unlike ds_bpermute.
-// bound_ctrl=1: every lane has a source under wave_rol, and it spares the compiler a v_mov to seed `old`
-__device__ __forceinline__ int rol1(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x134, 0xf, 0xf, true); }
-__device__ __forceinline__ float rol1(float v) { return __int_as_float(rol1(__float_as_int(v))); }
-__device__ __forceinline__ double rol2(double v)
-{
-    int lo = rol1(rol1(__double2loint(v))), hi = rol1(rol1(__double2hiint(v)));
-    return __hiloint2double(hi, lo);
-}
-__device__ __forceinline__ double rol4(double v)
-{
-    int lo = rol1(rol1(rol1(rol1(__double2loint(v))))), hi = rol1(rol1(rol1(rol1(__double2hiint(v)))));
-    return __hiloint2double(hi, lo);
-}
-
-// Horizontal 8-tap window sum over lanes l..l+7 (sliding balanced tree).
-// PSM_XLANE_MODE: which exchange levels use DPP rotations instead of ds_bpermute
-//   0: none, 1: distance 1, 2: distances 1 and 2, 3: all (1, 2, 4)
-#ifndef PSM_XLANE_MODE
-#define PSM_XLANE_MODE 2   // measured on the fused filter at 1080p x 256: mode 0 5.29 ms, 1 4.76, 2 4.69, 3 5.98
-#endif
-__device__ __forceinline__ double hsum8(float v, int i1, int i2, int i4)
-{
-    double s2 = __dadd_rn((double)v, (double)(PSM_XLANE_MODE >= 1 ? rol1(v) : lane_get(v, i1)));
-    double s4 = __dadd_rn(s2, PSM_XLANE_MODE >= 2 ? rol2(s2) : lane_get(s2, i2));
-    return __dadd_rn(s4, PSM_XLANE_MODE >= 3 ? rol4(s4) : lane_get(s4, i4));
-}
-
-// Vertical 8-tap sliding tree.  After feeding row yy, returns the window sum of rows yy-7..yy.
-struct VTree {
-    double hp;
-    double s2[2];
-    double s4[4];
-};
-template <int K>
-__device__ __forceinline__ double vstep(VTree &t, double hs)
-{
-    double n2 = __dadd_rn(t.hp, hs);         // hs[yy-1] + hs[yy]
-    double n4 = __dadd_rn(t.s2[K & 1], n2);  // s2[yy-3] + s2[yy-1]
-    double n8 = __dadd_rn(t.s4[K & 3], n4);  // s4[yy-7] + s4[yy-3]
-    t.s2[K & 1] = n2;
-    t.s4[K & 3] = n4;
-    t.hp = hs;
-    return n8;
-}
-
-// The per-voxel linear-model solve of GuidedFilter_cv (src/CVF.cpp:91-155) with the d-invariant
-// adjugate entries and 1/DET taken from the guidance planes.
-__device__ __forceinline__ float4 solve_ab(float mp, float mIp0, float mIp1, float mIp2, float4 g2,
-                                           float4 g3, float2 g4)
-{
-    const float mI0 = g2.x, mI1 = g2.y, mI2 = g2.z, inv = g2.w;
-    const float A00 = g3.x, A01 = g3.y, A02 = g3.z, A11 = g3.w, A12 = g4.x, A22 = g4.y;
-    float c0 = __fsub_rn(mIp0, __fmul_rn(mI0, mp));
-    float c1 = __fsub_rn(mIp1, __fmul_rn(mI1, mp));
-    float c2 = __fsub_rn(mIp2, __fmul_rn(mI2, mp));
-    float a0 = __fmul_rn(inv, __fadd_rn(__fadd_rn(__fmul_rn(c0, A00), __fmul_rn(c1, A01)), __fmul_rn(c2, A02)));
-    float a1 = __fmul_rn(inv, __fadd_rn(__fadd_rn(__fmul_rn(c0, A01), __fmul_rn(c1, A11)), __fmul_rn(c2, A12)));
-    float a2 = __fmul_rn(inv, __fadd_rn(__fadd_rn(__fmul_rn(c0, A02), __fmul_rn(c1, A12)), __fmul_rn(c2, A22)));
-    float b = __fsub_rn(__fsub_rn(__fsub_rn(mp, __fmul_rn(a0, mI0)), __fmul_rn(a1, mI1)), __fmul_rn(a2, mI2));
-    return make_float4(a0, a1, a2, b);
-}
-// q = ((box(b) + box(a0)*I0) + box(a1)*I1) + box(a2)*I2   (src/CVF.cpp:157-163)
-__device__ __forceinline__ float recombine(float ma0, float ma1, float ma2, float mb, float4 g1)
-{
-    return __fadd_rn(__fadd_rn(__fadd_rn(mb, __fmul_rn(ma0, g1.x)), __fmul_rn(ma1, g1.y)), __fmul_rn(ma2, g1.z));
-}
 
 // ------------------------------------------------------------------------------------------
 // image preparation: planarise + scale + gray + x-gradient  -> g1 = {I0,I1,I2,GrdX}
@@ -864,6 +755,9 @@ constexpr int PC_RING = 4;   // batches of four model rows kept in LDS
 #ifndef PSM_PC_LAYOUT
 #define PSM_PC_LAYOUT 0
 #endif
+#ifndef PSM_PC_NT
+#define PSM_PC_NT 1        // 1: nontemporal stores of the output rows (the filtered volume is next read by the WTA pass, long after it left the L2)
+#endif
 #if PSM_PC_LAYOUT == 0      // 2 A + 2 B waves, 52 / 48 columns: 96 outputs = 3 full lines per workgroup
 constexpr int PC_NA = 2, PC_NB = 2, PC_OUT_A = 52, PC_OUT_B = 48, PC_COLS = 96;
 #elif PSM_PC_LAYOUT == 1    // 3 A + 3 B waves, 57 / 54,54,52 columns: 160 outputs = 5 full lines
@@ -882,6 +776,27 @@ static_assert(PC_MCOLS >= PC_COLS + 7 && (PC_COLS % 4) == 0 && PC_OUT_A <= 57 &&
 // is never materialised - the producer waves evaluate myCostGrd (src/CVC.cpp:18-39) for their input
 // column on the fly from the two g1 planes (`G1` = this side's image, `Gother` = the other one), exactly
 // as k_cvc does; saves the 4 B/voxel write of CostConst and the 4 B/voxel read here.
+typedef unsigned pc_u2 __attribute__((ext_vector_type(2)));
+typedef unsigned pc_u4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t pc_rsrc(const void *p, unsigned bytes)
+{
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p), 0, bytes, 0x00020000);
+}
+__device__ __forceinline__ float pc_load1(__amdgpu_buffer_rsrc_t r, int voff, int soff)
+{
+    return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
+}
+__device__ __forceinline__ float2 pc_load2(__amdgpu_buffer_rsrc_t r, int voff, int soff)
+{
+    const pc_u2 v = __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0);
+    return make_float2(__uint_as_float(v.x), __uint_as_float(v.y));
+}
+__device__ __forceinline__ float4 pc_load4(__amdgpu_buffer_rsrc_t r, int voff, int soff)
+{
+    const pc_u4 v = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
+    return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+}
+
 template <bool VEC4, int CVC>
 __global__ __launch_bounds__(64 * (PC_NA + PC_NB)) PSM_PC_ATTR void k_cvf_pc(const float *__restrict__ vin, float *__restrict__ vout,
                                                const float4 *__restrict__ G1, const float4 *__restrict__ G2,
@@ -906,7 +821,16 @@ __global__ __launch_bounds__(64 * (PC_NA + PC_NB)) PSM_PC_ATTR void k_cvf_pc(con
     const int pair = xcd * ppx + pl;
     if (pl >= ppx || pair >= npairs) return;
     const int g = pair % ngroups, seg = pair / ngroups;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int lane = threadIdx.x & 63;
+#ifndef PSM_PC_ROLEMAP
+#define PSM_PC_ROLEMAP 0
+#endif
+    // hardware wave -> logical wave (role and column block).  Experiments on SIMD balance between the heavier
+    // producer and the lighter consumer role: 1 swaps the roles in pseudo-randomly chosen workgroups,
+    // 2 interleaves A,B,A,B, 3 both.
+    int wave = threadIdx.x >> 6;
+    if (PSM_PC_ROLEMAP & 2) wave = ((wave & 1) << 1) | (wave >> 1);
+    if (PSM_PC_ROLEMAP & 1) wave = (wave + ((((unsigned)jj * 2654435761u) >> 15) & 2)) & 3;
     const bool is_a = wave < PC_NA;
     const int xg = g * PC_COLS;                       // first output column of the workgroup
     const int xm0 = xg - 4;                           // first model column of the workgroup
@@ -942,18 +866,30 @@ __global__ __launch_bounds__(64 * (PC_NA + PC_NB)) PSM_PC_ATTR void k_cvf_pc(con
         float pin[2];
         float4 oth[2], gin[2], o2[2], o3[2];
         float2 o4[2];
+        // raw buffer loads: descriptors and row offsets in scalar registers, one constant 32-bit byte offset per lane
+        const __amdgpu_buffer_rsrc_t rG1 = pc_rsrc(G1, (unsigned)HW * 16u), rG2 = pc_rsrc(G2, (unsigned)HW * 16u);
+        const __amdgpu_buffer_rsrc_t rG3 = pc_rsrc(G3, (unsigned)HW * 16u), rG4 = pc_rsrc(G4, (unsigned)HW * 8u);
+        const __amdgpu_buffer_rsrc_t rGo = pc_rsrc(CVC == 0 ? G1 : Gother, (unsigned)HW * 16u);
+        const __amdgpu_buffer_rsrc_t rV = pc_rsrc(CVC == 0 ? (const void *)vd : (const void *)G1, (unsigned)HW * 4u);
+#if PSM_PC_ABL & 16   // experiment: every lane reads column 0 (same instruction count, minimal data movement; invalid results)
+        const int vci = 0, vcp = 0, vxa = 0;
+#elif PSM_PC_ABL & 32 // experiment: rows collapse to row 0 as well
+        const int vci = ci * 16, vcp = cpart * 16, vxa = xac * 16;
+#else
+        const int vci = ci * 16, vcp = cpart * 16, vxa = xac * 16;
+#endif
 #define PSM_ISSUE_PA(SLOT, STEP)                                                        \
     {                                                                                   \
-        const size_t off_ = (size_t)r101c(mstart - 5 + (STEP), H) * W + ci;             \
+        const int row_ = (PSM_PC_ABL & 32) ? 0 : r101c(mstart - 5 + (STEP), H) * W;     \
         int ya_ = mstart - 8 + (STEP);                                                  \
         ya_ = ya_ < 0 ? 0 : (ya_ > H - 1 ? H - 1 : ya_);                                \
-        const size_t oa_ = (size_t)ya_ * W + xac;                                       \
-        if (CVC == 0) pin[SLOT] = vd[off_];                                             \
-        else oth[SLOT] = Gother[off_ - ci + cpart];                                     \
-        gin[SLOT] = G1[off_];                                                           \
-        o2[SLOT] = G2[oa_];                                                             \
-        o3[SLOT] = G3[oa_];                                                             \
-        o4[SLOT] = G4[oa_];                                                             \
+        const int oa_ = (PSM_PC_ABL & 32) ? 0 : ya_ * W;                                \
+        if (CVC == 0) pin[SLOT] = pc_load1(rV, vci >> 2, row_ * 4);                     \
+        else oth[SLOT] = pc_load4(rGo, vcp, row_ * 16);                                 \
+        gin[SLOT] = pc_load4(rG1, vci, row_ * 16);                                      \
+        o2[SLOT] = pc_load4(rG2, vxa, oa_ * 16);                                        \
+        o3[SLOT] = pc_load4(rG3, vxa, oa_ * 16);                                        \
+        o4[SLOT] = pc_load2(rG4, vxa >> 1, oa_ * 8);                                    \
     }
         // one step: consume the loads of step S (slot K&1), issue those of step S+1
 #define PSM_STEP_PA(K, S, DST)                                                                      \
@@ -963,7 +899,11 @@ __global__ __launch_bounds__(64 * (PC_NA + PC_NB)) PSM_PC_ATTR void k_cvf_pc(con
         if (CVC == 0) p = pin[K & 1];                                                               \
         else {                                                                                      \
             p = cost_pair(gin[K & 1], oth[K & 1]);                                                  \
-            if (any_border) { const float cb_ = cost_border(gin[K & 1]); p = inb ? p : cb_; }       \
+            if (any_border) {   /* only where x < d (left) / x >= W-d (right) occurs in this wave */   \
+                asm volatile("; border cost");   /* keeps this a real branch */                     \
+                const float cb_ = cost_border(gin[K & 1]);                                          \
+                p = inb ? p : cb_;                                                                  \
+            }                                                                                       \
         }                                                                                           \
         double h0 = hsum8(p, i1, i2, i4);                                                           \
         double h1 = hsum8(__fmul_rn(gin[K & 1].x, p), i1, i2, i4);                                  \
@@ -1008,11 +948,13 @@ __global__ __launch_bounds__(64 * (PC_NA + PC_NB)) PSM_PC_ATTR void k_cvf_pc(con
         const int amax = 4 * nbA - 1;
         VTree t0 = {}, t1 = {}, t2 = {}, t3 = {};
         float o1x[4], o1y[4], o1z[4];                 // g1.xyz at (output row, output column), one batch ahead
+        const __amdgpu_buffer_rsrc_t rG1 = pc_rsrc(G1, (unsigned)HW * 16u);
+        const int vxb = xbc * 16;
 #define PSM_ISSUE_PB(SLOT, J)                                                           \
     {                                                                                   \
         int yb_ = y0 + (J) - 7;                                                         \
         yb_ = yb_ < 0 ? 0 : (yb_ > H - 1 ? H - 1 : yb_);                                \
-        const float4 g_ = G1[(size_t)yb_ * W + xbc];                                    \
+        const float4 g_ = pc_load4(rG1, vxb, yb_ * W * 16);                             \
         o1x[SLOT] = g_.x; o1y[SLOT] = g_.y; o1z[SLOT] = g_.z;                           \
     }
         // ring address of the model row that feed J consumes (wave-uniform arithmetic)
@@ -1032,8 +974,13 @@ __global__ __launch_bounds__(64 * (PC_NA + PC_NB)) PSM_PC_ATTR void k_cvf_pc(con
                     const float *src = &qbuf[c & 1][k][0];
                     if (VEC4) {
                         const int cc = lane * 4;
-                        if (lane < PC_COLS / 4 && xg + cc < W)
+                        if (lane < PC_COLS / 4 && xg + cc < W) {
+#if PSM_PC_NT
+                            __builtin_nontemporal_store(*reinterpret_cast<const f4v *>(src + cc), reinterpret_cast<f4v *>(row + cc));
+#else
                             *reinterpret_cast<float4 *>(row + cc) = *reinterpret_cast<const float4 *>(src + cc);
+#endif
+                        }
                     } else {
 #pragma unroll
                         for (int cc = lane; cc < PC_COLS; cc += 64)

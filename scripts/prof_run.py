@@ -17,9 +17,12 @@ if len(sys.argv) > 2:
     de.set_option(capi.PSM_OPT_SEG_ROWS, int(sys.argv[2]))
 if len(sys.argv) > 3:
     de.set_option(capi.PSM_OPT_WAVES, int(sys.argv[3]))
+if os.environ.get("PSM_FLAGS"):
+    de.set_option(capi.PSM_OPT_FLAGS, int(os.environ["PSM_FLAGS"]))
 for _ in range(2):
     de.CostConst_GPU()
-    de.box8_volume(0, download=False)
+    if not os.environ.get("PSM_FLAGS"):
+        de.box8_volume(0, download=False)
     de.CostFilter_GPU()
     de.DispSelect_device()
 de.synchronize()
