@@ -61,6 +61,9 @@ def main():
     ap.add_argument("--no-overlap", action="store_true",
                     help="N>1: exchange both sides after both filters instead of overlapping the left exchange "
                          "with the right filter")
+    ap.add_argument("--no-frame-pipeline", action="store_true",
+                    help="N>1: finish the exchange + merge of a frame inside its own step instead of one step later "
+                         "(default: the right side's exchange overlaps the next frame's left filter; two key buffers)")
     ap.add_argument("--shard-sim", type=int, default=0,
                     help="diagnostic: time only rank 0's disparity shard of a G-rank job on this GPU (no exchange); "
                          "the JSON line is then NOT the headline metric")
@@ -108,9 +111,13 @@ def main():
     de.set_option(capi.PSM_OPT_ASYNC, 1)
 
     keys_local = keys_all = None
+    kbuf = []
+    pending = []                 # (work handles, key buffer) of the frame whose merge is still outstanding
+    frame = [0]
     if use_dist:
         HW2 = 2 * H * W
-        keys_local = torch.empty(HW2, dtype=torch.int64, device="cuda")
+        kbuf = [torch.empty(HW2, dtype=torch.int64, device="cuda") for _ in range(2)]
+        keys_local = kbuf[0]
         keys_all = torch.empty(world * HW2 if args.exchange == "allgather" else 1, dtype=torch.int64, device="cuda")
         # one non-default torch stream carries both our kernels and the RCCL collective, so the
         # exchange is ordered against the kernels without host synchronisation
@@ -121,11 +128,37 @@ def main():
     if args.fgf:
         de.setSubsampleRate(args.fgf)
 
+    pipelined = use_dist and args.exchange == "allreduce" and not args.no_overlap and not args.no_frame_pipeline and not args.fgf
+
+    def finish_pending():
+        # exchange of an earlier frame -> final maps (the collectives ran on RCCL's stream meanwhile)
+        while pending:
+            works, kb = pending.pop(0)
+            for w_ in works:
+                w_.wait()
+            de.DispSelect_merge(kb.data_ptr(), 1, download=False)
+
     def step():
         de.CostConst_GPU()
         if args.fgf:
             de.CostFilter_FGF_GPU()
             de.DispSelect_device()
+            return
+        if pipelined:
+            # Frame pipeline: both exchanges are asynchronous; the merge of frame i is issued during frame i+1,
+            # after that frame's left filter, so no kernel of ours ever waits for a collective that has not had a
+            # whole filter pass to complete.  Keys alternate between two buffers.
+            HWk = H * W
+            kb = kbuf[frame[0] & 1]
+            frame[0] += 1
+            de.CostFilter_side(0)
+            de.DispSelect_partial_side(0, kb.data_ptr())
+            wl = dist.all_reduce(kb[:HWk], op=dist.ReduceOp.MIN, async_op=True)
+            finish_pending()
+            de.CostFilter_side(1)
+            de.DispSelect_partial_side(1, kb.data_ptr() + 8 * HWk)
+            wr = dist.all_reduce(kb[HWk:], op=dist.ReduceOp.MIN, async_op=True)
+            pending.append(((wl, wr), kb))
             return
         if use_dist and args.exchange == "allreduce" and not args.no_overlap:
             # left volume: filter, local minima, start its exchange (RCCL runs on the process group's own
@@ -157,6 +190,7 @@ def main():
             de.DispSelect_device()
 
     def sync():
+        finish_pending()
         if use_dist:
             torch.cuda.synchronize()
         de.synchronize()

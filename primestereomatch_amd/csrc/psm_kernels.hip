@@ -735,22 +735,23 @@ __global__ __launch_bounds__(256) void k_cvf_fused(const float *__restrict__ vin
 // The single-wave fusion above needs both sliding trees in one wave (250 VGPRs, 1-2 waves per SIMD)
 // and is latency bound.  Here the two halves run in DIFFERENT waves of one workgroup and the linear
 // models (a0,a1,a2,b) are handed over through LDS instead of HBM:
-//   waves 0-2 ("A"): p, g1 -> window sums -> solve -> model rows into an LDS ring (57 columns each)
-//   waves 3-5 ("B"): model rows from LDS (mirror-indexed at the image border) -> window sums -> q
-// One barrier per batch of four rows; B runs one batch behind A, the merged 16-byte-lane store of q
-// one batch behind B.  Each wave carries one tree (~150 VGPRs, 3 waves per SIMD).  Output rows 4..H-4
-// only (see k_cvf_fused).  The kernel is VALU bound (95 % VALU busy measured), so the widths are
-// chosen for lane efficiency, not for line alignment: 3 x 57 = 171 model columns feed 164 output
-// columns (B waves 55 + 55 + 54; 164 is a multiple of 4 so the merged rows are float4-aligned).
+//   producer waves ("A"): cost p (read, or built from the g1 planes), g1 -> window sums -> solve -> model rows
+//                         into an LDS ring of PC_RING batches of four rows
+//   consumer waves ("B"): model rows from the ring (REFLECT_101 of the model planes = ring index arithmetic,
+//                         columns and rows, so the image border needs no separate kernel) -> window sums -> q
+// One barrier per batch of four rows; B runs two batches behind A, the merged 16-byte-per-lane store of q one
+// batch behind B.  Each wave carries one set of trees (~146 VGPRs, 3 waves per SIMD, 3 workgroups per CU).
+// Default layout: 2 A waves x 52 model columns feed 2 B waves x 48 output columns = 96 outputs = three whole
+// 128-byte lines per row and workgroup (wider, unaligned layouts issue fewer instructions per voxel but write
+// slower).  The kernel is VALU-issue bound: 2.1e9 wave-instructions per 1080p x 256 launch at ~90 % of the
+// SIMDs' issue slots (rocprofv3 SQ_INSTS_VALU / GRBM_GUI_ACTIVE, profiles/); all of v_add_f64, v_cvt, v_ldexp_f64,
+// DPP moves and fp32 ops issue at the same rate (scripts/exp/rate.hip), ds_bpermute costs ~5 of them.
 #ifndef PSM_PC_ATTR
 #define PSM_PC_ATTR
 #endif
-#ifndef PSM_PC_P
-#define PSM_PC_P 1          // (measured: 1 -> 4.14 ms, 3 -> 4.37 ms at 1080p x 256)  load look-ahead of the producer waves in steps: 3 (4-slot ring) or 1 (2 slots)
-#endif
 constexpr int PC_RING = 4;   // batches of four model rows kept in LDS
 #ifndef PSM_PC_ABL
-#define PSM_PC_ABL 0   // experiments: 1 no global loads in A, 2 no B compute, 4 no A compute, 8 no barriers-between (invalid results)
+#define PSM_PC_ABL 0   // ablation experiments (invalid results): 16 every lane loads column 0, 32 every step loads row 0
 #endif
 #ifndef PSM_PC_LAYOUT
 #define PSM_PC_LAYOUT 0
@@ -821,16 +822,9 @@ __global__ __launch_bounds__(64 * (PC_NA + PC_NB)) PSM_PC_ATTR void k_cvf_pc(con
     const int pair = xcd * ppx + pl;
     if (pl >= ppx || pair >= npairs) return;
     const int g = pair % ngroups, seg = pair / ngroups;
-    const int lane = threadIdx.x & 63;
-#ifndef PSM_PC_ROLEMAP
-#define PSM_PC_ROLEMAP 0
-#endif
-    // hardware wave -> logical wave (role and column block).  Experiments on SIMD balance between the heavier
-    // producer and the lighter consumer role: 1 swaps the roles in pseudo-randomly chosen workgroups,
-    // 2 interleaves A,B,A,B, 3 both.
-    int wave = threadIdx.x >> 6;
-    if (PSM_PC_ROLEMAP & 2) wave = ((wave & 1) << 1) | (wave >> 1);
-    if (PSM_PC_ROLEMAP & 1) wave = (wave + ((((unsigned)jj * 2654435761u) >> 15) & 2)) & 3;
+    // (which hardware wave takes which role does not matter: swapping / interleaving the producer and consumer
+    // waves, per workgroup or pseudo-randomly, changed nothing - the CU balances the SIMDs itself)
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const bool is_a = wave < PC_NA;
     const int xg = g * PC_COLS;                       // first output column of the workgroup
     const int xm0 = xg - 4;                           // first model column of the workgroup
@@ -848,9 +842,6 @@ __global__ __launch_bounds__(64 * (PC_NA + PC_NB)) PSM_PC_ATTR void k_cvf_pc(con
     if (is_a) {
         // ---------------- producer: stage A ----------------
         // step s reads input row mstart-5+s; from step 8 on it yields model row mstart+(s-8)
-#ifdef PSM_PC_PRIO
-        __builtin_amdgcn_s_setprio(PSM_PC_PRIO);      // the producers are the barrier-critical role
-#endif
         const int xa0 = xm0 + wave * PC_OUT_A;        // first model column of this wave
         const int ci = r101c(xa0 - 4 + lane, W);      // input column of this lane
         const int xa = xa0 + lane;                    // model column of this lane
@@ -933,9 +924,6 @@ __global__ __launch_bounds__(64 * (PC_NA + PC_NB)) PSM_PC_ATTR void k_cvf_pc(con
     } else {
         // ---------------- consumer: stage B ----------------
         // feed j (j = 0 .. nf-1) is model row r101(y0-4+j); from feed 7 on the tree yields output row y0+j-7
-#ifdef PSM_PC_PRIO_B
-        __builtin_amdgcn_s_setprio(PSM_PC_PRIO_B);
-#endif
         const int wb = wave - PC_NA;
         const int bwidth = wb < PC_NB - 1 ? PC_OUT_B : PC_COLS - (PC_NB - 1) * PC_OUT_B;
         const int xb0 = xg + wb * PC_OUT_B;           // first output column of this wave
@@ -1235,17 +1223,19 @@ void launch_cvf_fused(hipStream_t s, March m, const float *vin, float *vout, Gui
     const int rows = yend - ybeg;
     int seg_rows = m.seg_rows;
     if (seg_rows <= 0) {
-        // 14 halo rows per segment: long segments are cheaper (~360 rows measured best at D=256), but a
-        // disparity shard with few slices needs more segments to keep >= ~4000 workgroups in the launch
-        const int per_seg = ((W + PC_COLS - 1) / PC_COLS) * Dloc;
-        int k = (rows + 399) / 400;
-        const int kmin = (4096 + per_seg - 1) / per_seg, kmax = rows / 64 > 1 ? rows / 64 : 1;
-        if (k < kmin) k = kmin;
-        if (k > kmax) k = kmax;
-        if (!(m.flags & 32)) {   // balanced XCD ownership: (groups x segments) a multiple of 8 if a nearby k allows it
-            const int ng = (W + PC_COLS - 1) / PC_COLS;
-            for (int kk = k; kk <= k + 3 && kk <= kmax; ++kk)
-                if ((ng * kk) % 8 == 0) { k = kk; break; }
+        // Segment count k: every segment re-walks 14 halo rows, and the launch runs in rounds of resident
+        // workgroups - per XCD ceil(pairs/8) (column group, segment) pairs x Dloc slices over 32 CUs x 3 workgroups.
+        // Pick the k with the smallest (rounds x rows walked per workgroup); matters most for a disparity shard with
+        // few slices, where a poor k leaves a round mostly empty (Dloc = 32 at 1080p: k = 6 instead of 8, -7 %).
+        const int ng = (W + PC_COLS - 1) / PC_COLS;
+        const int kmax = rows / 64 > 1 ? rows / 64 : 1;
+        long best = -1;
+        int k = 1;
+        for (int kk = 1; kk <= kmax && kk <= 32; ++kk) {
+            const long per_xcd = (long)((ng * kk + 7) / 8) * Dloc;
+            const long rounds = (per_xcd + 95) / 96;
+            const long cost = rounds * ((rows + kk - 1) / kk + 14);
+            if (best < 0 || cost < best) { best = cost; k = kk; }
         }
         seg_rows = (rows + k - 1) / k;
     }
