@@ -64,6 +64,8 @@ def main():
     ap.add_argument("--no-frame-pipeline", action="store_true",
                     help="N>1: finish the exchange + merge of a frame inside its own step instead of one step later "
                          "(default: the right side's exchange overlaps the next frame's left filter; two key buffers)")
+    ap.add_argument("--verify", action="store_true",
+                    help="N=1: also compare the maps of the timed path with a fresh single-context run (always done for N>1)")
     ap.add_argument("--shard-sim", type=int, default=0,
                     help="diagnostic: time only rank 0's disparity shard of a G-rank job on this GPU (no exchange); "
                          "the JSON line is then NOT the headline metric")
@@ -256,6 +258,23 @@ def main():
             v["alg_GBs"] = round(ALG_BYTES[nm] * vox_per_launch / (v["avg_ms"] * 1e-3) / 1e9, 1)
         v["avg_ms"] = round(v["avg_ms"], 4)
 
+    # ---- result check (outside the timed region): the maps the timed path left on the device ------------------
+    # against an unsharded single-context run of the same pair on this GPU.  With N > 1 this covers the RCCL
+    # exchange itself: rank 0's merged maps must equal the one-GPU maps bit for bit.
+    verified = None
+    if rank == 0 and args.shard_sim <= 1 and (use_dist or args.verify):
+        got_l, got_r = (m.copy() for m in de.download_maps())
+        de.set_option(capi.PSM_OPT_ASYNC, 0)
+        with P.DispEst(l, r, D, 8, True, device=local_rank) as ref:
+            if args.fgf:
+                ref.setSubsampleRate(args.fgf)
+            ref.CostConst_GPU()
+            ref.CostFilter_FGF_GPU() if args.fgf else ref.CostFilter_GPU()
+            ref.DispSelect_GPU()
+            verified = bool(np.array_equal(ref.lDisMap, got_l) and np.array_equal(ref.rDisMap, got_r))
+        if not verified:
+            print("bench.py: MAPS OF THE TIMED PATH DIFFER FROM THE ONE-GPU RUN", file=sys.stderr)
+
     box = None
     if args.box_bench and not use_dist:
         de.set_option(capi.PSM_OPT_PROFILE, 1)
@@ -300,6 +319,8 @@ def main():
                        "kernel_variant": args.variant, "shard_sim": args.shard_sim},
             "roofline": roofline, "cpu_baseline": cpu, "kernels": kern,
         }
+        if verified is not None:
+            out["verified_vs_single_gpu"] = verified
         if box:
             out["box_filter_pass"] = box
         print(json.dumps(out))

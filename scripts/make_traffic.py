@@ -1,0 +1,48 @@
+"""profiles/traffic.json from the rocprofv3 PMC summaries of scripts/gpu_run.sh (passes rd, wr).
+    python scripts/make_traffic.py gpurun_out/<tag> [kernel substring, default k_cvf_pc<true, 2>]
+Fabric-side bytes per launch = TCC_EA0_RDREQ_sum*128 (these kernels issue no 32-byte requests; equals
+2*FETCH_SIZE*1024, the gfx950 correction of MI355X_MICROARCH.md) + WRITE_SIZE*1024."""
+import json
+import os
+import re
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def counters(path, kernel):
+    out, cur = {}, None
+    for line in open(path):
+        if line.startswith("### counters:"):
+            cur = line
+        elif cur and kernel in cur:
+            m = re.match(r"\s+(\S+)\s+avg/dispatch = (\S+)", line)
+            if m:
+                out[m.group(1)] = float(m.group(2))
+    return out
+
+
+def main():
+    d = sys.argv[1]
+    kernel = sys.argv[2] if len(sys.argv) > 2 else "k_cvf_pc<true, 2>"
+    rd = counters(os.path.join(d, "pmc_rd.summary.txt"), kernel)
+    wr = counters(os.path.join(d, "pmc_wr.summary.txt"), kernel)
+    r32 = rd.get("TCC_EA0_RDREQ_32B_sum", 0.0)
+    rbytes = (rd["TCC_EA0_RDREQ_sum"] - r32) * 128 + r32 * 32
+    wbytes = wr["WRITE_SIZE"] * 1024
+    out = {
+        "_comment": "Fabric-side (L2 <-> Infinity Fabric) bytes per launch from rocprofv3 PMC passes (scripts/gpu_run.sh, "
+                    "scripts/make_traffic.py): TCC_EA0_RDREQ_sum*128 (+32 B per 32-byte request; equals 2*FETCH_SIZE*1024, the "
+                    "gfx950 correction of MI355X_MICROARCH.md) + WRITE_SIZE*1024. Infinity-cache (MALL) hits are counted: the "
+                    "d-invariant guidance planes are re-read for every slice and are served from L2/MALL, not from HBM. "
+                    f"Kernel: {kernel} (right volume, costs built on the fly).",
+        "c4:k_cvf_fused": round(rbytes + wbytes),
+        "c4:k_cvf_fused_read": round(rbytes),
+        "c4:k_cvf_fused_write": round(wbytes),
+    }
+    json.dump(out, open(os.path.join(ROOT, "profiles", "traffic.json"), "w"), indent=1)
+    print(json.dumps(out, indent=1))
+
+
+if __name__ == "__main__":
+    main()

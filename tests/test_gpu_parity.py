@@ -392,6 +392,35 @@ def test_full_size_c4_1920x1080(psm, oracle):
     _full_size_checks(psm, oracle, 1920, 1080, 256, 200, 206, (0, 64))
 
 
+def test_full_size_c5_3840x2160_band_and_lr_check(psm, oracle):
+    """BASELINE configs[4] geometry (3840x2160, + PP left-right check on the GPU) at a slice range the test can
+    afford: oracle parity on a row band of two slices, then the device L-R check and invalid fill against the
+    oracle's on the full 4K maps of an 8-shard job merged on one GPU."""
+    from primestereomatch_amd import synth
+    W, H, D = 3840, 2160, 256
+    _full_size_checks(psm, oracle, W, H, D, 100, 104, (1000, 1048))
+    Dm = 24
+    l, r, _ = synth.make_pair(W, H, Dm, seed=3)
+    shards = [psm.DispEst(l, r, Dm, d_range=(3 * g, 3 * (g + 1))) for g in range(8)]
+    try:
+        for s in shards:
+            s.CostConst_GPU(); s.CostFilter_GPU(); s.DispSelect_partial()
+        root = shards[0]
+        root.DispSelect_merge_ctx(shards)
+        ld, rd = root.lDisMap.copy(), root.rDisMap.copy()
+        root.LRCheck_GPU()
+        lv, rv = oracle.lr_check(ld, rd)
+        assert np.array_equal(root.lValid, lv) and np.array_equal(root.rValid, rv)
+        root.FillInv_GPU()
+        assert np.array_equal(root.lDisMap, oracle.fill_inv(ld, lv)) and np.array_equal(root.rDisMap, oracle.fill_inv(rd, rv))
+    finally:
+        for s in shards:
+            s.close()
+    with psm.DispEst(l, r, Dm) as de:
+        de.CostConst_GPU(); de.CostFilter_GPU(); de.DispSelect_GPU()
+        assert np.array_equal(de.lDisMap, ld) and np.array_equal(de.rDisMap, rd)
+
+
 def test_full_size_c4_sharded_wta_consistency(psm):
     """1920x1080x256 on one GPU: unsharded maps == 4 logical shards merged (checksum of maps)."""
     from primestereomatch_amd import synth
