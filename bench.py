@@ -49,7 +49,7 @@ def main():
     ap.add_argument("--variant", type=int, default=0)
     ap.add_argument("--flags", type=int, default=-1, help="PSM_OPT_FLAGS tuning bits (-1: library default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample-d", type=int, default=24, help="disparities in the CPU-baseline sample")
+    ap.add_argument("--cpu-sample-d", type=int, default=256, help="disparities in the CPU-baseline sample (default: the whole workload, ~10 s on 8 threads)")
     ap.add_argument("--force-dist", action="store_true", help="use the torch.distributed path even for N=1")
     ap.add_argument("--exchange", default="allreduce", choices=["allreduce", "allgather", "none"],
                     help="N>1 exchange step: one all_reduce(MIN) of the packed keys (default; ~2x33 MB per rank "

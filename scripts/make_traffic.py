@@ -33,8 +33,8 @@ def main():
     out = {
         "_comment": "Fabric-side (L2 <-> Infinity Fabric) bytes per launch from rocprofv3 PMC passes (scripts/gpu_run.sh, "
                     "scripts/make_traffic.py): TCC_EA0_RDREQ_sum*128 (+32 B per 32-byte request; equals 2*FETCH_SIZE*1024, the "
-                    "gfx950 correction of MI355X_MICROARCH.md) + WRITE_SIZE*1024. Infinity-cache (MALL) hits are counted: the "
-                    "d-invariant guidance planes are re-read for every slice and are served from L2/MALL, not from HBM. "
+                    "gfx950 correction of MI355X_MICROARCH.md) + WRITE_SIZE*1024. Requests served by the Infinity cache (MALL) "
+                    "are included, so this is an upper bound of the HBM bytes. "
                     f"Kernel: {kernel} (right volume, costs built on the fly).",
         "c4:k_cvf_fused": round(rbytes + wbytes),
         "c4:k_cvf_fused_read": round(rbytes),
