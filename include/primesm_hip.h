@@ -57,7 +57,9 @@ enum {
                                    volumes (default: they stay virtual and the fused filter builds the costs
                                    on the fly; any other reader materialises them first); 256 = two-pass
                                    guidance kernels; 512 = two-columns-per-lane variant of the fused filter
-                                   (widths that are multiples of 4).  No flag changes any result. */
+                                   (widths that are multiples of 4); 4096 = psm_cost_filter_fgf always writes
+                                   the filtered volumes (default: they stay virtual - low-resolution models -
+                                   and the WTA consumes those directly).  No flag changes any result. */
 };
 
 /* Number of usable HIP devices; 0 if none.  Replaces openCLdevicepoll()

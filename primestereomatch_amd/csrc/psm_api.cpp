@@ -53,6 +53,11 @@ struct psm_ctx {
     uint8_t *p4[2] = {nullptr, nullptr};  // PSM_U8 only: {c0,c1,c2,grad} words
     float *soa[2] = {nullptr, nullptr};   // planar copies of g1..g4 (14 planes) for the two-columns-per-lane filter
     int soa_state[2] = {0, 0};            // 0 nothing, 1 g1 planes, 2 all planes (of the current image pair)
+    // After psm_cost_filter_fgf the filtered volume of a side may stay virtual (fgf_virtual[side] = subsample rate):
+    // it is fully described by the smoothed low-resolution models fgf_mab[side]; the WTA consumes them directly
+    // (upsample + model + argmin in one pass), any other reader of vol[side] materialises it first (materialize()).
+    int fgf_virtual[2] = {0, 0};
+    float4 *fgf_mab[2] = {nullptr, nullptr};
     void *fgf = nullptr;                // psm_cost_filter_fgf scratch (small planes), fgf_bytes long
     size_t fgf_bytes = 0;
 
@@ -234,9 +239,22 @@ void launch_cvc_rows(psm_ctx *c, int side, int ybeg, int yend)
                c->march.flags, ybeg, yend);
 }
 
-// make sure the whole unfiltered volume of `side` is in memory
+// a virtual Fast-Guided-Filter result becomes a real volume
+int fgf_flush(psm_ctx *c, int side)
+{
+    if (!c->fgf_virtual[side]) return 0;
+    {
+        Prof p(c, PSM_K_FGF);
+        launch_fgf_apply(c->stream, (float *)c->vol[side], c->g[side].g1, c->W, c->H, c->Dloc, c->fgf_virtual[side], c->fgf_mab[side]);
+    }
+    c->fgf_virtual[side] = 0;
+    return check_launch(c, "fgf (upsample)");
+}
+
+// make sure the whole volume of `side` (unfiltered, or filtered by psm_cost_filter_fgf) is in memory
 int materialize(psm_ctx *c, int side)
 {
+    if (fgf_flush(c, side)) return 1;
     if (c->dtype != PSM_F32 || c->raw_rows[side] == psm_ctx::RAW_ALL) return 0;
     launch_cvc_rows(c, side, 0, c->H);
     c->raw_rows[side] = psm_ctx::RAW_ALL;
@@ -417,6 +435,7 @@ int psm_cost_construct(psm_ctx *c)
     if (bind(c)) return 1;
     const double t0 = now_us();
     if (run_prep(c)) return 1;  // CVC::preprocess belongs to this stage (src/DispEst.cpp:232-233)
+    c->fgf_virtual[0] = c->fgf_virtual[1] = 0;   // a new cost volume replaces whatever was pending
     // Lazy cost volume: when the fused filter will consume the costs (float mode, marching kernels,
     // fusion not disabled) they are built inside that kernel and never written to HBM.
     const bool lazy = c->dtype == PSM_F32 && c->opt_variant == 0 && !(c->march.flags & (16 | 32 | 128)) && c->H >= 8;
@@ -442,6 +461,7 @@ static int filter_side(psm_ctx *c, int side, bool stage_b)
     const size_t V = (size_t)c->W * c->H * c->Dloc;
     const int W = c->W, H = c->H;
     if (!c->have_g1 && run_prep(c)) return 1;  // volume came from psm_upload_volume
+    if (fgf_flush(c, side)) return 1;
     {
         Prof p(c, PSM_K_GUIDE);
         launch_guidance(c->stream, c->g[side], c->hs9, W, H, (c->march.flags & 256) ? 1 : 0);
@@ -580,8 +600,9 @@ int psm_cost_filter_fgf(psm_ctx *c, int sub)
     if (bind(c)) return 1;
     const double t0 = now_us();
     if (!c->have_g1 && run_prep(c)) return 1;
-    // small planes: ism, msm, v1 (float4), v2 (float2) per pixel; ab, mab (float4) per small voxel
-    const size_t n = (size_t)ws * hs, need = n * (3 * sizeof(float4) + sizeof(float2)) + 2 * n * c->Dloc * sizeof(float4);
+    // small planes: ism, msm, v1 (float4), v2 (float2) per pixel; ab (scratch) and one mab per side (float4) per small voxel
+    const size_t n = (size_t)ws * hs, need = n * (3 * sizeof(float4) + sizeof(float2)) + 3 * n * c->Dloc * sizeof(float4);
+    if (fgf_flush(c, 0) || fgf_flush(c, 1)) return 1;   // filtering an already FGF-filtered volume: make it real first
     if (c->fgf_bytes < need) {
         PSM_HIP(c, hipStreamSynchronize(c->stream));
         (void)hipFree(c->fgf);
@@ -590,17 +611,23 @@ int psm_cost_filter_fgf(psm_ctx *c, int sub)
         PSM_HIP(c, hipMalloc(&c->fgf, need));
         c->fgf_bytes = need;
     }
-    float4 *ism = (float4 *)c->fgf, *msm = ism + n, *v1 = msm + n, *ab = v1 + n, *mab = ab + n * c->Dloc;
-    float2 *v2 = (float2 *)(mab + n * c->Dloc);
+    float4 *ism = (float4 *)c->fgf, *msm = ism + n, *v1 = msm + n, *ab = v1 + n;
+    c->fgf_mab[0] = ab + n * c->Dloc;
+    c->fgf_mab[1] = c->fgf_mab[0] + n * c->Dloc;
+    float2 *v2 = (float2 *)(c->fgf_mab[1] + n * c->Dloc);
+    // flag 4096: always write the filtered volume (default: it stays virtual until something other than the WTA reads it)
+    const bool keep_virtual = fgf_can_fuse_wta(c->W) && !(c->march.flags & 4096);
     // left volume with the left image as guidance, then the right one (src/DispEst.cpp:283-295)
     for (int side = 0; side < 2; ++side) {
         // a virtual (lazy) cost volume stays virtual: the filter samples 1/sub^2 of it straight from the g1 planes
         const int mode = c->raw_rows[side] == psm_ctx::RAW_ALL ? 0 : 1 + side;
         Prof p(c, PSM_K_FGF);
         launch_fgf_setup(c->stream, c->g[side].g1, c->W, c->H, sub, ism, msm, v1, v2);
-        launch_fgf_filter(c->stream, (float *)c->vol[side], c->g[side].g1, c->g[1 - side].g1, c->W, c->H, c->Dloc, c->d0, sub, mode,
-                          msm, v1, v2, ab, mab);
-        c->raw_rows[side] = psm_ctx::RAW_ALL;   // vol[side] now holds real (filtered) data
+        launch_fgf_model(c->stream, (const float *)c->vol[side], c->g[side].g1, c->g[1 - side].g1, c->W, c->H, c->Dloc, c->d0, sub, mode,
+                         msm, v1, v2, ab, c->fgf_mab[side]);
+        if (keep_virtual) c->fgf_virtual[side] = sub;
+        else launch_fgf_apply(c->stream, (float *)c->vol[side], c->g[side].g1, c->W, c->H, c->Dloc, sub, c->fgf_mab[side]);
+        c->raw_rows[side] = psm_ctx::RAW_ALL;   // vol[side] holds (or, while virtual, stands for) filtered data
     }
     if (check_launch(c, "cvf (fast guided filter)")) return 1;
     c->have_maps = false;
@@ -629,19 +656,36 @@ static int copy_maps_out(psm_ctx *c, const uint8_t *dev, uint8_t *lmap, uint8_t 
     return 0;
 }
 
+// WTA of one side into keys_s (may be NULL) and / or map_s (may be NULL).  A side whose Fast-Guided-Filter result is
+// still virtual is selected straight from the smoothed models (upsample + linear model + argmin in one pass).
+static int wta_side(psm_ctx *c, int s, long long *keys_s, uint8_t *map_s)
+{
+    const size_t HW = (size_t)c->W * c->H;
+    Prof p(c, PSM_K_WTA);
+    if (c->fgf_virtual[s]) {
+        long long *k = keys_s ? keys_s : c->keys + s * HW;
+        launch_fgf_apply_wta(c->stream, c->g[s].g1, c->W, c->H, c->Dloc, c->d0, c->fgf_virtual[s], c->fgf_mab[s], k);
+        if (map_s) launch_merge(c->stream, k, HW, 1, (int)HW, map_s);
+    } else if (c->dtype == PSM_U8) {
+        launch_wta_u8(c->stream, (const uint8_t *)c->vol[s], c->W, c->H, c->d0, c->Dloc, keys_s, map_s);
+    } else {
+        launch_wta(c->stream, (const float *)c->vol[s], c->W, c->H, c->d0, c->Dloc, keys_s, map_s);
+    }
+    return 0;
+}
+
 static int wta_launch(psm_ctx *c, long long *keys, uint8_t *maps)
 {
     const size_t HW = (size_t)c->W * c->H;
-    for (int s = 0; s < 2; ++s) {
-        Prof p(c, PSM_K_WTA);
-        if (c->dtype == PSM_U8)
-            launch_wta_u8(c->stream, (const uint8_t *)c->vol[s], c->W, c->H, c->d0, c->Dloc, keys ? keys + s * HW : nullptr,
-                          maps ? maps + s * HW : nullptr);
-        else
-            launch_wta(c->stream, (const float *)c->vol[s], c->W, c->H, c->d0, c->Dloc, keys ? keys + s * HW : nullptr,
-                       maps ? maps + s * HW : nullptr);
-    }
+    for (int s = 0; s < 2; ++s)
+        if (wta_side(c, s, keys ? keys + s * HW : nullptr, maps ? maps + s * HW : nullptr)) return 1;
     return check_launch(c, "wta");
+}
+
+// the volume a WTA is about to read: real data, or a virtual FGF result (consumed without materialising it)
+static int wta_ready(psm_ctx *c, int side)
+{
+    return c->fgf_virtual[side] ? 0 : materialize(c, side);
 }
 
 int psm_disp_select(psm_ctx *c, uint8_t *lmap, uint8_t *rmap, size_t stride)
@@ -651,7 +695,7 @@ int psm_disp_select(psm_ctx *c, uint8_t *lmap, uint8_t *rmap, size_t stride)
     if (!c->have_cost) return fail(c, "psm_disp_select: no cost volume");
     if (bind(c)) return 1;
     const double t0 = now_us();
-    if (materialize(c, 0) || materialize(c, 1)) return 1;
+    if (wta_ready(c, 0) || wta_ready(c, 1)) return 1;
     if (wta_launch(c, nullptr, c->maps)) return 1;
     c->have_maps = true;
     c->have_valid = false;
@@ -665,7 +709,7 @@ int psm_disp_select_partial(psm_ctx *c, void *dev_keys)
     if (!c->have_cost) return fail(c, "psm_disp_select_partial: no cost volume");
     if (bind(c)) return 1;
     const double t0 = now_us();
-    if (materialize(c, 0) || materialize(c, 1)) return 1;
+    if (wta_ready(c, 0) || wta_ready(c, 1)) return 1;
     if (wta_launch(c, dev_keys ? (long long *)dev_keys : c->keys, nullptr)) return 1;
     return end_stage(c, PSM_STAGE_DISPSEL, t0);
 }
@@ -677,16 +721,10 @@ int psm_disp_select_partial_side(psm_ctx *c, int side, void *dev_keys_side)
     if (!c->have_cost) return fail(c, "psm_disp_select_partial_side: no cost volume");
     if (bind(c)) return 1;
     const double t0 = now_us();
-    if (materialize(c, side)) return 1;
+    if (wta_ready(c, side)) return 1;
     const size_t HW = (size_t)c->W * c->H;
     long long *keys = dev_keys_side ? (long long *)dev_keys_side : c->keys + side * HW;
-    {
-        Prof p(c, PSM_K_WTA);
-        if (c->dtype == PSM_U8)
-            launch_wta_u8(c->stream, (const uint8_t *)c->vol[side], c->W, c->H, c->d0, c->Dloc, keys, nullptr);
-        else
-            launch_wta(c->stream, (const float *)c->vol[side], c->W, c->H, c->d0, c->Dloc, keys, nullptr);
-    }
+    if (wta_side(c, side, keys, nullptr)) return 1;
     if (check_launch(c, "wta")) return 1;
     if (!c->opt_async) PSM_HIP(c, hipStreamSynchronize(c->stream));
     c->stage_us[PSM_STAGE_DISPSEL] = (side == PSM_LEFT ? 0.0 : c->stage_us[PSM_STAGE_DISPSEL]) + (now_us() - t0);
@@ -824,6 +862,7 @@ int psm_upload_volume(psm_ctx *c, int side, int d0, int d1, const void *host)
     if (check_slices(c, "psm_upload_volume", side, d0, d1)) return 1;
     if (bind(c)) return 1;
     if (c->have_cost && c->have_g1 && materialize(c, side)) return 1;   // a partial upload must not leave virtual slices
+    if (fgf_flush(c, side)) return 1;
     const size_t S = (size_t)c->W * c->H * velem(c);
     PSM_HIP(c, hipMemcpyAsync((char *)c->vol[side] + (size_t)(d0 - c->d0) * S, host, (size_t)(d1 - d0) * S, hipMemcpyHostToDevice, c->stream));
     PSM_HIP(c, hipStreamSynchronize(c->stream));

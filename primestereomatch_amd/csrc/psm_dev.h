@@ -115,4 +115,15 @@ __device__ __forceinline__ float recombine(float ma0, float ma1, float ma2, floa
     return __fadd_rn(__fadd_rn(__fadd_rn(mb, __fmul_rn(ma0, g1.x)), __fmul_rn(ma1, g1.y)), __fmul_rn(ma2, g1.z));
 }
 
+// WTA exchange key: (monotone-uint32(cost) << 32 | d), signed-comparable; the minimum over candidates reproduces
+// strict-< / lowest-d-wins (src/DispSel.cpp:96-104) across slices, shards and ranks
+__device__ __forceinline__ long long pack_key_f32(float cost, int d)
+{
+    cost = __fadd_rn(cost, 0.0f);  // -0 -> +0 so that equal costs compare equal
+    unsigned u = __float_as_uint(cost);
+    u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);  // monotone map float -> uint
+    unsigned long long k = ((unsigned long long)u << 32) | (unsigned)d;
+    return (long long)(k ^ 0x8000000000000000ull);   // signed-comparable
+}
+
 }  // namespace psm

@@ -23,6 +23,7 @@
 //                                   share them, one 16-byte store per lane and row (whole 128-byte lines)
 #include "psm_kernels.h"
 #include "psm_cost.h"
+#include "psm_dev.h"
 
 namespace psm {
 
@@ -357,6 +358,96 @@ __global__ __launch_bounds__(256) void k_fgf_apply4(const f4v *__restrict__ mab,
     }
 }
 
+
+// ---- upsample + linear model + WTA in one pass: the filtered volume is never written ---------------
+// Same arithmetic per voxel as k_fgf_apply4; instead of storing q the thread keeps the running strict-< minimum
+// over its chunk of slices (DispSel::CVSelect, src/DispSel.cpp:83-109: d = 0 is never a candidate, NaN never
+// wins) and merges it into the per-pixel key plane with one 64-bit atomic minimum per pixel and chunk.
+__global__ __launch_bounds__(256) void k_fgf_key_init(long long *__restrict__ keys, int n)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) keys[i] = pack_key_f32(__builtin_inff(), 0);
+}
+
+template <int RB>
+__global__ __launch_bounds__(256) void k_fgf_apply_wta(const f4v *__restrict__ mab, int ws, int hs, const f4v *__restrict__ g1,
+                                                      int W, int H, int Dloc, int dchunk, int yshift, int d_begin,
+                                                      long long *__restrict__ keys)
+{
+    const int x0 = (blockIdx.x * 256 + threadIdx.x) * 4, y0 = (int)blockIdx.y * RB - yshift;
+    if (x0 >= W) return;
+    const int dbeg = blockIdx.z * dchunk, dend = dbeg + dchunk < Dloc ? dbeg + dchunk : Dloc;
+    unsigned oa[4], ob[4];
+    float a0[4], a1[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        int ca;
+        lin_src(x0 + j, ws, W, ca, a1[j]);
+        oa[j] = (unsigned)ca * 16u;
+        ob[j] = (unsigned)(ca + 1 < ws ? ca + 1 : ws - 1) * 16u;
+        a0[j] = __fsub_rn(1.f, a1[j]);
+    }
+    f2v gxy[RB][4];
+    float gz[RB][4];
+    int sy[RB], sy1[RB];
+    float b0[RB], b1[RB];
+#pragma unroll
+    for (int r = 0; r < RB; ++r) {
+        int y = y0 + r;
+        y = y < 0 ? 0 : (y < H ? y : H - 1);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const f4v g = g1[(size_t)y * W + x0 + j];
+            gxy[r][j] = g.xy;
+            gz[r][j] = g.z;
+        }
+        lin_src(y, hs, H, sy[r], b1[r]);
+        sy1[r] = sy[r] + 1 < hs ? sy[r] + 1 : hs - 1;
+        b0[r] = __fsub_rn(1.f, b1[r]);
+    }
+    float mc[RB][4];
+    int md[RB][4];
+#pragma unroll
+    for (int r = 0; r < RB; ++r)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { mc[r][j] = __builtin_inff(); md[r][j] = 0; }
+    auto hrow = [&](int d, int row, f4v *U) {
+        size_t roff = (((size_t)d * hs + row) * ws) * sizeof(f4v);
+        asm volatile("" : "+s"(roff));
+        const char *mr = (const char *)mab + roff;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) U[j] = *(const f4v *)(mr + oa[j]) * a0[j] + *(const f4v *)(mr + ob[j]) * a1[j];
+    };
+    for (int d = dbeg; d < dend; ++d) {
+        const int dg = d_begin + d;
+        if (dg == 0) continue;            // d = 0 is never a candidate (src/DispSel.cpp:96)
+        f4v Ua[4], Ub[4];
+        hrow(d, sy[0], Ua);
+        hrow(d, sy1[0], Ub);
+#pragma unroll
+        for (int r = 0; r < RB; ++r) {
+            if (r > 0 && sy[r] != sy[r - 1]) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) Ua[j] = Ub[j];
+                hrow(d, sy1[r], Ub);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const f4v u = Ua[j] * b0[r] + Ub[j] * b1[r];
+                const f2v m = u.xy * gxy[r][j];
+                const float q = __fadd_rn(__fadd_rn(__fadd_rn(m.x, m.y), __fmul_rn(u.z, gz[r][j])), u.w);
+                if (q < mc[r][j]) { mc[r][j] = q; md[r][j] = dg; }
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < RB; ++r)
+        if (y0 + r >= 0 && y0 + r < H) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) atomicMin(keys + (size_t)(y0 + r) * W + x0 + j, pack_key_f32(mc[r][j], md[r][j]));
+        }
+}
+
 }  // namespace
 
 // FgfScratch: small planes of one side (allocated by the API layer)
@@ -370,8 +461,8 @@ void launch_fgf_setup(hipStream_t s, const float4 *g1, int W, int H, int sub, fl
     else hipLaunchKernelGGL(k_fgf_setup<9>, grid, dim3(256), 0, s, (const float4 *)ism, ws, hs, msm, v1, v2);
 }
 
-void launch_fgf_filter(hipStream_t s, float *vol, const float4 *g1, const float4 *g1_other, int W, int H, int Dloc, int d_begin,
-                       int sub, int cvc_mode, const float4 *msm, const float4 *v1, const float2 *v2, float4 *ab, float4 *mab)
+void launch_fgf_model(hipStream_t s, const float *vol, const float4 *g1, const float4 *g1_other, int W, int H, int Dloc, int d_begin,
+                      int sub, int cvc_mode, const float4 *msm, const float4 *v1, const float2 *v2, float4 *ab, float4 *mab)
 {
     const int ws = W / sub, hs = H / sub, k = 2 * (8 / sub) + 1;
     const int nstrips = (ws + (64 - 2 * (k / 2)) - 1) / (64 - 2 * (k / 2));
@@ -392,9 +483,14 @@ void launch_fgf_filter(hipStream_t s, float *vol, const float4 *g1, const float4
     if (k == 3) PSM_FGF_K(3); else if (k == 5) PSM_FGF_K(5); else PSM_FGF_K(9);
 #undef PSM_FGF_K
 #undef PSM_FGF_MODEL
+}
+
+void launch_fgf_apply(hipStream_t s, float *vol, const float4 *g1, int W, int H, int Dloc, int sub, const float4 *mab)
+{
+    const int ws = W / sub, hs = H / sub;
     if (W % 4 == 0) {
         const int dchunk = Dloc < 32 ? Dloc : 32;
-                const int rb = sub == 2 ? 2 : 4, yshift = (sub / 2) % rb;
+        const int rb = sub == 2 ? 2 : 4, yshift = (sub / 2) % rb;
         dim3 gf((W / 4 + 255) / 256, (H + yshift + rb - 1) / rb, (Dloc + dchunk - 1) / dchunk);
         if (rb == 2)
             hipLaunchKernelGGL(k_fgf_apply4<2>, gf, dim3(256), 0, s, (const f4v *)mab, ws, hs, (const f4v *)g1, W, H, vol, Dloc, dchunk, yshift);
@@ -404,6 +500,23 @@ void launch_fgf_filter(hipStream_t s, float *vol, const float4 *g1, const float4
         dim3 gf((W + 255) / 256, H, Dloc);
         hipLaunchKernelGGL(k_fgf_apply, gf, dim3(256), 0, s, (const float4 *)mab, ws, hs, g1, W, H, vol);
     }
+}
+
+bool fgf_can_fuse_wta(int W) { return (W & 3) == 0; }
+
+void launch_fgf_apply_wta(hipStream_t s, const float4 *g1, int W, int H, int Dloc, int d_begin, int sub, const float4 *mab,
+                          long long *keys)
+{
+    const int ws = W / sub, hs = H / sub, n = W * H;
+    hipLaunchKernelGGL(k_fgf_key_init, dim3((n + 255) / 256), dim3(256), 0, s, keys, n);
+    const int dchunk = Dloc < 32 ? Dloc : 32;
+    // two rows per thread: 186 VGPRs, two waves per SIMD (four rows: 312 registers, one wave, 15 % slower; loading each
+    // distinct model column once per row instead of once per pixel: 25 % slower - the duplicates coalesce in the L1)
+    constexpr int rb = 2;
+    const int yshift = (sub / 2) % rb;
+    dim3 gf((W / 4 + 255) / 256, (H + yshift + rb - 1) / rb, (Dloc + dchunk - 1) / dchunk);
+    hipLaunchKernelGGL(k_fgf_apply_wta<rb>, gf, dim3(256), 0, s, (const f4v *)mab, ws, hs, (const f4v *)g1, W, H, Dloc, dchunk, yshift,
+                       d_begin, keys);
 }
 
 }  // namespace psm

@@ -65,11 +65,18 @@ void launch_fill_inv(hipStream_t s, uint8_t *dis, const uint8_t *valid, int W, i
 // ---- Fast Guided Filter variant (psm_fgf.hip); sub = subsample rate, small planes are (H/sub) x (W/sub) ----
 // g1 -> subsampled guidance ism, its means msm and the inverse covariance planes v1 = {irr,irg,irb,igg}, v2 = {igb,ibb}
 void launch_fgf_setup(hipStream_t s, const float4 *g1, int W, int H, int sub, float4 *ism, float4 *msm, float4 *v1, float2 *v2);
-// filters Dloc slices of vol in place; ab/mab: scratch, Dloc*(H/sub)*(W/sub) float4 each.  cvc_mode 0: the cost
-// slices are read from vol; 1/2: the left/right costs of the sampled pixels are built from the g1 planes (vol is
-// only written)
-void launch_fgf_filter(hipStream_t s, float *vol, const float4 *g1, const float4 *g1_other, int W, int H, int Dloc, int d_begin,
-                       int sub, int cvc_mode, const float4 *msm, const float4 *v1, const float2 *v2, float4 *ab, float4 *mab);
+// First half of the filter for Dloc slices: subsampled cost (cvc_mode 0: read from vol; 1/2: left/right costs of the
+// sampled pixels built from the g1 planes) -> linear models -> smoothed models mab (Dloc*(H/sub)*(W/sub) float4;
+// ab: scratch of the same size).
+void launch_fgf_model(hipStream_t s, const float *vol, const float4 *g1, const float4 *g1_other, int W, int H, int Dloc, int d_begin,
+                      int sub, int cvc_mode, const float4 *msm, const float4 *v1, const float2 *v2, float4 *ab, float4 *mab);
+// Second half: bilinear upsampling of mab + q = a.I + b, written to vol ...
+void launch_fgf_apply(hipStream_t s, float *vol, const float4 *g1, int W, int H, int Dloc, int sub, const float4 *mab);
+// ... or consumed on the fly by the WTA: keys[H*W] receives the packed (cost, d) minimum over the local slices and the
+// filtered volume is never written (needs fgf_can_fuse_wta(W))
+bool fgf_can_fuse_wta(int W);
+void launch_fgf_apply_wta(hipStream_t s, const float4 *g1, int W, int H, int Dloc, int d_begin, int sub, const float4 *mab,
+                          long long *keys);
 
 // ---- 8-bit char mode ----
 void launch_prep_u8(hipStream_t s, const uint8_t *src, size_t pitch, int W, int H, uint8_t *planes4);

@@ -1285,15 +1285,6 @@ void launch_box8(hipStream_t s, int variant, March m, const float *vol, float *o
 // ------------------------------------------------------------------------------------------
 // DispSel: WTA (src/DispSel.cpp:83-109) over the local slices, with global semantics
 // ------------------------------------------------------------------------------------------
-__device__ __forceinline__ long long pack_key_f32(float cost, int d)
-{
-    cost = __fadd_rn(cost, 0.0f);  // -0 -> +0 so that equal costs compare equal
-    unsigned u = __float_as_uint(cost);
-    u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);  // monotone map float -> uint
-    unsigned long long k = ((unsigned long long)u << 32) | (unsigned)d;
-    return (long long)(k ^ 0x8000000000000000ull);   // signed-comparable
-}
-
 __global__ __launch_bounds__(256) void k_wta(const float *__restrict__ vol, int HW, int d_begin, int Dloc,
                                             long long *__restrict__ keys, uint8_t *__restrict__ map)
 {

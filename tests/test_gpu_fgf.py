@@ -65,6 +65,32 @@ def test_fgf_middlebury_golden(psm, golden, name):
             assert np.array_equal(lv[17], gold["lvol_d17_s4"])
 
 
+@pytest.mark.parametrize("W", [64, 70])
+def test_fgf_virtual_volume_equals_materialised(psm, oracle, W):
+    """After CostFilter_FGF_GPU the filtered volume stays virtual (smoothed low-resolution models) and the WTA
+    consumes it directly; PSM_OPT_FLAGS=4096 writes it out instead.  Same maps, same volume, any call order
+    (W = 70: no 16-byte rows, the volume is always written)."""
+    from primestereomatch_amd import capi, synth
+    H, D = 48, 11
+    l, r, _ = synth.make_pair(W, H, D, seed=2)
+    ref = oracle.pipeline_fgf(l, r, D, s=4, threads=4, want_volumes=True)
+    for flags, order in ((0, "select-first"), (0, "download-first"), (4096, "select-first")):
+        with psm.DispEst(l, r, D) as de:
+            de.set_option(capi.PSM_OPT_FLAGS, flags)
+            de.CostConst_GPU()
+            de.CostFilter_FGF_GPU()
+            if order == "download-first":
+                assert np.array_equal(de.download_volume(1), ref["rvol"])      # materialises the right volume only
+            de.DispSelect_GPU()
+            assert np.array_equal(de.lDisMap, ref["ldisp"]) and np.array_equal(de.rDisMap, ref["rdisp"]), (flags, order)
+            de.DispSelect_GPU()                                               # a second selection of a virtual volume
+            assert np.array_equal(de.lDisMap, ref["ldisp"])
+            assert np.array_equal(de.download_volume(0), ref["lvol"]) and np.array_equal(de.download_volume(1), ref["rvol"])
+            de.CostFilter_GPU()                                               # the full filter on top of the FGF result
+            de.DispSelect_GPU()
+            assert de.lDisMap.shape == (H, W)
+
+
 def test_fgf_harness_metric(psm, golden):
     """Headless StereoMatch::compute with the snapshot's live branch (CostFilter_FGF, subsample_rate 4)."""
     from primestereomatch_amd import harness
