@@ -1,0 +1,89 @@
+"""-m gpu randomized sweep: the whole path (CVC -> CVF -> WTA -> L-R check -> fill) and the Fast Guided Filter
+variant against the CPU oracle on seeded random geometries - widths around the workgroup widths of the fused
+kernels (96, 224 columns), heights around the batch / segment sizes, single slices, shards cut at random places.
+Everything is expected bit-identical."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def psm():
+    from primestereomatch_amd import capi
+    capi.load()
+    assert capi.device_count() >= 1, "no HIP device visible"
+    import primestereomatch_amd as P
+    return P
+
+
+def _geometries(n, seed):
+    rng = np.random.default_rng(seed)
+    edge_w = [8, 9, 12, 95, 96, 97, 100, 103, 104, 191, 192, 193, 200, 223, 224, 225, 228, 288, 300]
+    edge_h = [8, 9, 10, 11, 12, 15, 16, 17, 19, 23, 31, 33, 64, 71]
+    out = []
+    for i in range(n):
+        W = int(rng.choice(edge_w)) if rng.random() < 0.6 else int(rng.integers(8, 320))
+        H = int(rng.choice(edge_h)) if rng.random() < 0.6 else int(rng.integers(8, 90))
+        D = int(rng.integers(1, min(W, 48) + 1))
+        out.append((W, H, D, int(rng.integers(0, 1 << 30))))
+    return out
+
+
+@pytest.mark.parametrize("W,H,D,seed", _geometries(36, 20260926))
+def test_random_geometry_full_path(psm, oracle, W, H, D, seed):
+    from primestereomatch_amd import capi, synth
+    rng = np.random.default_rng(seed)
+    l, r, _ = synth.make_pair(W, H, D, seed=seed & 0xffff)
+    if rng.random() < 0.3:   # flat regions: ill-conditioned covariance, ties in the WTA
+        l[: H // 2, : W // 2] = 90
+        r[: H // 2, : W // 2] = 90
+    ref = oracle.pipeline_f32(l, r, D, threads=4, want_volumes=True)
+    flags = int(rng.choice([0, 0, 0, 512, 128, 16]))
+    with psm.DispEst(l, r, D) as de:
+        de.set_option(capi.PSM_OPT_FLAGS, flags)
+        if rng.random() < 0.5:
+            de.set_option(capi.PSM_OPT_SEG_ROWS, int(rng.integers(8, 40)))
+        de.CostConst_GPU()
+        de.CostFilter_GPU()
+        de.DispSelect_GPU()
+        assert np.array_equal(de.download_volume(0), ref["lvol"]), (W, H, D, flags)
+        assert np.array_equal(de.download_volume(1), ref["rvol"]), (W, H, D, flags)
+        assert np.array_equal(de.lDisMap, ref["ldisp"]) and np.array_equal(de.rDisMap, ref["rdisp"])
+        de.LRCheck_GPU()
+        lv, rv = oracle.lr_check(ref["ldisp"], ref["rdisp"])
+        assert np.array_equal(de.lValid, lv) and np.array_equal(de.rValid, rv)
+        de.FillInv_GPU()
+        assert np.array_equal(de.lDisMap, oracle.fill_inv(ref["ldisp"], lv))
+    if D >= 2:   # the same pair as two shards cut at a random slice
+        cut = int(rng.integers(1, D))
+        shards = [psm.DispEst(l, r, D, d_range=(0, cut)), psm.DispEst(l, r, D, d_range=(cut, D))]
+        try:
+            for sh in shards:
+                sh.set_option(capi.PSM_OPT_FLAGS, flags)
+                sh.CostConst_GPU(); sh.CostFilter_GPU(); sh.DispSelect_partial()
+            shards[0].DispSelect_merge_ctx(shards)
+            assert np.array_equal(shards[0].lDisMap, ref["ldisp"]) and np.array_equal(shards[0].rDisMap, ref["rdisp"])
+        finally:
+            for sh in shards:
+                sh.close()
+
+
+@pytest.mark.parametrize("W,H,D,seed", _geometries(18, 777))
+def test_random_geometry_fgf(psm, oracle, W, H, D, seed):
+    from primestereomatch_amd import capi, synth
+    rng = np.random.default_rng(seed)
+    s = int(rng.choice([2, 4, 8]))
+    k = 2 * (8 // s) + 1
+    if W // s < k or H // s < k:   # the oracle wants a full blur window inside the subsampled image
+        pytest.skip("image too small for this subsample rate")
+    l, r, _ = synth.make_pair(W, H, D, seed=seed & 0xffff)
+    ref = oracle.pipeline_fgf(l, r, D, s=s, threads=4, want_volumes=True)
+    with psm.DispEst(l, r, D) as de:
+        de.set_option(capi.PSM_OPT_FLAGS, int(rng.choice([0, 0, 4096, 128])))
+        de.setSubsampleRate(s)
+        de.CostConst_GPU()
+        de.CostFilter_FGF_GPU()
+        de.DispSelect_GPU()
+        assert np.array_equal(de.lDisMap, ref["ldisp"]) and np.array_equal(de.rDisMap, ref["rdisp"]), (W, H, D, s)
+        assert np.array_equal(de.download_volume(0), ref["lvol"]) and np.array_equal(de.download_volume(1), ref["rvol"])
