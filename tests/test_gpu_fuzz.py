@@ -87,3 +87,18 @@ def test_random_geometry_fgf(psm, oracle, W, H, D, seed):
         de.DispSelect_GPU()
         assert np.array_equal(de.lDisMap, ref["ldisp"]) and np.array_equal(de.rDisMap, ref["rdisp"]), (W, H, D, s)
         assert np.array_equal(de.download_volume(0), ref["lvol"]) and np.array_equal(de.download_volume(1), ref["rvol"])
+
+
+@pytest.mark.parametrize("W,H,D,seed", _geometries(12, 4242))
+def test_random_geometry_u8_mode(psm, oracle, W, H, D, seed):
+    """8-bit char mode (build-defined contract, oracle/psm_oracle.h): integer work, bit-exact."""
+    from primestereomatch_amd import synth
+    l, r, _ = synth.make_pair(W, H, D, seed=seed & 0xffff)
+    ref = oracle.pipeline_u8(l, r, D, threads=4, want_volumes=True, want_raw=True)
+    with psm.DispEst(l, r, D, dtype="u8") as de:
+        de.CostConst_GPU()
+        assert np.array_equal(de.download_volume(0), ref["raw_l"]) and np.array_equal(de.download_volume(1), ref["raw_r"])
+        de.CostFilter_GPU()
+        de.DispSelect_GPU()
+        assert np.array_equal(de.download_volume(0), ref["lvol"]) and np.array_equal(de.download_volume(1), ref["rvol"])
+        assert np.array_equal(de.lDisMap, ref["ldisp"]) and np.array_equal(de.rDisMap, ref["rdisp"])
