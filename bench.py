@@ -144,7 +144,14 @@ def main():
         de.CostConst_GPU()
         if args.fgf:
             de.CostFilter_FGF_GPU()
-            de.DispSelect_device()
+            if use_dist:
+                de.DispSelect_partial(keys_local.data_ptr())
+                dist.all_reduce(keys_local, op=dist.ReduceOp.MIN)
+                de.DispSelect_merge(keys_local.data_ptr(), 1, download=False)
+            elif args.shard_sim > 1:
+                de.DispSelect_partial()
+            else:
+                de.DispSelect_device()
             return
         if pipelined:
             # Frame pipeline: both exchanges are asynchronous; the merge of frame i is issued during frame i+1,
