@@ -18,9 +18,11 @@
 //                                   cost of the sampled pixel from the g1 planes, so the FGF path never needs the
 //                                   full-resolution cost volume in memory (it samples 1/s^2 of it).
 //   k_fgf_smooth<K>                 same marching scheme on the (a_r,a_g,a_b,b) planes
-//   k_fgf_apply4                    full resolution: 4 pixels x 4 rows per thread, guidance in registers across a
-//                                   chunk of slices, horizontally interpolated rows cached across the rows that
-//                                   share them, one 16-byte store per lane and row (whole 128-byte lines)
+//   k_fgf_apply_wta                 full resolution, default consumer: upsample + linear model + winner-takes-all in one
+//                                   pass (4 pixels x 2 rows per thread, guidance in registers across a chunk of slices,
+//                                   one 64-bit atomic minimum per pixel and chunk) - the filtered volume is never written
+//   k_fgf_apply4                    the same upsample + model writing the volume (4 pixels x 4 rows per thread, one
+//                                   16-byte store per lane and row); runs only when something else reads the volume
 #include "psm_kernels.h"
 #include "psm_cost.h"
 #include "psm_dev.h"
@@ -258,8 +260,8 @@ __global__ __launch_bounds__(256) void k_fgf_apply(const float4 *__restrict__ ma
 
 
 // 4 pixels x RB rows per thread, looping over a chunk of slices with the guidance in registers (W % 4 == 0).
-// The interpolation arithmetic is written on 4-vectors (components of one model pixel) so that it compiles to
-// packed fp32 multiplies/adds (v_pk_mul_f32 / v_pk_add_f32): same IEEE roundings, half the VALU issue slots.
+// Plain fp32 arithmetic: on this part a packed fp32 op issues in four cycles, a scalar one in two, and the vector
+// forms cost registers (even-aligned pairs) and therefore occupancy.
 typedef float f4v __attribute__((ext_vector_type(4)));
 typedef float f2v __attribute__((ext_vector_type(2)));
 // Software pipeline: the model rows of slice d+1 are requested before the outputs of slice d are stored.  A wave's
@@ -286,8 +288,7 @@ __global__ __launch_bounds__(256) void k_fgf_apply4(const f4v *__restrict__ mab,
         ob[j] = (unsigned)(ca + 1 < ws ? ca + 1 : ws - 1) * 16u;
         a0[j] = __fsub_rn(1.f, a1[j]);
     }
-    f2v gxy[RB][4];
-    float gz[RB][4];
+    float gx[RB][4], gy[RB][4], gz[RB][4];
     int sy[RB], sy1[RB];
     float b0[RB], b1[RB];
 #pragma unroll
@@ -297,8 +298,7 @@ __global__ __launch_bounds__(256) void k_fgf_apply4(const f4v *__restrict__ mab,
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const f4v g = g1[(size_t)y * W + x0 + j];
-            gxy[r][j] = g.xy;
-            gz[r][j] = g.z;
+            gx[r][j] = g.x; gy[r][j] = g.y; gz[r][j] = g.z;
         }
         lin_src(y, hs, H, sy[r], b1[r]);
         sy1[r] = sy[r] + 1 < hs ? sy[r] + 1 : hs - 1;
@@ -316,9 +316,17 @@ __global__ __launch_bounds__(256) void k_fgf_apply4(const f4v *__restrict__ mab,
             R[2 * j + 1] = *(const f4v *)(mr + ob[j]);
         }
     };
+    auto lerp4 = [](f4v s0, float w0, f4v s1, float w1) -> f4v {   // S0*w0 + S1*w1 per component, fp32, no FMA
+        f4v r;
+        r.x = __fadd_rn(__fmul_rn(s0.x, w0), __fmul_rn(s1.x, w1));
+        r.y = __fadd_rn(__fmul_rn(s0.y, w0), __fmul_rn(s1.y, w1));
+        r.z = __fadd_rn(__fmul_rn(s0.z, w0), __fmul_rn(s1.z, w1));
+        r.w = __fadd_rn(__fmul_rn(s0.w, w0), __fmul_rn(s1.w, w1));
+        return r;
+    };
     auto hrow = [&](const f4v *R, f4v *U) {  // row pass of cv::resize INTER_LINEAR: S[sx]*(1-fx) + S[sx+1]*fx
 #pragma unroll
-        for (int j = 0; j < 4; ++j) U[j] = R[2 * j] * a0[j] + R[2 * j + 1] * a1[j];
+        for (int j = 0; j < 4; ++j) U[j] = lerp4(R[2 * j], a0[j], R[2 * j + 1], a1[j]);
     };
     request(dbeg, sy[0], Ra);
     request(dbeg, sy1[0], Rb);
@@ -346,10 +354,9 @@ __global__ __launch_bounds__(256) void k_fgf_apply4(const f4v *__restrict__ mab,
             }
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const f4v u = Ua[j] * b0[r] + Ub[j] * b1[r];      // column pass
-                const f2v m = u.xy * gxy[r][j];
+                const f4v u = lerp4(Ua[j], b0[r], Ub[j], b1[r]);      // column pass
                 // src/fastguidedfilter.cpp:204: mean_a_r.mul(I_r) + mean_a_g.mul(I_g) + mean_a_b.mul(I_b) + mean_b
-                o[r][j] = __fadd_rn(__fadd_rn(__fadd_rn(m.x, m.y), __fmul_rn(u.z, gz[r][j])), u.w);
+                o[r][j] = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(u.x, gx[r][j]), __fmul_rn(u.y, gy[r][j])), __fmul_rn(u.z, gz[r][j])), u.w);
             }
         }
 #pragma unroll
@@ -387,8 +394,7 @@ __global__ __launch_bounds__(256) void k_fgf_apply_wta(const f4v *__restrict__ m
         ob[j] = (unsigned)(ca + 1 < ws ? ca + 1 : ws - 1) * 16u;
         a0[j] = __fsub_rn(1.f, a1[j]);
     }
-    f2v gxy[RB][4];
-    float gz[RB][4];
+    float gx[RB][4], gy[RB][4], gz[RB][4];
     int sy[RB], sy1[RB];
     float b0[RB], b1[RB];
 #pragma unroll
@@ -398,8 +404,7 @@ __global__ __launch_bounds__(256) void k_fgf_apply_wta(const f4v *__restrict__ m
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const f4v g = g1[(size_t)y * W + x0 + j];
-            gxy[r][j] = g.xy;
-            gz[r][j] = g.z;
+            gx[r][j] = g.x; gy[r][j] = g.y; gz[r][j] = g.z;
         }
         lin_src(y, hs, H, sy[r], b1[r]);
         sy1[r] = sy[r] + 1 < hs ? sy[r] + 1 : hs - 1;
@@ -411,12 +416,20 @@ __global__ __launch_bounds__(256) void k_fgf_apply_wta(const f4v *__restrict__ m
     for (int r = 0; r < RB; ++r)
 #pragma unroll
         for (int j = 0; j < 4; ++j) { mc[r][j] = __builtin_inff(); md[r][j] = 0; }
+    auto lerp4 = [](f4v s0, float w0, f4v s1, float w1) -> f4v {   // S0*w0 + S1*w1 per component, fp32, no FMA
+        f4v r;
+        r.x = __fadd_rn(__fmul_rn(s0.x, w0), __fmul_rn(s1.x, w1));
+        r.y = __fadd_rn(__fmul_rn(s0.y, w0), __fmul_rn(s1.y, w1));
+        r.z = __fadd_rn(__fmul_rn(s0.z, w0), __fmul_rn(s1.z, w1));
+        r.w = __fadd_rn(__fmul_rn(s0.w, w0), __fmul_rn(s1.w, w1));
+        return r;
+    };
     auto hrow = [&](int d, int row, f4v *U) {
         size_t roff = (((size_t)d * hs + row) * ws) * sizeof(f4v);
         asm volatile("" : "+s"(roff));
         const char *mr = (const char *)mab + roff;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) U[j] = *(const f4v *)(mr + oa[j]) * a0[j] + *(const f4v *)(mr + ob[j]) * a1[j];
+        for (int j = 0; j < 4; ++j) U[j] = lerp4(*(const f4v *)(mr + oa[j]), a0[j], *(const f4v *)(mr + ob[j]), a1[j]);
     };
     for (int d = dbeg; d < dend; ++d) {
         const int dg = d_begin + d;
@@ -433,9 +446,8 @@ __global__ __launch_bounds__(256) void k_fgf_apply_wta(const f4v *__restrict__ m
             }
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const f4v u = Ua[j] * b0[r] + Ub[j] * b1[r];
-                const f2v m = u.xy * gxy[r][j];
-                const float q = __fadd_rn(__fadd_rn(__fadd_rn(m.x, m.y), __fmul_rn(u.z, gz[r][j])), u.w);
+                const f4v u = lerp4(Ua[j], b0[r], Ub[j], b1[r]);
+                const float q = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(u.x, gx[r][j]), __fmul_rn(u.y, gy[r][j])), __fmul_rn(u.z, gz[r][j])), u.w);
                 if (q < mc[r][j]) { mc[r][j] = q; md[r][j] = dg; }
             }
         }
@@ -510,8 +522,10 @@ void launch_fgf_apply_wta(hipStream_t s, const float4 *g1, int W, int H, int Dlo
     const int ws = W / sub, hs = H / sub, n = W * H;
     hipLaunchKernelGGL(k_fgf_key_init, dim3((n + 255) / 256), dim3(256), 0, s, keys, n);
     const int dchunk = Dloc < 32 ? Dloc : 32;
-    // two rows per thread: 186 VGPRs, two waves per SIMD (four rows: 312 registers, one wave, 15 % slower; loading each
-    // distinct model column once per row instead of once per pixel: 25 % slower - the duplicates coalesce in the L1)
+    // two rows per thread, plain fp32 arithmetic: 134 VGPRs, three waves per SIMD -> 0.75 ms per 1080p x 256 volume.
+    // Measured alternatives: four rows 1.00 ms, one row 1.35 ms; packed-fp32 vector arithmetic (186 VGPRs) 0.98 ms;
+    // loading every distinct model column once per row instead of once per pixel and tap 0.87 ms (the duplicate
+    // addresses coalesce in the L1, the extra control flow does not pay).
     constexpr int rb = 2;
     const int yshift = (sub / 2) % rb;
     dim3 gf((W / 4 + 255) / 256, (H + yshift + rb - 1) / rb, (Dloc + dchunk - 1) / dchunk);
