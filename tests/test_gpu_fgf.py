@@ -91,6 +91,24 @@ def test_fgf_virtual_volume_equals_materialised(psm, oracle, W):
             assert de.lDisMap.shape == (H, W)
 
 
+def test_fgf_applied_twice(psm, oracle):
+    """A second psm_cost_filter_fgf filters the (virtual) result of the first one: it is materialised first."""
+    from primestereomatch_amd import synth
+    H, W, D, s = 40, 56, 3, 4
+    l, r, _ = synth.make_pair(W, H, D, 8)
+    lf = oracle.u8_to_f32(l)
+    setup = oracle.fgf_setup(lf, s)
+    once = oracle.pipeline_fgf(l, r, D, s=s, threads=2, want_volumes=True)["lvol"]
+    twice = np.stack([oracle.fgf_filter(lf, setup, once[d], s) for d in range(D)])
+    with psm.DispEst(l, r, D) as de:
+        de.CostConst_GPU()
+        de.CostFilter_FGF_GPU()
+        de.CostFilter_FGF_GPU()
+        assert np.array_equal(de.download_volume(0), twice)
+        de.DispSelect_GPU()
+        assert np.array_equal(de.lDisMap, oracle.wta(twice))
+
+
 def test_fgf_harness_metric(psm, golden):
     """Headless StereoMatch::compute with the snapshot's live branch (CostFilter_FGF, subsample_rate 4)."""
     from primestereomatch_amd import harness
