@@ -51,9 +51,9 @@ enum {
     PSM_OPT_PROFILE = 2,        /* 1: bracket every kernel launch with hipEvents              */
     PSM_OPT_SEG_ROWS = 3,       /* rows per y-segment of the marching kernels (0 = auto)      */
     PSM_OPT_WAVES = 4,          /* waves (disparity slices) per workgroup: 1,2,4,8            */
-    PSM_OPT_FLAGS = 5           /* tuning bits: 2,4 = block traversal order of stage A; 8/64 = alternative CVC
-                                   kernels; 16 = two-stage guided filter instead of the fused one; 32 =
-                                   single-wave fused filter; 128 = psm_cost_construct always writes the cost
+    PSM_OPT_FLAGS = 5           /* tuning bits: 1 = nontemporal stores in the two-stage filter; 2,4 = block traversal
+                                   order of its stage A; 64 = plain (4-byte store) CVC kernel; 16 = two-stage guided
+                                   filter instead of the fused one; 128 = psm_cost_construct always writes the cost
                                    volumes (default: they stay virtual and the fused filter builds the costs
                                    on the fly; any other reader materialises them first); 256 = two-pass
                                    guidance kernels; 512 = two-columns-per-lane variant of the fused filter

@@ -201,8 +201,8 @@ int run_prep(psm_ctx *c)
     return 0;
 }
 
-// The 16 B/voxel (a0,a1,a2,b) scratch is only needed by the two-stage filter, the single-wave fused
-// kernel's border bands, psm_filter_stage_a and psm_box8_volume: allocate it on first use.
+// The 16 B/voxel (a0,a1,a2,b) scratch is only needed by the two-stage filter, psm_filter_stage_a and
+// psm_box8_volume: allocate it on first use.
 int ensure_ab(psm_ctx *c)
 {
     if (c->ab) return 0;
@@ -438,7 +438,7 @@ int psm_cost_construct(psm_ctx *c)
     c->fgf_virtual[0] = c->fgf_virtual[1] = 0;   // a new cost volume replaces whatever was pending
     // Lazy cost volume: when the fused filter will consume the costs (float mode, marching kernels,
     // fusion not disabled) they are built inside that kernel and never written to HBM.
-    const bool lazy = c->dtype == PSM_F32 && c->opt_variant == 0 && !(c->march.flags & (16 | 32 | 128)) && c->H >= 8;
+    const bool lazy = c->dtype == PSM_F32 && c->opt_variant == 0 && !(c->march.flags & (16 | 128)) && c->H >= 8;
     for (int s = 0; s < 2; ++s) {
         if (c->dtype == PSM_U8) {
             Prof p(c, PSM_K_CVC);
@@ -475,7 +475,7 @@ static int filter_side(psm_ctx *c, int side, bool stage_b)
     if (!fused && materialize(c, side)) return 1;
     // flag 512: the two-columns-per-lane form of the producer/consumer kernel (k_cvf_pc2: 31 % fewer VALU
     // instructions per voxel but only two waves per SIMD; measured slower, kept as a tested variant - DESIGN.md 4.2)
-    const bool pc2 = fused && (c->march.flags & 512) && !(c->march.flags & 32) && (W & 3) == 0 && W >= 8;
+    const bool pc2 = fused && (c->march.flags & 512) && (W & 3) == 0 && W >= 8;
     if (pc2) {
         {
             Prof p(c, PSM_K_GUIDE);
@@ -500,7 +500,7 @@ static int filter_side(psm_ctx *c, int side, bool stage_b)
         return check_launch(c, "cvf (fused, two columns per lane)");
     }
     if (fused) {
-        if (!(c->march.flags & 32) && c->raw_rows[side] != psm_ctx::RAW_ALL) {
+        if (c->raw_rows[side] != psm_ctx::RAW_ALL) {
             // producer/consumer kernel on a virtual cost volume: nothing is read from vol[side], so the
             // filtered volume is written straight into it
             {
@@ -510,38 +510,15 @@ static int filter_side(psm_ctx *c, int side, bool stage_b)
             c->raw_rows[side] = psm_ctx::RAW_ALL;   // vol[side] now holds real (filtered) data
             return check_launch(c, "cvf (fused, lazy costs)");
         }
+        // producer/consumer kernel reading a materialised cost volume: out of place, all rows in one launch
         if (ensure_spare(c)) return 1;
         float *out = c->spare;
-        if (!(c->march.flags & 32)) {
-            // producer/consumer kernel reading a materialised cost volume: out of place, all rows in one launch
+        {
             Prof p(c, PSM_K_CVF_F);
             launch_cvf_fused(c->stream, c->march, fv, out, c->g[side], W, H, c->Dloc, 0, H, c->g[1 - side].g1, c->d0, 0);
-        } else {
-            // single-wave fused kernel: rows 4 .. H-4 only; the border rows, whose second box filter reflects
-            // model rows, go through the two-stage kernels on thin bands (7 model rows, 4+3 outputs)
-            if (materialize(c, side) || ensure_ab(c)) return 1;
-            {
-                Prof p(c, PSM_K_CVF_A);
-                if (H >= 14) {
-                    launch_cvf_a(c->stream, 0, c->march, fv, c->ab, c->g[side], W, H, c->Dloc, 0, 7);
-                    launch_cvf_a(c->stream, 0, c->march, fv, c->ab, c->g[side], W, H, c->Dloc, H - 7, H);
-                } else {
-                    launch_cvf_a(c->stream, 0, c->march, fv, c->ab, c->g[side], W, H, c->Dloc, 0, H);
-                }
-            }
-            {
-                Prof p(c, PSM_K_CVF_B);
-                launch_cvf_b(c->stream, 0, c->march, c->ab, out, c->g[side], W, H, c->Dloc, 0, 4);
-                launch_cvf_b(c->stream, 0, c->march, c->ab, out, c->g[side], W, H, c->Dloc, H - 3 > 4 ? H - 3 : 4, H);
-            }
-            {
-                Prof p(c, PSM_K_CVF_F);
-                launch_cvf_fused(c->stream, c->march, fv, out, c->g[side], W, H, c->Dloc, 4, H - 3, c->g[1 - side].g1, c->d0, 0);
-            }
         }
         c->spare = fv;          // ping-pong: the filtered volume becomes vol[side]
         c->vol[side] = out;
-        c->raw_rows[side] = psm_ctx::RAW_ALL;   // vol[side] now holds real (filtered) data
         return check_launch(c, "cvf (fused)");
     }
     if (ensure_ab(c)) return 1;

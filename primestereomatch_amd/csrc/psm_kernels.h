@@ -21,8 +21,8 @@ struct Guidance {
 struct March {       // geometry of the marching kernels
     int seg_rows;    // output rows per y-segment (0 = auto)
     int waves;       // waves (= disparity slices) per workgroup: 1,2,4,8
-    int flags;       // bit 0: nontemporal stores of 4-byte outputs; bits 1-2: block traversal order;
-                     // bit 3: 16-byte-store CVC kernel
+    int flags;       // PSM_OPT_FLAGS (include/primesm_hip.h): bit 0 nontemporal stores of 4-byte outputs, bits 1-2
+                     // block traversal order of stage A, bit 6 plain CVC kernel, ...
 };
 
 // image -> g1 (planarise, scale, gray, x-gradient).  src: device copy of the interleaved image.

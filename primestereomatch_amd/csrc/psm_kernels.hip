@@ -256,44 +256,6 @@ __global__ __launch_bounds__(256) void k_cvc(const float4 *__restrict__ base, co
     }
 }
 
-// Four consecutive pixels per thread -> one 16-byte store per lane: a wave then writes whole
-// 128-byte lines in one request and the L2 does not fill them from HBM first (dword stores did:
-// k_cvc read as many bytes as it wrote).  Needs W % 4 == 0.
-template <bool RIGHT>
-__global__ __launch_bounds__(256) void k_cvc4(const float4 *__restrict__ base, const float4 *__restrict__ other,
-                                             float *__restrict__ vol, int W, int H, int d_begin, int Dloc, int y0)
-{
-    int x = (blockIdx.x * blockDim.x + threadIdx.x) * 4, y = blockIdx.y + y0;
-    int dl0 = blockIdx.z * CVC_DC;
-    if (x >= W) return;
-    const size_t HW = (size_t)H * W;
-    const size_t row = (size_t)y * W;
-    float4 a[4];
-    float cb[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        a[j] = base[row + x + j];
-        cb[j] = cost_border(a[j]);
-    }
-#pragma unroll
-    for (int k = 0; k < CVC_DC; ++k) {
-        int dl = dl0 + k;
-        if (dl >= Dloc) break;
-        int d = d_begin + dl;
-        float c[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            int xx = x + j;
-            if (RIGHT) {
-                if (xx < W - d) c[j] = cost_pair(a[j], other[row + xx + d]); else c[j] = cb[j];
-            } else {
-                if (xx >= d) c[j] = cost_pair(a[j], other[row + xx - d]); else c[j] = cb[j];
-            }
-        }
-        *reinterpret_cast<float4 *>(vol + (size_t)dl * HW + row + x) = make_float4(c[0], c[1], c[2], c[3]);
-    }
-}
-
 // One pixel per lane for the (coalesced) loads and the arithmetic, but the eight cost rows of a wave
 // are parked in LDS and written back with 16 bytes per lane: one store instruction then covers four
 // 256-byte row pieces, each two complete cache lines, instead of four 64-byte partial writes per
@@ -346,8 +308,7 @@ void launch_cvc(hipStream_t s, const float4 *g1_base, const float4 *g1_other, fl
         if (right) hipLaunchKernelGGL(KERNEL<true>, grid, dim3(256), 0, s, g1_base, g1_other, vol, W, H, d_begin, Dloc, ybeg); \
         else hipLaunchKernelGGL(KERNEL<false>, grid, dim3(256), 0, s, g1_base, g1_other, vol, W, H, d_begin, Dloc, ybeg);      \
     }
-    if (!(flags & 64) && !(flags & 8) && (W & 3) == 0) PSM_LAUNCH_CVC(k_cvc_t, (W + 255) / 256)
-    else if ((flags & 8) && (W & 3) == 0) PSM_LAUNCH_CVC(k_cvc4, (W / 4 + 255) / 256)
+    if (!(flags & 64) && (W & 3) == 0) PSM_LAUNCH_CVC(k_cvc_t, (W + 255) / 256)
     else PSM_LAUNCH_CVC(k_cvc, (W + 255) / 256)
 #undef PSM_LAUNCH_CVC
 }
@@ -610,131 +571,11 @@ __global__ __launch_bounds__(256) void k_cvf_b(const float4 *__restrict__ ab, fl
 #undef PSM_ISSUE_B
 }
 
-// ---- fused guided filter: p -> q without the (a0,a1,a2,b) round trip through HBM ----------------
-// Stage A and stage B chained inside one wave.  Lane l of a wave whose first output column is x0
-//   reads the input column      x0 - 8 + l   (p, g1)
-//   owns the linear model at    x0 - 4 + l   (window sums of lanes l..l+7, solve -> a0,a1,a2,b)
-//   owns the output column      x0     + l   (window sums of the models of lanes l..l+7)
-// so 48 of the 64 lanes produce outputs (two 7-column halos).  Rows work the same way: the model
-// rows trail the input rows by 3 and the output rows trail the model rows by 3; the second tree
-// starts once 8 model rows exist.  The volume is read once and written once (8 B/voxel instead of
-// 40); the 16 B/voxel store that bounded stage A (and the vmcnt it tied up) is gone.
-// BORDER_REFLECT_101 of the (a,b) planes, which the second box filter sees at the image border:
-//   * columns: a lane whose model column falls outside the image takes the model of the mirrored
-//     column from the lane that owns it (one extra cross-lane gather, only in border strips);
-//   * rows: this kernel only produces output rows 4 .. H-4, whose windows need no reflected model
-//     row; rows 0..3 and H-3..H-1 are produced by the unfused kernels on two thin bands.
-constexpr int OUT_FUSED = 48;
-constexpr int XF_COLS = 4 * OUT_FUSED;  // 192 output columns = 6 full lines per workgroup
-
-template <bool VEC4>
-__global__ __launch_bounds__(256) void k_cvf_fused(const float *__restrict__ vin, float *__restrict__ vout,
-                                                  const float4 *__restrict__ G1, const float4 *__restrict__ G2,
-                                                  const float4 *__restrict__ G3, const float2 *__restrict__ G4,
-                                                  int W, int H, int Dloc, int ngroups, int nsegs, int seg_rows,
-                                                  int ybeg, int yend)
-{
-    __shared__ __attribute__((aligned(16))) float lds[2][4 * XF_COLS];
-    int id = blockIdx.x;
-    const int g = id % ngroups, rest = id / ngroups;
-    const int d = rest % Dloc, seg = rest / Dloc;
-    if (seg >= nsegs) return;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int xg = g * XF_COLS;
-    const int x0 = xg + wave * OUT_FUSED;
-    const int ci = r101c(x0 - 8 + lane, W);          // input column
-    const int xa = x0 - 4 + lane;                    // model column (may be outside the image)
-    const int xac = xa < 0 ? 0 : (xa > W - 1 ? W - 1 : xa);
-    const int xb = x0 + lane;                        // output column
-    const int xbc = min(xb, W - 1);
-    const int y0 = ybeg + seg * seg_rows, y1 = min(yend, y0 + seg_rows);
-    const int i1 = ((lane + 1) & 63) << 2, i2 = ((lane + 2) & 63) << 2, i4 = ((lane + 4) & 63) << 2;
-    // mirror lane for REFLECT_101 of the model columns (wave-uniform switch)
-    const bool need_mirror = (x0 - 4 < 0) || (x0 + 59 > W - 1);
-    int ml = r101(xa, W) - (x0 - 4);
-    ml = ml < 0 ? 0 : (ml > 63 ? 63 : ml);
-    const int im = ml << 2;
-
-    const size_t HW = (size_t)H * W;
-    const float *vd = vin + (size_t)d * HW;
-    float *od = vout + (size_t)d * HW;
-    VTree ta0 = {}, ta1 = {}, ta2 = {}, ta3 = {}, tb0 = {}, tb1 = {}, tb2 = {}, tb3 = {};
-    const int n = (y1 - y0) + 14;
-    const int ybase = y0 - 8;   // input row of step 0; model row = ybase+s-3; output row = ybase+s-6
-
-    float pin[4];
-    float4 gin[4], o2[4], o3[4], o1[4];
-    float2 o4[4];
-#define PSM_ISSUE_F(SLOT, STEP)                                                         \
-    {                                                                                   \
-        const size_t off_ = (size_t)r101c(ybase + (STEP), H) * W + ci;                  \
-        pin[SLOT] = vd[off_];                                                           \
-        gin[SLOT] = G1[off_];                                                           \
-        int ya_ = ybase + (STEP) - 3;                                                   \
-        ya_ = ya_ < 0 ? 0 : (ya_ > H - 1 ? H - 1 : ya_);                                \
-        const size_t oa_ = (size_t)ya_ * W + xac;                                       \
-        o2[SLOT] = G2[oa_];                                                             \
-        o3[SLOT] = G3[oa_];                                                             \
-        o4[SLOT] = G4[oa_];                                                             \
-        int yb_ = ybase + (STEP) - 6;                                                   \
-        yb_ = yb_ < 0 ? 0 : (yb_ > H - 1 ? H - 1 : yb_);                                \
-        o1[SLOT] = G1[(size_t)yb_ * W + xbc];                                           \
-    }
-    PSM_ISSUE_F(0, 0) __builtin_amdgcn_sched_barrier(0);
-    PSM_ISSUE_F(1, 1) __builtin_amdgcn_sched_barrier(0);
-    PSM_ISSUE_F(2, 2) __builtin_amdgcn_sched_barrier(0);
-    for (int i = 0; i < n; i += 4) {
-        float qb[4];
-#define PSM_STEP_F(K)                                                                               \
-    {                                                                                               \
-        const int step = i + K;                                                                     \
-        PSM_ISSUE_F((K + 3) & 3, step + 3)                                                          \
-        const float p = pin[K];                                                                     \
-        double h0 = hsum8(p, i1, i2, i4);                                                           \
-        double h1 = hsum8(__fmul_rn(gin[K].x, p), i1, i2, i4);                                      \
-        double h2 = hsum8(__fmul_rn(gin[K].y, p), i1, i2, i4);                                      \
-        double h3 = hsum8(__fmul_rn(gin[K].z, p), i1, i2, i4);                                      \
-        double n0 = vstep<K>(ta0, h0), n1 = vstep<K>(ta1, h1), n2 = vstep<K>(ta2, h2), n3 = vstep<K>(ta3, h3); \
-        float4 r = solve_ab(box_out(n0), box_out(n1), box_out(n2), box_out(n3), o2[K], o3[K], o4[K]); \
-        if (need_mirror) {                                                                          \
-            r.x = lane_get(r.x, im); r.y = lane_get(r.y, im); r.z = lane_get(r.z, im); r.w = lane_get(r.w, im); \
-        }                                                                                           \
-        double e0 = hsum8(r.x, i1, i2, i4), e1 = hsum8(r.y, i1, i2, i4);                            \
-        double e2 = hsum8(r.z, i1, i2, i4), e3 = hsum8(r.w, i1, i2, i4);                            \
-        /* rows fed before step 7 are not models yet; they have left the window by step 14 */      \
-        double m0 = vstep<K>(tb0, e0), m1 = vstep<K>(tb1, e1), m2 = vstep<K>(tb2, e2), m3 = vstep<K>(tb3, e3); \
-        qb[K] = recombine(box_out(m0), box_out(m1), box_out(m2), box_out(m3), o1[K]);               \
-        __builtin_amdgcn_sched_barrier(0);                                                          \
-    }
-        PSM_STEP_F(0) PSM_STEP_F(1) PSM_STEP_F(2) PSM_STEP_F(3)
-#undef PSM_STEP_F
-        // merged, line-aligned store of the four output rows of this batch
-        float *buf = lds[(i >> 2) & 1];
-#pragma unroll
-        for (int k = 0; k < 4; ++k)
-            if (lane < OUT_FUSED) buf[k * XF_COLS + wave * OUT_FUSED + lane] = qb[k];
-        __syncthreads();
-        const int step = i + wave;
-        if (step >= 14 && step < n) {
-            float *row = od + (size_t)(ybase + step - 6) * W + xg;
-            if (VEC4) {
-                const int c = lane * 4;
-                if (lane < XF_COLS / 4 && xg + c < W)
-                    *reinterpret_cast<float4 *>(row + c) = *reinterpret_cast<const float4 *>(buf + wave * XF_COLS + c);
-            } else {
-#pragma unroll
-                for (int c = lane; c < XF_COLS; c += 64)
-                    if (xg + c < W) row[c] = buf[wave * XF_COLS + c];
-            }
-        }
-    }
-#undef PSM_ISSUE_F
-}
-
 // ---- fused guided filter, producer/consumer form ---------------------------------------------------
-// The single-wave fusion above needs both sliding trees in one wave (250 VGPRs, 1-2 waves per SIMD)
-// and is latency bound.  Here the two halves run in DIFFERENT waves of one workgroup and the linear
-// models (a0,a1,a2,b) are handed over through LDS instead of HBM:
+// Stage A and stage B of the guided filter chained without the (a0,a1,a2,b) round trip through HBM (16 B/voxel
+// written and read again by the two-stage kernels).  Both sliding trees in one wave need 250 VGPRs (1-2 waves per
+// SIMD; measured 8.3-9.3 ms per 1080p x 256 volume, latency bound), so the two halves run in DIFFERENT waves of
+// one workgroup and the linear models are handed over through LDS:
 //   producer waves ("A"): cost p (read, or built from the g1 planes), g1 -> window sums -> solve -> model rows
 //                         into an LDS ring of PC_RING batches of four rows
 //   consumer waves ("B"): model rows from the ring (REFLECT_101 of the model planes = ring index arithmetic,
@@ -1241,7 +1082,7 @@ void launch_cvf_fused(hipStream_t s, March m, const float *vin, float *vout, Gui
     }
     if (seg_rows > rows) seg_rows = rows;
     const int nsegs = (rows + seg_rows - 1) / seg_rows;
-    if (!(m.flags & 32)) {
+    {
         const int ngroups = (W + PC_COLS - 1) / PC_COLS;
         const int nblocks = 8 * ((ngroups * nsegs + 7) / 8) * Dloc;
         const dim3 blk(64 * (PC_NA + PC_NB));
@@ -1254,16 +1095,7 @@ void launch_cvf_fused(hipStream_t s, March m, const float *vin, float *vout, Gui
         else if (cvc_mode == 2) { if (v4) PSM_LAUNCH_PC(true, 2); else PSM_LAUNCH_PC(false, 2); }
         else { if (v4) PSM_LAUNCH_PC(true, 0); else PSM_LAUNCH_PC(false, 0); }
 #undef PSM_LAUNCH_PC
-        return;
     }
-    const int ngroups = (W + XF_COLS - 1) / XF_COLS;
-    const int nblocks = ngroups * Dloc * nsegs;
-    if ((W & 3) == 0)
-        hipLaunchKernelGGL(k_cvf_fused<true>, dim3(nblocks), dim3(256), 0, s, vin, vout, (const float4 *)gd.g1, (const float4 *)gd.g2,
-                           (const float4 *)gd.g3, (const float2 *)gd.g4, W, H, Dloc, ngroups, nsegs, seg_rows, ybeg, yend);
-    else
-        hipLaunchKernelGGL(k_cvf_fused<false>, dim3(nblocks), dim3(256), 0, s, vin, vout, (const float4 *)gd.g1, (const float4 *)gd.g2,
-                           (const float4 *)gd.g3, (const float2 *)gd.g4, W, H, Dloc, ngroups, nsegs, seg_rows, ybeg, yend);
 }
 
 void launch_box8(hipStream_t s, int variant, March m, const float *vol, float *out, int W, int H, int Dloc)
