@@ -9,14 +9,16 @@
 // Reference arithmetic followed: src/CVC.cpp:18-46,122-179, src/CVF.cpp:44-165,
 // src/DispSel.cpp:83-109, src/PP.cpp:17-50 (paths in the reference repository).
 //
-// Kernel design (DESIGN.md "Kernels"): the guided filter's two box-filter rounds are "marching"
-// kernels: one wave owns 64 adjacent columns of one disparity slice (56 outputs + 8 halo) and
-// walks down the rows.  Horizontal 8-tap sums are built with three cross-lane exchanges
-// (distance 1, 2, 4: a sliding balanced tree, 3 fp64 adds per output), vertical sums with a
-// register-resident sliding tree (7 doubles of state per channel, 3 fp64 adds per output).
-// Every voxel is loaded from HBM once per stage with coalesced row reads; the waves of a
-// workgroup process different slices of the same pixels so the d-invariant guidance is served
-// from L1/L2.  MFMA is not used: nothing here is a dense contraction.
+// Kernel design: the guided filter's two box-filter rounds are "marching" kernels: one wave
+// owns 64 adjacent columns of one disparity slice (up to 57 outputs + 7 halo) and walks down the rows.
+// Horizontal 8-tap sums are built with three cross-lane exchanges (distance 1, 2, 4: a sliding balanced
+// tree, 3 fp64 adds per output), vertical sums with a register-resident sliding tree (7 doubles of state
+// per channel, 3 fp64 adds per output).  The product path is k_cvf_pc: cost build + both filter rounds in
+// one kernel, producer and consumer waves coupled through an LDS ring, so a voxel costs one 4-byte store
+// and no volume read.  The two-stage kernels (k_cvc_t, k_cvf_a, k_cvf_b), the plain box filter (k_box8) and
+// the direct per-voxel kernels are the fallback / diagnostic / cross-check forms of the same arithmetic.
+// The Fast Guided Filter row lives in psm_fgf.hip, the two-columns-per-lane experiment in psm_pc2.hip.
+// MFMA is not used: nothing here is a dense contraction.
 #include "psm_kernels.h"
 #include "psm_cost.h"
 #include "psm_dev.h"
