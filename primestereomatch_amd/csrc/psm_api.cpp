@@ -471,11 +471,12 @@ static int filter_side(psm_ctx *c, int side, bool stage_b)
         fv = c->fvol;
         launch_u8_to_f32(c->stream, (const uint8_t *)c->vol[side], fv, V);
     }
-    const bool fused = stage_b && c->dtype == PSM_F32 && c->opt_variant == 0 && !(c->march.flags & 16) && H >= 8;
+    // (8-bit mode: the float copy of the volume goes through the same fused kernel and is re-quantised afterwards)
+    const bool fused = stage_b && c->opt_variant == 0 && !(c->march.flags & 16) && H >= 8;
     if (!fused && materialize(c, side)) return 1;
     // flag 512: the two-columns-per-lane form of the producer/consumer kernel (k_cvf_pc2: 31 % fewer VALU
     // instructions per voxel but only two waves per SIMD; measured slower, kept as a tested variant - DESIGN.md 4.2)
-    const bool pc2 = fused && (c->march.flags & 512) && (W & 3) == 0 && W >= 8;
+    const bool pc2 = fused && c->dtype == PSM_F32 && (c->march.flags & 512) && (W & 3) == 0 && W >= 8;
     if (pc2) {
         {
             Prof p(c, PSM_K_GUIDE);
@@ -517,8 +518,12 @@ static int filter_side(psm_ctx *c, int side, bool stage_b)
             Prof p(c, PSM_K_CVF_F);
             launch_cvf_fused(c->stream, c->march, fv, out, c->g[side], W, H, c->Dloc, 0, H, c->g[1 - side].g1, c->d0, 0);
         }
-        c->spare = fv;          // ping-pong: the filtered volume becomes vol[side]
-        c->vol[side] = out;
+        if (c->dtype == PSM_U8) {
+            launch_f32_to_u8(c->stream, out, (uint8_t *)c->vol[side], V);   // q8 = sat_u8(rintf(q * 255))
+        } else {
+            c->spare = fv;          // ping-pong: the filtered volume becomes vol[side]
+            c->vol[side] = out;
+        }
         return check_launch(c, "cvf (fused)");
     }
     if (ensure_ab(c)) return 1;
