@@ -40,7 +40,7 @@ struct psm_ctx {
     size_t raw_bytes = 0;
     int raw_depth = -1;                 // PSM_IMG_* of the staged pair, -1 = nothing uploaded
     Guidance g[2] = {};
-    double *hs9 = nullptr;
+    double *hs9 = nullptr;              // scratch of the two-pass guidance kernels (PSM_OPT_FLAGS 256), allocated on first use
     void *vol[2] = {nullptr, nullptr};  // [Dloc][H][W] float (PSM_F32) or uint8 (PSM_U8)
     float *fvol = nullptr;              // PSM_U8 only: float work volume of one side
     float *spare = nullptr;             // PSM_F32: output volume of the fused filter (ping-pong with vol[side])
@@ -324,7 +324,6 @@ int psm_create_shard(psm_ctx **out, int width, int height, int max_disp, int d_b
         if (e == hipSuccess) e = hipMalloc(&c->vol[s], V * velem(c));
         if (e == hipSuccess && dtype == PSM_U8) e = hipMalloc((void **)&c->p4[s], HW * 4);
     }
-    if (e == hipSuccess) e = hipMalloc((void **)&c->hs9, 9 * HW * sizeof(double));
     if (e == hipSuccess && dtype == PSM_U8) e = hipMalloc((void **)&c->fvol, V * sizeof(float));
     if (e == hipSuccess) e = hipMalloc((void **)&c->keys, 2 * HW * sizeof(long long));
     if (e == hipSuccess) e = hipMalloc((void **)&c->maps, 2 * HW);
@@ -462,6 +461,7 @@ static int filter_side(psm_ctx *c, int side, bool stage_b)
     const int W = c->W, H = c->H;
     if (!c->have_g1 && run_prep(c)) return 1;  // volume came from psm_upload_volume
     if (fgf_flush(c, side)) return 1;
+    if ((c->march.flags & 256) && !c->hs9) PSM_HIP(c, hipMalloc((void **)&c->hs9, (size_t)9 * W * H * sizeof(double)));
     {
         Prof p(c, PSM_K_GUIDE);
         launch_guidance(c->stream, c->g[side], c->hs9, W, H, (c->march.flags & 256) ? 1 : 0);
