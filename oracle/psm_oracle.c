@@ -125,9 +125,76 @@ void psmo_cvc_build_right(const float *lImg, const float *rImg, const float *lGr
 /* CVF                                                                              */
 /* ------------------------------------------------------------------------------- */
 
+/* Which summation order the box filters use (psmo_set_box_order):
+ *   PSMO_BOX_TREE (default) - the canonical balanced tree of psm_oracle.h (segment independent; what the HIP kernels
+ *                             evaluate bit for bit);
+ *   PSMO_BOX_OCV            - the order OpenCV's own engines execute for a CV_32F boxFilter / blur
+ *                             (modules/imgproc box_filter: RowSum<float,double> + ColumnSum<double,float>):
+ *                             a running sum along each row, s += (double)S[i+k] - (double)S[i], and a running column
+ *                             accumulator SUM over the whole image height, out = (float)((SUM + newest) * scale),
+ *                             SUM = (SUM + newest) - oldest.
+ * Read by every thread of the pipelines; set it before starting one. */
+static int g_box_order = PSMO_BOX_TREE;
+void psmo_set_box_order(int order) { g_box_order = order == PSMO_BOX_OCV ? PSMO_BOX_OCV : PSMO_BOX_TREE; }
+int psmo_get_box_order(void) { return g_box_order; }
+
+/* cv::boxFilter / cv::blur with a k x k kernel on a CV_32F plane in OpenCV's own evaluation order.
+ * anchor = k/2 (the default anchor (-1,-1)), BORDER_REFLECT_101, normalised.
+ *   RowSum<float,double>::operator() (generic branch; OpenCV >= 3.4 special-cases ksize 3 and 5 as a plain
+ *   left-to-right sum per output, which is what `direct_rows` selects):
+ *       s = 0; for i < k: s += (double)S[i];  D[0] = s;  then  s += (double)S[i+k] - (double)S[i];  D[i+1] = s
+ *     on the border-extended row S (FilterEngine pads `anchor` pixels left, k-1-anchor right).
+ *   ColumnSum<double,float>::operator(): SUM = 0; the first k-1 (border-extended) rows are added top to bottom;
+ *     per output row: s0 = SUM + Sp; D = (float)(s0 * scale); SUM = s0 - Sm.   scale = 1./(k*k) (double). */
+static void box_ocv(const float *src, int H, int W, int k, float *dst, double *hs)
+{
+    const int an = k / 2;
+    const double scale = 1. / ((double)k * k);
+    const int direct_rows = (k == 3 || k == 5);
+    double *ext = (double *)malloc((size_t)(W + k) * sizeof(double));
+    for (int y = 0; y < H; ++y) {
+        const float *s = src + (size_t)y * W;
+        double *h = hs + (size_t)y * W;
+        for (int i = 0; i < W + k - 1; ++i) ext[i] = (double)s[r101(i - an, W)];
+        if (direct_rows) {
+            for (int x = 0; x < W; ++x) {
+                double a = ext[x];
+                for (int i = 1; i < k; ++i) a += ext[x + i];
+                h[x] = a;
+            }
+        } else {
+            double a = 0;
+            for (int i = 0; i < k; ++i) a += ext[i];
+            h[0] = a;
+            for (int x = 0; x < W - 1; ++x) {
+                a += ext[x + k] - ext[x];
+                h[x + 1] = a;
+            }
+        }
+    }
+    double *SUM = (double *)calloc((size_t)W, sizeof(double));
+    for (int j = 0; j < k - 1; ++j) {
+        const double *Sp = hs + (size_t)r101(j - an, H) * W;
+        for (int x = 0; x < W; ++x) SUM[x] += Sp[x];
+    }
+    for (int y = 0; y < H; ++y) {
+        const double *Sp = hs + (size_t)r101(y + k - 1 - an, H) * W;
+        const double *Sm = hs + (size_t)r101(y - an, H) * W;
+        float *o = dst + (size_t)y * W;
+        for (int x = 0; x < W; ++x) {
+            double s0 = SUM[x] + Sp[x];
+            o[x] = (float)(s0 * scale);
+            SUM[x] = s0 - Sm[x];
+        }
+    }
+    free(SUM);
+    free(ext);
+}
+
 /* box with caller-provided double scratch (H*W) so threads do not malloc per call */
 static void box8_ws(const float *src, int H, int W, float *dst, double *hs)
 {
+    if (g_box_order == PSMO_BOX_OCV) { box_ocv(src, H, W, 8, dst, hs); return; }
     for (int y = 0; y < H; ++y) {
         const float *s = src + (size_t)y * W;
         double *h = hs + (size_t)y * W;
@@ -273,6 +340,7 @@ static void blur_k(const float *src, int H, int W, int k, float *dst, double *hs
 {
     const int r = k / 2;
     const double scale = 1.0 / (k * k);
+    if (g_box_order == PSMO_BOX_OCV) { box_ocv(src, H, W, k, dst, hs); return; }
     for (int y = 0; y < H; ++y)
         for (int x = 0; x < W; ++x) {
             double a = 0.0;
@@ -975,6 +1043,66 @@ void psmo_fill_inv(uint8_t *dis, const uint8_t *valid, int H, int W)
                 d[x] = d[rFirst];
         }
     }
+}
+
+/* ------------------------------------------------------------------------------- */
+/* weighted-median post-filter ("next" row; src/PP.cpp:145-247 wgtMedian)           */
+/* ------------------------------------------------------------------------------- */
+
+#define MED_SZ 19   /* include/PP.h:12 */
+#define SIG_CLR 0.1 /* include/PP.h:13 (double) */
+#define SIG_DIS 9   /* include/PP.h:14 (int) */
+
+void psmo_wgt_median(const float *img, uint8_t *dis, const uint8_t *valid, int H, int W, int maxDis, int right)
+{
+    /* src/PP.cpp:155-196 (left map) / 199-245 (right map: the two distances go through sqrt, :218,:223).
+     * The map is updated IN PLACE in raster order, so a filtered pixel sees the already filtered pixels
+     * above / to the left of it (and, through the modulo wrap, the still unfiltered ones at the far end). */
+    const int wndR = MED_SZ / 2;
+    float *disHist = (float *)malloc((size_t)(maxDis > 0 ? maxDis : 1) * sizeof(float));
+    for (int y = 0; y < H; ++y) {
+        uint8_t *disData = dis + (size_t)y * W;
+        const float *p = img + (size_t)y * W * 3;
+        const uint8_t *validData = valid + (size_t)y * W;
+        for (int x = 0; x < W; ++x) {
+            if (validData[x] != 0) continue; /* just filter invalid pixels */
+            memset(disHist, 0, sizeof(float) * (size_t)maxDis);
+            float sumWgt = 0.0f;
+            for (int wy = -wndR; wy <= wndR; ++wy) {
+                int qy = (y + wy + H) % H;
+                const float *q = img + (size_t)qy * W * 3;
+                const uint8_t *qDisData = dis + (size_t)qy * W;
+                for (int wx = -wndR; wx <= wndR; ++wx) {
+                    int qx = (x + wx + W) % W;
+                    int qDep = qDisData[qx];
+                    if (qDep != 0) {
+                        float disWgt = (float)(wx * wx + wy * wy);
+                        if (right) disWgt = sqrtf(disWgt); /* sqrt(float) of <cmath>: float */
+                        float d0 = p[3 * x] - q[3 * qx], d1 = p[3 * x + 1] - q[3 * qx + 1], d2 = p[3 * x + 2] - q[3 * qx + 2];
+                        float clrWgt = d0 * d0 + d1 * d1 + d2 * d2;
+                        if (right) clrWgt = sqrtf(clrWgt);
+                        /* -disWgt / (SIG_DIS*SIG_DIS): float / int -> float; clrWgt / (SIG_CLR*SIG_CLR): float / double
+                         * -> double; exp(double) of the host libm; result narrowed to float */
+                        float biWgt = (float)exp((double)(-disWgt / (SIG_DIS * SIG_DIS)) - (double)clrWgt / (SIG_CLR * SIG_CLR));
+                        disHist[qDep] += biWgt;
+                        sumWgt += biWgt;
+                    }
+                }
+            }
+            float halfWgt = sumWgt / 2.0f;
+            sumWgt = 0.0f;
+            int filterDep = 0;
+            for (int d = 0; d < maxDis; ++d) {
+                sumWgt += disHist[d];
+                if (sumWgt >= halfWgt) {
+                    filterDep = d;
+                    break;
+                }
+            }
+            disData[x] = (uint8_t)filterDep; /* set new disparity */
+        }
+    }
+    free(disHist);
 }
 
 /* ------------------------------------------------------------------------------- */

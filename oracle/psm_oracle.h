@@ -63,6 +63,17 @@ void psmo_cvc_build_right(const float *lImg, const float *rImg, const float *lGr
  * H, W >= 8. */
 void psmo_box8(const float *src, int H, int W, float *dst);
 
+/* Summation order of every box filter below (psmo_box8, the guided filters, the pipelines):
+ * PSMO_BOX_TREE = the canonical order above (default; what the HIP kernels evaluate bit for bit);
+ * PSMO_BOX_OCV  = the order OpenCV's engines execute for CV_32F (RowSum<float,double>: running sum along the
+ * row, s += (double)S[i+k] - (double)S[i]; ColumnSum<double,float>: running column accumulator over the whole image,
+ * out = (float)((SUM + newest) * (1./(k*k))), SUM = (SUM + newest) - oldest) - i.e. what the reference binary executes
+ * at src/CVF.cpp:50,63,82,88,158,160 when OpenCV's generic (non-IPP) path runs.  Both orders sum the same 64 taps
+ * in double; they differ only where a double addition rounds.  Process-global: set it before starting a pipeline. */
+enum { PSMO_BOX_TREE = 0, PSMO_BOX_OCV = 1 };
+void psmo_set_box_order(int order);
+int psmo_get_box_order(void);
+
 /* src/CVF.cpp:44-70 CVF::preprocess.  rgb: 3 planes, mean: 3 planes, var: 6 planes
  * (order 00,01,02,11,12,22), each H*W floats, stored back to back. */
 void psmo_cvf_preprocess(const float *img, int H, int W, float *rgb, float *mean, float *var);
@@ -142,6 +153,17 @@ void psmo_lr_check(const uint8_t *ldis, const uint8_t *rdis, int H, int W, uint8
                    uint8_t *rvalid);
 /* src/PP.cpp:52-143 fillInv (one map at a time) */
 void psmo_fill_inv(uint8_t *dis, const uint8_t *valid, int H, int W);
+
+/* ---- "next" row: weighted-median post-filter (plain bilateral-histogram form, not JointWMF) ------ */
+/* src/PP.cpp:145-247 wgtMedian, one map at a time: every pixel with valid == 0 is replaced by the weighted median of
+ * the disparities in its 19 x 19 window (MED_SZ, include/PP.h:12; modulo wrap at the image border; pixels of
+ * disparity 0 do not vote), weights exp(-disWgt/81 - clrWgt/0.01) (SIG_DIS 9, SIG_CLR 0.1) with
+ *   right == 0 (left map,  :169-175): disWgt = wx^2+wy^2,        clrWgt = |p-q|^2
+ *   right != 0 (right map, :216-224): disWgt = sqrt(wx^2+wy^2),  clrWgt = sqrt(|p-q|^2)
+ * img: H x W x 3 float (the CV_32FC3 image PP::processDM receives), dis: H x W, updated IN PLACE in raster order
+ * (later pixels see earlier results - the sequential semantics of the reference's single-threaded form).
+ * exp is the host libm's double exp, narrowed to float, as in the reference. */
+void psmo_wgt_median(const float *img, uint8_t *dis, const uint8_t *valid, int H, int W, int maxDis, int right);
 
 /* ---- evaluation recipe of the harness (src/StereoMatch.cpp:275-311) -------------- */
 /* disp: raw WTA map; gt: ground-truth map (disparity*scale); mask: 0/255 or NULL.

@@ -238,3 +238,34 @@ def pipeline_fgf(l_bgr, r_bgr, D, s=4, threads=8, want_volumes=False):
     if want_volumes:
         out["lvol"], out["rvol"] = lv, rv
     return out
+
+
+BOX_TREE, BOX_OCV = 0, 1
+
+
+class box_order:
+    """Context manager: run the enclosed oracle calls with the given box-filter summation order
+    (BOX_TREE = canonical balanced tree, BOX_OCV = OpenCV's running RowSum/ColumnSum order)."""
+
+    def __init__(self, order):
+        self.order = int(order)
+
+    def __enter__(self):
+        lib().psmo_get_box_order.restype = C.c_int
+        self.prev = lib().psmo_get_box_order()
+        lib().psmo_set_box_order(self.order)
+        return self
+
+    def __exit__(self, *exc):
+        lib().psmo_set_box_order(self.prev)
+        return False
+
+
+def wgt_median(img_f32, dis, valid, maxDis, right=False):
+    """src/PP.cpp:145-247 wgtMedian for one map (right: the right-map formula with the two sqrt)."""
+    img = _f32(img_f32)
+    d = _u8(dis).copy()
+    v = _u8(valid)
+    H, W = d.shape
+    lib().psmo_wgt_median(_p(img), _p(d), _p(v), H, W, int(maxDis), int(bool(right)))
+    return d
