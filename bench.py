@@ -38,6 +38,21 @@ CONFIGS = {
 ALG_BYTES = {"cvf_fused": 40.0, "cvf_a": 20.0, "cvf_b": 20.0, "cvc": 4.0, "wta": 4.0, "box8": 8.0, "pipeline": 48.0}
 
 
+def spawn_ranks(n):
+    """Re-run this command as n ranks (one per GPU) under torch.distributed.run; returns its exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # the host driver only supports dmabuf IPC (RCCL needs it)
+    env.setdefault("OMP_NUM_THREADS", "8")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -49,7 +64,10 @@ def main():
     ap.add_argument("--variant", type=int, default=0)
     ap.add_argument("--flags", type=int, default=-1, help="PSM_OPT_FLAGS tuning bits (-1: library default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample-d", type=int, default=256, help="disparities in the CPU-baseline sample (default: the whole workload, ~10 s on 8 threads)")
+    ap.add_argument("--cpu-sample-d", type=int, default=0,
+                    help="disparities in the CPU-baseline sample (0 = auto: the whole D at 1080p and below (~10 s on 8 threads), "
+                         "proportionally fewer for larger images)")
+    ap.add_argument("--cpu-wide", action="store_true", help="also time the CPU baseline on min(64, host cores) threads (doubles its run time)")
     ap.add_argument("--force-dist", action="store_true", help="use the torch.distributed path even for N=1")
     ap.add_argument("--exchange", default="allreduce", choices=["allreduce", "allgather", "none"],
                     help="N>1 exchange step: one all_reduce(MIN) of the packed keys (default; ~2x33 MB per rank "
@@ -72,6 +90,14 @@ def main():
     args = ap.parse_args()
 
     N = args.gpus
+    if N < 1:
+        raise SystemExit("bench.py: --gpus must be >= 1")
+    if N > CONFIGS[args.config][2]:
+        raise SystemExit(f"bench.py: --gpus {N} exceeds the {CONFIGS[args.config][2]} disparity slices of config {args.config} (one shard per rank)")
+    if N > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
+        # bare `python bench.py --gpus N`: become the launcher - one rank per GPU under torch.distributed.run on
+        # 127.0.0.1 - and pass rank 0's single JSON line through
+        return spawn_ranks(N)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -83,7 +109,7 @@ def main():
         import torch
         import torch.distributed as dist
         if world != N:
-            raise SystemExit(f"bench.py --gpus {N} needs WORLD_SIZE={N} (got {world}); launch with torch.distributed.run")
+            raise SystemExit(f"bench.py --gpus {N}: WORLD_SIZE={world} in the environment does not match")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
         torch.cuda.set_device(local_rank)
@@ -224,6 +250,32 @@ def main():
     voxels_per_step = 2.0 * W * H * D           # both volumes, all ranks
     value = voxels_per_step / (elapsed / args.steps)
 
+    # ---- per-step times (SURVEY.md 8d asks for the median): each step bracketed by its own synchronisation; the
+    # frame-pipelined N>1 path finishes a frame's exchange one step later, so its steps are only meaningful in bulk ----
+    step_ms = []
+    for _ in range(max(3, min(args.steps, 20))):
+        sync()
+        ts = time.perf_counter()
+        step()
+        sync()
+        step_ms.append(1e3 * (time.perf_counter() - ts))
+    step_ms.sort()
+    median_ms = step_ms[len(step_ms) // 2]
+
+    # ---- PCIe legs the reference's stage timers include (src/StereoMatch.cpp:227-237), never part of `value` ----
+    pcie = None
+    if rank == 0:
+        sync()
+        ts = time.perf_counter()
+        de.setInputImages(l, r)              # H2D of the u8 pair (blocking)
+        h2d = 1e3 * (time.perf_counter() - ts)
+        step(); sync()                       # maps of this pair on the device again
+        ts = time.perf_counter()
+        de.download_maps()                   # D2H of the two u8 maps (blocking)
+        d2h = 1e3 * (time.perf_counter() - ts)
+        pcie = {"h2d_ms": round(h2d, 3), "d2h_ms": round(d2h, 3), "h2d_bytes": int(l.nbytes + r.nbytes), "d2h_bytes": 2 * W * H,
+                "note": "u8 pair in, two u8 maps out; excluded from value"}
+
     # ---- per-kernel device time (hipEvents on the launch stream), separate pass -----------
     de.set_option(capi.PSM_OPT_PROFILE, 1)
     de.reset_kernel_times()
@@ -249,6 +301,8 @@ def main():
     roofline = {"bound": "hbm", "kernel": "k_" + dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
                 "alg_bytes_per_launch": ALG_BYTES[dom] * vox_per_launch, "avg_launch_ms": round(dom_ms, 4),
+                "note": "achieved/frac credit the fused kernel with the staged pipeline's algorithmic bytes (SURVEY.md 8d); "
+                        "its physical HBM rate is traffic_GBs - the kernel is VALU-issue bound, not HBM bound",
                 "pipeline_alg_GBs": round(ALG_BYTES["pipeline"] * value / 1e9, 1),
                 "pipeline_frac": round(ALG_BYTES["pipeline"] * value / 1e9 / HBM_PEAK_GBS, 4)}
     traffic_file = os.path.join(ROOT, "profiles", "traffic.json")
@@ -257,7 +311,9 @@ def main():
             tr = json.load(open(traffic_file))
             key = f"{args.config}:k_{dom}"
             if key in tr and world == 1:
-                roofline["traffic"] = tr[key]    # HBM bytes per launch from rocprofv3 PMC passes
+                roofline["traffic"] = tr[key]    # HBM bytes per launch from rocprofv3 PMC passes (not measured in this run)
+                roofline["traffic_source"] = tr.get("_source", "profiles/traffic.json (rocprofv3 --pmc passes of scripts/gpu_run.sh)")
+                roofline["traffic_GBs"] = round(tr[key] / (dom_ms * 1e-3) / 1e9, 1)   # physical HBM rate of the kernel
         except Exception:
             pass
     for nm, v in kern.items():
@@ -302,7 +358,8 @@ def main():
         from oracle import psm_oracle_py as O   # checker / baseline only - never on the GPU path
         cores = os.cpu_count() or 1
         threads = min(8, cores)                 # MAX_CPU_THREADS (include/ComFunc.h:52)
-        sd = max(2, min(args.cpu_sample_d, D))
+        sd = args.cpu_sample_d if args.cpu_sample_d > 0 else int(256.0 * (1920 * 1080) / (W * H))
+        sd = max(2, min(sd, D))
         tcpu = time.perf_counter()
         res = O.pipeline_f32(l, r, sd, threads=threads)
         tcpu = time.perf_counter() - tcpu
@@ -316,7 +373,7 @@ def main():
         # the same restatement on more host cores (SURVEY.md 8d asks for 8 threads and for the box's core count):
         # context only, the contract's cpu_baseline is the 8-thread figure above
         wide = min(64, cores)
-        if wide > threads:
+        if args.cpu_wide and wide > threads:
             resw = O.pipeline_f32(l, r, sd, threads=wide)
             sw = (resw["cvc_ms"] + resw["cvf_ms"] + resw["dispsel_ms"]) * 1e-3
             cpu["wide"] = {"value": round(2.0 * W * H * sd / sw, 1), "cores": wide}
@@ -332,6 +389,7 @@ def main():
                        "parallelism": "1 GPU" if world == 1 else f"D sharded over {world} ranks + 1 RCCL {args.exchange} of packed minima",
                        "kernel_variant": args.variant, "shard_sim": args.shard_sim},
             "roofline": roofline, "cpu_baseline": cpu, "kernels": kern,
+            "median_ms_per_step": round(median_ms, 4), "pcie": pcie,
         }
         if verified is not None:
             out["verified_vs_single_gpu"] = verified
@@ -346,4 +404,4 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

@@ -43,7 +43,8 @@ enum { PSM_STAGE_CVC = 0, PSM_STAGE_CVF = 1, PSM_STAGE_DISPSEL = 2, PSM_STAGE_PP
        PSM_STAGE_COUNT = 4 };
 /* kernels whose device time can be queried with psm_kernel_time_ms() */
 enum { PSM_K_PREP = 0, PSM_K_CVC = 1, PSM_K_GUIDE = 2, PSM_K_CVF_A = 3, PSM_K_CVF_B = 4,
-       PSM_K_WTA = 5, PSM_K_MERGE = 6, PSM_K_BOX = 7, PSM_K_LRC = 8, PSM_K_CVF_F = 9, PSM_K_FGF = 10, PSM_K_COUNT = 11 };
+       PSM_K_WTA = 5, PSM_K_MERGE = 6, PSM_K_BOX = 7, PSM_K_LRC = 8, PSM_K_CVF_F = 9, PSM_K_FGF = 10, PSM_K_WMF = 11,
+       PSM_K_COUNT = 12 };
 /* options for psm_set_option */
 enum {
     PSM_OPT_ASYNC = 0,          /* 1: stage calls only enqueue; use psm_synchronize()        */
@@ -168,7 +169,21 @@ int psm_lr_check(psm_ctx *ctx, uint8_t *lvalid, uint8_t *rvalid, size_t stride);
  * Modifies the device maps in place; lmap/rmap (optional) receive them. */
 int psm_fill_invalid(psm_ctx *ctx, uint8_t *lmap, uint8_t *rmap, size_t stride);
 
+/* "next" row: the plain weighted-median post-filter, wgtMedian (src/PP.cpp:145-247; constants MED_SZ 19, SIG_CLR 0.1,
+ * SIG_DIS 9, include/PP.h:12-14), on the device maps of the last psm_disp_select/psm_disp_merge, for the pixels the
+ * last psm_lr_check marked invalid (the sequence of PP::processDM: lrCheck, fillInv, wgtMedian, src/PP.cpp:405-410).
+ * Left map with the left image and the squared distances (:169-175), right map with the right image and the
+ * square-rooted ones (:216-224).  Same result as the reference's single-threaded form: the map is filtered in place in
+ * raster order, a filtered pixel sees the filtered pixels before it (run here as a row-dataflow pipeline).
+ * Needs W, H >= 9 (the reference's modulo wrap is undefined below that).  lmap/rmap (optional) receive the maps. */
+int psm_wgt_median(psm_ctx *ctx, uint8_t *lmap, uint8_t *rmap, size_t stride);
+
 /* ---- debug / bench entry points (no counterpart in the reference) ---- */
+
+/* Replace the device maps and validity masks (any may be NULL = keep) - lets the post-processing stages run on maps
+ * that did not come from this context's WTA.  H rows of W bytes, pitch `stride`; map values must be < max_disp. */
+int psm_upload_maps(psm_ctx *ctx, const uint8_t *lmap, const uint8_t *rmap, const uint8_t *lvalid, const uint8_t *rvalid,
+                    size_t stride);
 
 /* Copy slices [d0,d1) (global disparity numbers) of a volume to/from dense host memory
  * [d1-d0][H][W]; element type = the context's dtype. */

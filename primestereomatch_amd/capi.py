@@ -18,7 +18,7 @@ PSM_IMG_U8, PSM_IMG_F32 = 0, 1
 PSM_LEFT, PSM_RIGHT = 0, 1
 PSM_STAGE_CVC, PSM_STAGE_CVF, PSM_STAGE_DISPSEL, PSM_STAGE_PP = 0, 1, 2, 3
 (PSM_K_PREP, PSM_K_CVC, PSM_K_GUIDE, PSM_K_CVF_A, PSM_K_CVF_B, PSM_K_WTA, PSM_K_MERGE, PSM_K_BOX,
- PSM_K_LRC, PSM_K_CVF_F, PSM_K_FGF) = range(11)
+ PSM_K_LRC, PSM_K_CVF_F, PSM_K_FGF, PSM_K_WMF) = range(12)
 PSM_OPT_ASYNC, PSM_OPT_KERNEL_VARIANT, PSM_OPT_PROFILE, PSM_OPT_SEG_ROWS, PSM_OPT_WAVES, PSM_OPT_FLAGS = range(6)
 
 # every symbol include/primesm_hip.h declares: (name, restype, argtypes)
@@ -47,6 +47,8 @@ SYMBOLS = [
     ("psm_download_maps", _i, [_vp, _vp, _vp, _sz]),
     ("psm_lr_check", _i, [_vp, _vp, _vp, _sz]),
     ("psm_fill_invalid", _i, [_vp, _vp, _vp, _sz]),
+    ("psm_wgt_median", _i, [_vp, _vp, _vp, _sz]),
+    ("psm_upload_maps", _i, [_vp, _vp, _vp, _vp, _vp, _sz]),
     ("psm_download_volume", _i, [_vp, _i, _i, _i, _vp]),
     ("psm_upload_volume", _i, [_vp, _i, _i, _i, _vp]),
     ("psm_filter_stage_a", _i, [_vp, _i]),

@@ -50,6 +50,7 @@ struct psm_ctx {
     int gather_ranks = 0;
     uint8_t *maps = nullptr;            // [2][H][W]
     uint8_t *valid = nullptr;           // [2][H][W]
+    int *wm = nullptr;                  // psm_wgt_median scratch: nxt[H][W+1], prog[H], err[1]; allocated on first use
     uint8_t *p4[2] = {nullptr, nullptr};  // PSM_U8 only: {c0,c1,c2,grad} words
     float *soa[2] = {nullptr, nullptr};   // planar copies of g1..g4 (14 planes) for the two-columns-per-lane filter
     int soa_state[2] = {0, 0};            // 0 nothing, 1 g1 planes, 2 all planes (of the current image pair)
@@ -108,7 +109,10 @@ hipEvent_t get_event(psm_ctx *c)
         return e;
     }
     hipEvent_t e = nullptr;
-    (void)hipEventCreate(&e);
+    if (hipEventCreate(&e) != hipSuccess) {
+        (void)hipGetLastError();
+        return nullptr;    // Prof then skips this launch's timing instead of recording a null event
+    }
     return e;
 }
 
@@ -121,8 +125,9 @@ struct Prof {
     {
         if (c->opt_profile) {
             a = get_event(c);
-            b = get_event(c);
-            (void)hipEventRecord(a, c->stream);
+            b = a ? get_event(c) : nullptr;
+            if (a && !b) { c->event_pool.push_back(a); a = nullptr; }
+            if (a) (void)hipEventRecord(a, c->stream);
         }
     }
     ~Prof()
@@ -176,6 +181,7 @@ void free_all(psm_ctx *c)
     (void)hipFree(c->gather);
     (void)hipFree(c->maps);
     (void)hipFree(c->valid);
+    (void)hipFree(c->wm);
     (void)hipFree(c->fgf);
     for (auto &t : c->timers)
         for (auto &p : t.pending) {
@@ -298,8 +304,13 @@ int psm_create_shard(psm_ctx **out, int width, int height, int max_disp, int d_b
     if (!out) return fail(nullptr, "psm_create: out is NULL");
     *out = nullptr;
     if (width < 8 || height < 8) return fail(nullptr, "psm_create: image %dx%d smaller than the 8x8 filter window", width, height);
-    if ((long long)width * height > 0x3fffffffLL) return fail(nullptr, "psm_create: image too large");
+    // the marching kernels address the 16-byte guidance planes with 32-bit byte offsets (buffer descriptors of W*H*16
+    // bytes, row offsets y*W*16): W*H < 2^27; the post-processing row kernels keep two ints per column in LDS: W <= 8192
+    if ((long long)width * height >= (1LL << 27)) return fail(nullptr, "psm_create: image %dx%d too large (W*H must be < 2^27)", width, height);
+    if (width > 8192) return fail(nullptr, "psm_create: width %d > 8192", width);
     if (max_disp < 1 || max_disp > 256) return fail(nullptr, "psm_create: max_disp %d outside [1,256] (maps are 8-bit)", max_disp);
+    // lrCheck indexes (x - d + W) % W (src/PP.cpp:28): negative - undefined in the reference - once d > W
+    if (max_disp > width) return fail(nullptr, "psm_create: max_disp %d > width %d", max_disp, width);
     if (d_begin < 0 || d_end > max_disp || d_begin >= d_end) return fail(nullptr, "psm_create: bad slice range [%d,%d) of %d", d_begin, d_end, max_disp);
     if (dtype != PSM_F32 && dtype != PSM_U8) return fail(nullptr, "psm_create: unknown dtype %d", dtype);
     int ndev = psm_device_count();
@@ -326,7 +337,7 @@ int psm_create_shard(psm_ctx **out, int width, int height, int max_disp, int d_b
     }
     if (e == hipSuccess && dtype == PSM_U8) e = hipMalloc((void **)&c->fvol, V * sizeof(float));
     if (e == hipSuccess) e = hipMalloc((void **)&c->keys, 2 * HW * sizeof(long long));
-    if (e == hipSuccess) e = hipMalloc((void **)&c->maps, 2 * HW);
+    if (e == hipSuccess) e = hipMalloc((void **)&c->maps, 2 * HW + 4);   // +4: psm_wgt_median reads/updates whole aligned dwords
     if (e == hipSuccess) e = hipMalloc((void **)&c->valid, 2 * HW);
     if (e != hipSuccess) {
         fail(nullptr, "psm_create: device setup failed: %s", hipGetErrorString(e));
@@ -424,6 +435,9 @@ int psm_upload_pair(psm_ctx *c, const void *l, const void *r, int channels, size
     c->have_g1 = false;
     c->have_cost = false;
     c->have_maps = false;
+    c->have_valid = false;
+    c->raw_rows[0] = c->raw_rows[1] = psm_ctx::RAW_ALL;   // nothing virtual survives a new pair
+    c->fgf_virtual[0] = c->fgf_virtual[1] = 0;
     return 0;
 }
 
@@ -632,8 +646,13 @@ static int copy_maps_out(psm_ctx *c, const uint8_t *dev, uint8_t *lmap, uint8_t 
     const size_t HW = (size_t)c->W * c->H;
     if (stride == 0) stride = c->W;
     if (stride < (size_t)c->W) return fail(c, "map stride %zu < width %d", stride, c->W);
-    if (lmap) PSM_HIP(c, hipMemcpy2DAsync(lmap, stride, dev, c->W, c->W, c->H, hipMemcpyDeviceToHost, c->stream));
-    if (rmap) PSM_HIP(c, hipMemcpy2DAsync(rmap, stride, dev + HW, c->W, c->W, c->H, hipMemcpyDeviceToHost, c->stream));
+    if (stride == (size_t)c->W) {   // dense host maps: one linear copy each (the 2-D path is several times slower to pageable memory)
+        if (lmap) PSM_HIP(c, hipMemcpyAsync(lmap, dev, HW, hipMemcpyDeviceToHost, c->stream));
+        if (rmap) PSM_HIP(c, hipMemcpyAsync(rmap, dev + HW, HW, hipMemcpyDeviceToHost, c->stream));
+    } else {
+        if (lmap) PSM_HIP(c, hipMemcpy2DAsync(lmap, stride, dev, c->W, c->W, c->H, hipMemcpyDeviceToHost, c->stream));
+        if (rmap) PSM_HIP(c, hipMemcpy2DAsync(rmap, stride, dev + HW, c->W, c->W, c->H, hipMemcpyDeviceToHost, c->stream));
+    }
     if (lmap || rmap) PSM_HIP(c, hipStreamSynchronize(c->stream));
     return 0;
 }
@@ -734,6 +753,7 @@ int psm_disp_merge(psm_ctx *c, const void *dev_keys_all, int nranks, uint8_t *lm
     }
     if (check_launch(c, "merge")) return 1;
     c->have_maps = true;
+    c->have_valid = false;   // new maps: a validity mask of an earlier frame does not describe them
     if (copy_maps_out(c, c->maps, lmap, rmap, stride)) return 1;
     if (!c->opt_async) PSM_HIP(c, hipStreamSynchronize(c->stream));
     c->stage_us[PSM_STAGE_DISPSEL] += now_us() - t0;
@@ -811,10 +831,55 @@ int psm_fill_invalid(psm_ctx *c, uint8_t *lmap, uint8_t *rmap, size_t stride)
         launch_fill_inv(c->stream, c->maps + HW, c->valid + HW, c->W, c->H);
     }
     if (check_launch(c, "fill_inv")) return 1;
-    c->have_valid = false;   // the maps changed; validity refers to the unfilled maps
+    // have_valid stays set: the mask still says which pixels the L-R check rejected, which is what the next stage of
+    // PP::processDM (wgtMedian, src/PP.cpp:405-410) filters
     if (copy_maps_out(c, c->maps, lmap, rmap, stride)) return 1;
     if (!c->opt_async) PSM_HIP(c, hipStreamSynchronize(c->stream));
     c->stage_us[PSM_STAGE_PP] += now_us() - t0;
+    return 0;
+}
+
+int psm_wgt_median(psm_ctx *c, uint8_t *lmap, uint8_t *rmap, size_t stride)
+{
+    if (!c) return 1;
+    if (!c->have_maps || !c->have_valid) return fail(c, "psm_wgt_median: needs disparity maps and psm_lr_check");
+    if (!c->have_images) return fail(c, "psm_wgt_median: no image pair uploaded (colour weights)");
+    if (c->W < 9 || c->H < 9) return fail(c, "psm_wgt_median: image %dx%d smaller than the 19x19 window's wrap allows", c->W, c->H);
+    if (bind(c)) return 1;
+    const double t0 = now_us();
+    if (!c->have_g1 && run_prep(c)) return 1;
+    const size_t HW = (size_t)c->W * c->H, nn = (size_t)c->H * (c->W + 1);
+    if (!c->wm) PSM_HIP(c, hipMalloc((void **)&c->wm, (nn + c->H + 1) * sizeof(int)));
+    int *nxt = c->wm, *prog = c->wm + nn, *err = prog + c->H;
+    PSM_HIP(c, hipMemsetAsync(err, 0, sizeof(int), c->stream));
+    for (int s = 0; s < 2; ++s) {
+        Prof p(c, PSM_K_WMF);
+        launch_wgt_median(c->stream, c->maps + s * HW, c->valid + s * HW, c->g[s].g1, c->W, c->H, c->D, s, nxt, prog, err);
+    }
+    if (check_launch(c, "wgt_median")) return 1;
+    int herr = 0;
+    PSM_HIP(c, hipMemcpyAsync(&herr, err, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    PSM_HIP(c, hipStreamSynchronize(c->stream));
+    if (herr) return fail(c, "psm_wgt_median: row pipeline stalled (watchdog); maps are not valid");
+    if (copy_maps_out(c, c->maps, lmap, rmap, stride)) return 1;
+    c->stage_us[PSM_STAGE_PP] += now_us() - t0;
+    return 0;
+}
+
+int psm_upload_maps(psm_ctx *c, const uint8_t *lmap, const uint8_t *rmap, const uint8_t *lvalid, const uint8_t *rvalid, size_t stride)
+{
+    if (!c) return 1;
+    if (stride == 0) stride = c->W;
+    if (stride < (size_t)c->W) return fail(c, "psm_upload_maps: stride %zu < width %d", stride, c->W);
+    if (bind(c)) return 1;
+    const size_t HW = (size_t)c->W * c->H;
+    const uint8_t *src[4] = {lmap, rmap, lvalid, rvalid};
+    uint8_t *dst[4] = {c->maps, c->maps + HW, c->valid, c->valid + HW};
+    for (int i = 0; i < 4; ++i)
+        if (src[i]) PSM_HIP(c, hipMemcpy2DAsync(dst[i], c->W, src[i], stride, c->W, c->H, hipMemcpyHostToDevice, c->stream));
+    PSM_HIP(c, hipStreamSynchronize(c->stream));
+    if (lmap && rmap) { c->have_maps = true; c->have_valid = false; }
+    if (lvalid && rvalid && c->have_maps) c->have_valid = true;
     return 0;
 }
 

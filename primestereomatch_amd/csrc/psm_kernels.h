@@ -62,6 +62,11 @@ void launch_lr_check(hipStream_t s, const uint8_t *l, const uint8_t *r, int W, i
 // fill invalid pixels of one map in place (valid: 0/1 per pixel)
 void launch_fill_inv(hipStream_t s, uint8_t *dis, const uint8_t *valid, int W, int H);
 
+// weighted-median post-filter of one map, in place, with the reference's raster-order semantics (psm_pp.hip).
+// nxt: scratch of H*(W+1) ints, prog: H ints, err: 1 int (set to 1 if the dataflow watchdog fired)
+void launch_wgt_median(hipStream_t s, uint8_t *dis, const uint8_t *valid, const float4 *g1, int W, int H, int maxDis, int right,
+                       int *nxt, int *prog, int *err);
+
 // ---- Fast Guided Filter variant (psm_fgf.hip); sub = subsample rate, small planes are (H/sub) x (W/sub) ----
 // g1 -> subsampled guidance ism, its means msm and the inverse covariance planes v1 = {irr,irg,irb,igg}, v2 = {igb,ibb}
 void launch_fgf_setup(hipStream_t s, const float4 *g1, int W, int H, int sub, float4 *ism, float4 *msm, float4 *v1, float2 *v2);

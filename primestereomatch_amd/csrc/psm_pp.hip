@@ -1,0 +1,209 @@
+// psm_pp.hip - post-processing "next" row: the plain weighted-median filter of src/PP.cpp:145-247 (wgtMedian) on gfx950.
+//
+// The reference filters the map IN PLACE in raster order: every invalid pixel is replaced by the weighted median of the
+// disparities in its 19 x 19 (modulo-wrapped) window, and that window already contains the filtered values of the
+// invalid pixels before it in raster order.  A data-parallel "all pixels from the input map" evaluation is a different
+// filter.  What is parallel: the dependence is local - a pixel only depends on the earlier INVALID pixels inside its
+// window - so the rows run as a dataflow pipeline:
+//   * one wave per image row, rows dispatched in order; the wave walks its invalid pixels left to right;
+//   * prog[y] = "every invalid pixel of row y left of this column is final".  Before a pixel is evaluated, lanes 0..18
+//     (one per window row) wait until no unfinished invalid pixel of an EARLIER row lies inside the window
+//     (nxt[y][x] = next invalid column >= x makes that test O(1)); rows later in raster order are read as they are: the
+//     window relation is symmetric on the torus, so a later pixel inside the window cannot have been filtered yet - it
+//     is itself waiting for this one;
+//   * no fences: the map is read with agent-scope atomic dword loads and updated with one returning agent-scope
+//     atomic XOR of the byte's changed bits (only this wave ever writes that byte; rows may share a dword when W % 4
+//     != 0), and prog[y] is stored after the XOR has returned.  Release/acquire fences (L2 write-back + invalidate per
+//     pixel) made the first version ~100x slower: 1.9 s instead of tens of ms for a 450 x 375 pair;
+//   * the 361 weights of a pixel are evaluated by the 64 lanes in parallel (fp32 colour distance op for op, double exp
+//     narrowed to float as the reference does); the histogram bins and the total are then accumulated in window raster
+//     order (lane l owns bins l, l+64, ..: every lane scans the 361 (disparity, weight) pairs from LDS and adds the ones
+//     that fall into its bins, so every float sum is formed in exactly the reference's order);
+//   * the threshold scan runs over the non-empty bins in ascending order (adding an empty bin is the identity).
+// A waiting wave only ever waits for rows with a smaller block index, so in-order dispatch guarantees progress; a
+// watchdog turns a (never observed) stall into an error flag instead of a hang.
+#include "psm_kernels.h"
+#include "psm_dev.h"
+
+namespace psm {
+
+constexpr int WM_R = 9;                 // MED_SZ / 2, include/PP.h:12
+constexpr int WM_K = 2 * WM_R + 1;      // 19
+constexpr int WM_TAPS = WM_K * WM_K;    // 361
+
+// nxt[y][x] (x = 0..W) = smallest x' >= x with valid[y][x'] == 0, W if there is none; prog[y] = nxt[y][0]
+__global__ __launch_bounds__(64) void k_wm_next(const uint8_t *__restrict__ valid, int W, int *__restrict__ nxt, int *__restrict__ prog)
+{
+    const int y = blockIdx.x, lane = threadIdx.x;
+    const uint8_t *v = valid + (size_t)y * W;
+    int *n = nxt + (size_t)y * (W + 1);
+    int carry = W;
+    if (lane == 0) n[W] = W;
+    for (int x0 = ((W - 1) / 64) * 64; x0 >= 0; x0 -= 64) {
+        const int x = x0 + lane;
+        const bool inv = x < W && v[x] == 0;
+        const unsigned long long m = __builtin_amdgcn_ballot_w64(inv);
+        const unsigned long long up = m >> lane;            // invalid flags of columns x, x+1, ...
+        const int nx = up ? x + __builtin_ctzll(up) : carry;
+        if (x < W) n[x] = nx;
+        if (m) carry = x0 + __builtin_ctzll(m);
+    }
+    if (lane == 0) prog[y] = carry;
+}
+
+template <bool RIGHT>
+__device__ __forceinline__ float wm_weight(float4 p, float4 q, int wx, int wy)
+{
+    // src/PP.cpp:169-175 (left) / 216-224 (right)
+    float disWgt = (float)(wx * wx + wy * wy);
+    const float d0 = __fsub_rn(p.x, q.x), d1 = __fsub_rn(p.y, q.y), d2 = __fsub_rn(p.z, q.z);
+    float clrWgt = __fadd_rn(__fadd_rn(__fmul_rn(d0, d0), __fmul_rn(d1, d1)), __fmul_rn(d2, d2));
+    if (RIGHT) {
+        disWgt = __fsqrt_rn(disWgt);
+        clrWgt = __fsqrt_rn(clrWgt);
+    }
+    // -disWgt / (SIG_DIS*SIG_DIS): float / int -> float;  clrWgt / (SIG_CLR*SIG_CLR): float / double -> double
+    const double arg = __dsub_rn((double)__fdiv_rn(-disWgt, 81.0f), __ddiv_rn((double)clrWgt, 0.1 * 0.1));
+    return (float)exp(arg);
+}
+
+// one map byte through an agent-scope atomic load of the dword that holds it (coherent across the XCDs' L2s)
+__device__ __forceinline__ int wm_load_byte(const uint8_t *p)
+{
+    const uintptr_t a = (uintptr_t)p;
+    const unsigned w = __hip_atomic_load((const unsigned *)(a & ~(uintptr_t)3), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return (int)((w >> ((a & 3) * 8)) & 0xffu);
+}
+
+template <bool RIGHT, int NB>   // NB = ceil(maxDis / 64) histogram bins per lane
+__global__ __launch_bounds__(64) void k_wgt_median(uint8_t *dis, const float4 *__restrict__ g1, const int *__restrict__ nxt,
+                                                  int *prog, int W, int H, int maxDis, int *err)
+{
+    __shared__ float2 taps[WM_TAPS + 3];     // (disparity as float bits, weight) in window raster order
+    __shared__ float hist[64 * NB];
+    const int y = blockIdx.x, lane = threadIdx.x;
+    const int *myn = nxt + (size_t)y * (W + 1);
+    uint8_t *drow = dis + (size_t)y * W;
+    // window row of this lane (lanes 0..18) for the dependency test
+    const int wy_l = lane - WM_R;
+    const int qy_l = lane < WM_K ? (y + wy_l + H) % H : y;
+    const bool earlier = lane < WM_K && qy_l < y;
+    const int *qn = nxt + (size_t)qy_l * (W + 1);
+    // tap t of this lane's k-th round: t = lane + 64 k  (k = 0..5, 361 taps)
+    constexpr int WM_ROUNDS = (WM_TAPS + 63) / 64;
+    int x = myn[0];
+    while (x < W) {
+        // ---- 361 weights, 64 at a time: they depend on the colours only, so they are evaluated BEFORE the wait - on a
+        // map whose invalid pixels chain (every pixel waiting for its left neighbour) the wait is the critical path ----
+        const float4 p = g1[(size_t)y * W + x];
+        float wgt[WM_ROUNDS];
+        int tap_off[WM_ROUNDS];
+#pragma unroll
+        for (int k = 0; k < WM_ROUNDS; ++k) {
+            const int t = min(lane + 64 * k, WM_TAPS - 1);
+            const int wy = t / WM_K - WM_R, wx = t % WM_K - WM_R;
+            const int qy = (y + wy + H) % H, qx = (x + wx + W) % W;
+            tap_off[k] = qy * W + qx;
+            wgt[k] = wm_weight<RIGHT>(p, g1[tap_off[k]], wx, wy);
+        }
+        // ---- wait until every earlier invalid pixel inside the window is final ----
+        {
+            const int lo = x - WM_R, hi = x + WM_R;
+            int a0, b0, a1 = 1, b1 = 0;   // up to two column intervals (second one empty by default)
+            if (W < WM_K) { a0 = 0; b0 = W - 1; }
+            else if (lo < 0) { a0 = lo + W; b0 = W - 1; a1 = 0; b1 = hi; }
+            else if (hi >= W) { a0 = lo; b0 = W - 1; a1 = 0; b1 = hi - W; }
+            else { a0 = lo; b0 = hi; }
+            unsigned spins = 0;
+            for (;;) {
+                bool ok = true;
+                if (earlier) {
+                    const int pr = __hip_atomic_load(&prog[qy_l], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    int s0 = max(a0, pr);
+                    if (s0 <= b0 && qn[s0] <= b0) ok = false;
+                    int s1 = max(a1, pr);
+                    if (s1 <= b1 && qn[s1] <= b1) ok = false;
+                }
+                if (__builtin_amdgcn_ballot_w64(!ok) == 0) break;
+                __builtin_amdgcn_s_sleep(1);
+                if (++spins > (1u << 24)) {          // watchdog: never hang the device
+                    if (lane == 0) atomicExch(err, 1);
+                    break;
+                }
+            }
+            // (the loop exit depends on the prog values just loaded, so the map loads below are issued after them)
+        }
+        // ---- the window's current disparities; a pixel of disparity 0 does not vote (src/PP.cpp:167) ----
+#pragma unroll
+        for (int k = 0; k < WM_ROUNDS; ++k) {
+            const int t = lane + 64 * k;
+            const int dep = wm_load_byte(dis + tap_off[k]);
+            if (t < WM_TAPS) taps[t] = make_float2(__int_as_float(dep), dep != 0 ? wgt[k] : 0.0f);
+        }
+        __syncthreads();
+        // ---- histogram + total in window raster order (adding 0.0f for "does not vote" is the identity) ----
+        float acc[NB];
+#pragma unroll
+        for (int j = 0; j < NB; ++j) acc[j] = 0.0f;
+        float tot = 0.0f;
+#pragma unroll 19
+        for (int t = 0; t < WM_TAPS; ++t) {
+            const float2 tw = taps[t];
+            const int dep = __float_as_int(tw.x);
+            tot = __fadd_rn(tot, tw.y);
+#pragma unroll
+            for (int j = 0; j < NB; ++j) acc[j] = __fadd_rn(acc[j], dep == lane + 64 * j ? tw.y : 0.0f);
+        }
+#pragma unroll
+        for (int j = 0; j < NB; ++j) hist[lane + 64 * j] = acc[j];
+        __syncthreads();
+        // ---- threshold scan over the non-empty bins, ascending d (src/PP.cpp:184-192) ----
+        const float half = __fdiv_rn(tot, 2.0f);
+        float run = 0.0f;
+        int filterDep = 0;
+        bool found = false;
+        if (run >= half) { filterDep = 0; found = true; }        // d = 0: sumWgt(0) >= halfWgt only when nobody voted
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            unsigned long long m = __builtin_amdgcn_ballot_w64(acc[j] != 0.0f && lane + 64 * j < maxDis);
+            while (m && !found) {
+                const int b = __builtin_ctzll(m);
+                m &= m - 1;
+                run = __fadd_rn(run, hist[b + 64 * j]);
+                if (run >= half) { filterDep = b + 64 * j; found = true; }
+            }
+        }
+        // (not found: the running sum never reaches half - only possible with NaN weights - filterDep stays 0 as in the reference)
+        const int xn = myn[x + 1];
+        if (lane == 0) {
+            const int old = __float_as_int(taps[WM_TAPS / 2].x);      // the centre tap is this pixel's current value
+            int pv = xn;
+            if (old != filterDep) {
+                const uintptr_t a = (uintptr_t)(drow + x);
+                const unsigned r = __hip_atomic_fetch_xor((unsigned *)(a & ~(uintptr_t)3), (unsigned)(old ^ filterDep) << ((a & 3) * 8),
+                                                          __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                asm volatile("" : "+v"(pv) : "v"(r));                 // prog is stored only after the XOR has returned
+            }
+            __hip_atomic_store(&prog[y], pv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __syncthreads();
+        x = xn;
+    }
+}
+
+void launch_wgt_median(hipStream_t s, uint8_t *dis, const uint8_t *valid, const float4 *g1, int W, int H, int maxDis, int right,
+                       int *nxt, int *prog, int *err)
+{
+    hipLaunchKernelGGL(k_wm_next, dim3(H), dim3(64), 0, s, valid, W, nxt, prog);
+    const int nb = (maxDis + 63) / 64;
+#define PSM_LAUNCH_WM(R, NBV) \
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_wgt_median<R, NBV>), dim3(H), dim3(64), 0, s, dis, g1, (const int *)nxt, prog, W, H, maxDis, err)
+    if (right) {
+        if (nb <= 1) PSM_LAUNCH_WM(true, 1); else if (nb == 2) PSM_LAUNCH_WM(true, 2); else if (nb == 3) PSM_LAUNCH_WM(true, 3); else PSM_LAUNCH_WM(true, 4);
+    } else {
+        if (nb <= 1) PSM_LAUNCH_WM(false, 1); else if (nb == 2) PSM_LAUNCH_WM(false, 2); else if (nb == 3) PSM_LAUNCH_WM(false, 3); else PSM_LAUNCH_WM(false, 4);
+    }
+#undef PSM_LAUNCH_WM
+}
+
+}  // namespace psm

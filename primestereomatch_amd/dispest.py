@@ -142,6 +142,18 @@ class DispEst:
                  "FillInv_GPU")
         return 0
 
+    def WgtMedian_GPU(self) -> int:
+        """PP wgtMedian (src/PP.cpp:145-247) on the device, for the pixels LRCheck_GPU marked invalid; updates
+        lDisMap / rDisMap.  Same result as the reference's sequential in-place form."""
+        self._ck(self._lib.psm_wgt_median(self._h, _ptr(self.lDisMap), _ptr(self.rDisMap), self.wid), "WgtMedian_GPU")
+        return 0
+
+    def upload_maps(self, lmap=None, rmap=None, lvalid=None, rvalid=None):
+        arrs = [None if a is None else np.ascontiguousarray(a, dtype=np.uint8) for a in (lmap, rmap, lvalid, rvalid)]
+        for a in arrs:
+            assert a is None or a.shape == (self.hei, self.wid)
+        self._ck(self._lib.psm_upload_maps(self._h, *[_ptr(a) for a in arrs], self.wid), "upload_maps")
+
     def set_option(self, option: int, value: int):
         self._ck(self._lib.psm_set_option(self._h, int(option), int(value)), "set_option")
 

@@ -1,0 +1,152 @@
+"""-m gpu tests added in round 2:
+
+* weighted-median post-filter (psm_wgt_median, src/PP.cpp:145-247) against the oracle's sequential in-place restatement -
+  integer maps, bit-exact; the mismatch count (device exp vs host libm exp, narrowed to float) is reported and must be 0;
+* the HIP filtered volumes against the oracle evaluated in OPENCV'S OWN summation order (PSMO_BOX_OCV: RowSum/ColumnSum
+  running sums) - the order the reference binary executes at src/CVF.cpp:50,63,82,88,158,160 - within the north-star
+  tolerance, WTA maps identical (expected and asserted: 0 differing voxels on the Middlebury pairs).
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def psm():
+    from primestereomatch_amd import capi
+    capi.load()
+    assert capi.device_count() >= 1, "no HIP device visible"
+    import primestereomatch_amd as P
+    return P
+
+
+def _wm_inputs(H, W, D, seed, frac_invalid, smooth=True):
+    rng = np.random.default_rng(seed)
+    img = rng.integers(0, 256, (H, W, 3), dtype=np.uint8)
+    if smooth:   # piecewise-constant colours + small noise: colour weights that are not all ~0
+        base = rng.integers(0, 256, (H // 8 + 1, W // 8 + 1, 3))
+        img = np.clip(np.kron(base, np.ones((8, 8, 1)))[:H, :W] + rng.integers(-3, 4, (H, W, 3)), 0, 255).astype(np.uint8)
+    lm = rng.integers(0, D, (H, W)).astype(np.uint8)
+    rm = rng.integers(0, D, (H, W)).astype(np.uint8)
+    lv = (rng.random((H, W)) > frac_invalid).astype(np.uint8)
+    rv = (rng.random((H, W)) > frac_invalid).astype(np.uint8)
+    return img, lm, rm, lv, rv
+
+
+@pytest.mark.parametrize("H,W,D,frac", [(21, 26, 16, 0.3), (40, 70, 64, 0.6), (33, 210, 200, 1.0), (12, 9, 8, 0.5),
+                                        (48, 256, 256, 0.15)])
+def test_wgt_median_random_maps(psm, oracle, H, W, D, frac):
+    l, lm, rm, lv, rv = _wm_inputs(H, W, D, seed=H * W + D, frac_invalid=frac)
+    r = np.roll(l, 3, axis=1)
+    with psm.DispEst(l, r, D) as de:
+        de.upload_maps(lm, rm, lv, rv)
+        de.WgtMedian_GPU()
+        gl, gr = de.lDisMap.copy(), de.rDisMap.copy()
+    el = oracle.wgt_median(oracle.u8_to_f32(l), lm, lv, D, right=False)
+    er = oracle.wgt_median(oracle.u8_to_f32(r), rm, rv, D, right=True)
+    print(f"[wmf] {W}x{H} D={D}: left mismatches {(gl != el).sum()}, right {(gr != er).sum()} "
+          f"of {(lv == 0).sum()} / {(rv == 0).sum()} filtered pixels")
+    assert np.array_equal(gl, el) and np.array_equal(gr, er)
+    assert np.array_equal(gl[lv != 0], lm[lv != 0])
+
+
+@pytest.mark.parametrize("name", ["cones", "teddy"])
+def test_wgt_median_after_lr_check_middlebury(psm, oracle, golden, name):
+    """PP::processDM's sequence (src/PP.cpp:405-410): lrCheck -> fillInv -> wgtMedian on the real pair."""
+    pair = golden(f"{name}_pair.npz")
+    l, r = pair["l_bgr"], pair["r_bgr"]
+    with psm.DispEst(l, r, 64) as de:
+        de.CostConst_GPU(); de.CostFilter_GPU(); de.DispSelect_GPU()
+        de.LRCheck_GPU()
+        lv, rv = de.lValid.copy(), de.rValid.copy()
+        de.FillInv_GPU()
+        lf, rf = de.lDisMap.copy(), de.rDisMap.copy()
+        de.WgtMedian_GPU()
+        gl, gr = de.lDisMap.copy(), de.rDisMap.copy()
+        us = de.stage_time_us(3)
+    el = oracle.wgt_median(oracle.u8_to_f32(l), lf, lv, 64, right=False)
+    er = oracle.wgt_median(oracle.u8_to_f32(r), rf, rv, 64, right=True)
+    nl, nr = int((gl != el).sum()), int((gr != er).sum())
+    print(f"[wmf] {name}: {int((lv == 0).sum())} + {int((rv == 0).sum())} pixels filtered, mismatches vs oracle: {nl} + {nr}; "
+          f"PP stage {us / 1e3:.2f} ms")
+    assert nl == 0 and nr == 0
+    assert not np.array_equal(gl, lf)          # the filter did something
+
+
+def test_wgt_median_needs_lr_check(psm):
+    from primestereomatch_amd import capi
+    rng = np.random.default_rng(0)
+    l = rng.integers(0, 256, (16, 24, 3), dtype=np.uint8)
+    with psm.DispEst(l, l, 8) as de:
+        de.CostConst_GPU(); de.CostFilter_GPU(); de.DispSelect_GPU()
+        with pytest.raises(capi.PsmError):
+            de.WgtMedian_GPU()                 # no validity mask yet
+        de.LRCheck_GPU()
+        de.WgtMedian_GPU()
+        # a new WTA invalidates the mask (stale validity after new maps)
+        de.DispSelect_GPU()
+        with pytest.raises(capi.PsmError):
+            de.FillInv_GPU()
+
+
+def test_create_rejects_what_the_kernels_cannot_address(psm):
+    from primestereomatch_amd import capi
+    rng = np.random.default_rng(1)
+    l = rng.integers(0, 256, (16, 24, 3), dtype=np.uint8)
+    with pytest.raises(capi.PsmError):
+        psm.DispEst(l, l, 32)                  # max_disp > width: lrCheck's modulo goes negative (undefined in the reference)
+    lib = capi.load()
+    import ctypes as C
+    h = C.c_void_p()
+    assert lib.psm_create(C.byref(h), 16384, 8192, 64, 0, 0) != 0       # W*H >= 2^27: 32-bit plane offsets
+    assert b"too large" in lib.psm_last_error(None) or b"8192" in lib.psm_last_error(None)
+
+
+# ------------------------------------------------------------------------------------------
+# HIP path vs the oracle in OpenCV's own summation order
+# ------------------------------------------------------------------------------------------
+def _gpu_pipeline(psm, l, r, D):
+    with psm.DispEst(l, r, D) as de:
+        de.CostConst_GPU(); de.CostFilter_GPU(); de.DispSelect_GPU()
+        return de.lDisMap.copy(), de.rDisMap.copy(), de.download_volume(0), de.download_volume(1)
+
+
+@pytest.mark.parametrize("name", ["cones", "teddy"])
+def test_hip_vs_opencv_order_oracle_middlebury(psm, oracle, golden, name):
+    pair = golden(f"{name}_pair.npz")
+    l, r = pair["l_bgr"], pair["r_bgr"]
+    ld, rd, lv, rv = _gpu_pipeline(psm, l, r, 64)
+    with oracle.box_order(oracle.BOX_OCV):
+        ref = oracle.pipeline_f32(l, r, 64, threads=8, want_volumes=True)
+    for nm, g, e in (("lvol", lv, ref["lvol"]), ("rvol", rv, ref["rvol"])):
+        d = np.abs(g.astype(np.float64) - e)
+        print(f"[ocv-order] {name} {nm}: max|dq|={d.max():.3e}  voxels>1e-4: {int((d > TOL).sum())}  bit-different: {int((g != e).sum())}")
+        assert d.max() <= TOL
+    nmap = int((ld != ref["ldisp"]).sum() + (rd != ref["rdisp"]).sum())
+    print(f"[ocv-order] {name}: WTA pixels different from the OpenCV-order evaluation: {nmap}")
+    assert nmap == 0
+
+
+@pytest.mark.parametrize("W,H,D,band", [(1280, 720, 128, (300, 380)), (1920, 1080, 256, (500, 564))])
+def test_hip_vs_opencv_order_oracle_full_size_band(psm, oracle, W, H, D, band):
+    """C3 / C4 geometry: a few slices of the full-size run against the OpenCV-order oracle.  The running column sums of
+    the OpenCV order depend on every row above, so the oracle filters the whole plane (two slices only)."""
+    from primestereomatch_amd import synth
+    l, r, _ = synth.make_pair(W, H, D, seed=0)
+    d_lo, d_hi = D // 2, D // 2 + 2
+    with psm.DispEst(l, r, D, d_range=(d_lo, d_hi)) as de:
+        de.CostConst_GPU(); de.CostFilter_GPU()
+        q = de.download_volume(0)
+    lf, rf = oracle.u8_to_f32(l), oracle.u8_to_f32(r)
+    lG, rG = oracle.cvc_preprocess(lf), oracle.cvc_preprocess(rf)
+    with oracle.box_order(oracle.BOX_OCV):
+        rgb, mean, var = oracle.cvf_preprocess(lf)
+        for d in range(d_lo, d_hi):
+            qq = oracle.guided_filter(rgb, mean, var, oracle.cvc_build(lf, rf, lG, rG, d))
+            dd = np.abs(q[d - d_lo].astype(np.float64) - qq)
+            print(f"[ocv-order] {W}x{H} d={d}: max|dq|={dd.max():.3e}  voxels>1e-4: {int((dd > TOL).sum())}  "
+                  f"bit-different: {int((q[d - d_lo] != qq).sum())} of {qq.size}")
+            assert dd.max() <= TOL
