@@ -264,7 +264,7 @@ def main():
 
     # ---- PCIe legs the reference's stage timers include (src/StereoMatch.cpp:227-237), never part of `value` ----
     pcie = None
-    if rank == 0:
+    if rank == 0 and args.shard_sim <= 1:
         sync()
         ts = time.perf_counter()
         de.setInputImages(l, r)              # H2D of the u8 pair (blocking)
@@ -295,10 +295,16 @@ def main():
     vox_per_launch = float(W) * H * (d1 - d0)   # one launch = all local slices of one side
     if args.fgf:   # per launch pair (setup + model + smooth + apply of one side): cost read at 1/s^2, model planes, q write
         ALG_BYTES["cvf_fgf"] = 4.0 + 68.0 / (args.fgf * args.fgf)
+    # the default fused kernel also builds the costs and runs the WTA over its slices ("select" mode): it is credited
+    # with the whole staged pipeline's algorithmic bytes (CVC 4 + CVF 40 + WTA 4); --flags 8192 is the storing form (CVF only)
+    select_mode = not args.fgf and args.variant == 0 and not (max(args.flags, 0) & (16 | 512 | 8192))
+    if select_mode:
+        ALG_BYTES["cvf_fused"] = 48.0
     dom = max(("cvf_fgf",) if args.fgf else ("cvf_fused", "cvf_a", "cvf_b"), key=lambda k: kern.get(k, {"avg_ms": 0})["avg_ms"])
     dom_ms = kern[dom]["avg_ms"]
     achieved = ALG_BYTES[dom] * vox_per_launch / (dom_ms * 1e-3) / 1e9
-    roofline = {"bound": "hbm", "kernel": "k_" + dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+    roofline = {"bound": "hbm", "kernel": "k_cvf_pc (select mode: CVC+CVF+WTA fused)" if (select_mode and dom == "cvf_fused") else "k_" + dom,
+                "alg_bytes_per_voxel": ALG_BYTES[dom], "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
                 "alg_bytes_per_launch": ALG_BYTES[dom] * vox_per_launch, "avg_launch_ms": round(dom_ms, 4),
                 "note": "achieved/frac credit the fused kernel with the staged pipeline's algorithmic bytes (SURVEY.md 8d); "

@@ -60,7 +60,11 @@ enum {
                                    guidance kernels; 512 = two-columns-per-lane variant of the fused filter
                                    (widths that are multiples of 4); 4096 = psm_cost_filter_fgf always writes
                                    the filtered volumes (default: they stay virtual - low-resolution models -
-                                   and the WTA consumes those directly).  No flag changes any result. */
+                                   and the WTA consumes those directly); 8192 = psm_cost_filter always writes the
+                                   filtered volumes (default: the fused kernel runs the WTA over the local slices
+                                   itself and the filtered volumes stay virtual - packed per-pixel minima - until
+                                   something other than psm_disp_select* reads them); 16384 = two-columns-per-lane,
+                                   channel-split variant of that kernel (k_cvf_q2).  No flag changes any result. */
 };
 
 /* Number of usable HIP devices; 0 if none.  Replaces openCLdevicepoll()

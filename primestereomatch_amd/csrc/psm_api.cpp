@@ -58,6 +58,13 @@ struct psm_ctx {
     // it is fully described by the smoothed low-resolution models fgf_mab[side]; the WTA consumes them directly
     // (upsample + model + argmin in one pass), any other reader of vol[side] materialises it first (materialize()).
     int fgf_virtual[2] = {0, 0};
+    // After psm_cost_filter (default path) the filtered volume of a side is virtual as well (gf_virtual[side]): the fused
+    // kernel ran in "select" mode - cost build, guided filter and the WTA over the local slices in one pass - and left
+    // the packed per-pixel minima in keys[side].  vol[side] is then untouched (raw_rows[side] still describes the
+    // UNFILTERED volume); any reader of the filtered volume re-runs the filter in "store" mode first (materialize()).
+    bool gf_virtual[2] = {false, false};
+    void *gf_scratch = nullptr;         // chunk planes of the select-mode kernel (PcPlan::scratch_bytes)
+    size_t gf_scratch_bytes = 0;
     float4 *fgf_mab[2] = {nullptr, nullptr};
     void *fgf = nullptr;                // psm_cost_filter_fgf scratch (small planes), fgf_bytes long
     size_t fgf_bytes = 0;
@@ -182,6 +189,7 @@ void free_all(psm_ctx *c)
     (void)hipFree(c->maps);
     (void)hipFree(c->valid);
     (void)hipFree(c->wm);
+    (void)hipFree(c->gf_scratch);
     (void)hipFree(c->fgf);
     for (auto &t : c->timers)
         for (auto &p : t.pending) {
@@ -204,6 +212,28 @@ int run_prep(psm_ctx *c)
     if (check_launch(c, "prep")) return 1;
     c->soa_state[0] = c->soa_state[1] = 0;
     c->have_g1 = true;
+    return 0;
+}
+
+// The float volumes are allocated on first use: the default path (lazy costs + select-mode filter) never touches them.
+int ensure_vol(psm_ctx *c, int side)
+{
+    if (c->vol[side]) return 0;
+    const size_t V = (size_t)c->W * c->H * c->Dloc;
+    PSM_HIP(c, hipMalloc(&c->vol[side], V * velem(c)));
+    return 0;
+}
+
+// chunk planes of the select-mode fused kernel (shared by both sides: each side reduces them to keys[side] right away)
+int ensure_gf_scratch(psm_ctx *c, size_t bytes)
+{
+    if (c->gf_scratch && c->gf_scratch_bytes >= bytes) return 0;
+    PSM_HIP(c, hipStreamSynchronize(c->stream));
+    (void)hipFree(c->gf_scratch);
+    c->gf_scratch = nullptr;
+    c->gf_scratch_bytes = 0;
+    PSM_HIP(c, hipMalloc(&c->gf_scratch, bytes));
+    c->gf_scratch_bytes = bytes;
     return 0;
 }
 
@@ -249,6 +279,7 @@ void launch_cvc_rows(psm_ctx *c, int side, int ybeg, int yend)
 int fgf_flush(psm_ctx *c, int side)
 {
     if (!c->fgf_virtual[side]) return 0;
+    if (ensure_vol(c, side)) return 1;
     {
         Prof p(c, PSM_K_FGF);
         launch_fgf_apply(c->stream, (float *)c->vol[side], c->g[side].g1, c->W, c->H, c->Dloc, c->fgf_virtual[side], c->fgf_mab[side]);
@@ -261,7 +292,27 @@ int fgf_flush(psm_ctx *c, int side)
 int materialize(psm_ctx *c, int side)
 {
     if (fgf_flush(c, side)) return 1;
+    if (c->gf_virtual[side]) {
+        // the guided-filter result exists only as WTA keys: run the same fused kernel again, this time storing q
+        if (ensure_vol(c, side)) return 1;
+        Prof p(c, PSM_K_CVF_F);
+        if (c->raw_rows[side] == psm_ctx::RAW_ALL) {          // materialised costs in vol[side]: out of place
+            if (ensure_spare(c)) return 1;
+            launch_cvf_fused(c->stream, c->march, (const float *)c->vol[side], c->spare, c->g[side], c->W, c->H, c->Dloc, 0, c->H,
+                             c->g[1 - side].g1, c->d0, 0);
+            float *t = (float *)c->vol[side];
+            c->vol[side] = c->spare;
+            c->spare = t;
+        } else {
+            launch_cvf_fused(c->stream, c->march, nullptr, (float *)c->vol[side], c->g[side], c->W, c->H, c->Dloc, 0, c->H,
+                             c->g[1 - side].g1, c->d0, 1 + side);
+        }
+        c->gf_virtual[side] = false;
+        c->raw_rows[side] = psm_ctx::RAW_ALL;                 // vol[side] now holds real (filtered) data
+        return check_launch(c, "cvf (materialize)");
+    }
     if (c->dtype != PSM_F32 || c->raw_rows[side] == psm_ctx::RAW_ALL) return 0;
+    if (ensure_vol(c, side)) return 1;
     launch_cvc_rows(c, side, 0, c->H);
     c->raw_rows[side] = psm_ctx::RAW_ALL;
     return check_launch(c, "cvc (materialize)");
@@ -332,7 +383,7 @@ int psm_create_shard(psm_ctx **out, int width, int height, int max_disp, int d_b
         if (e == hipSuccess) e = hipMalloc((void **)&c->g[s].g2, HW * sizeof(float4));
         if (e == hipSuccess) e = hipMalloc((void **)&c->g[s].g3, HW * sizeof(float4));
         if (e == hipSuccess) e = hipMalloc((void **)&c->g[s].g4, HW * sizeof(float2));
-        if (e == hipSuccess) e = hipMalloc(&c->vol[s], V * velem(c));
+        if (e == hipSuccess && dtype == PSM_U8) e = hipMalloc(&c->vol[s], V * velem(c));   // PSM_F32: on first use (ensure_vol)
         if (e == hipSuccess && dtype == PSM_U8) e = hipMalloc((void **)&c->p4[s], HW * 4);
     }
     if (e == hipSuccess && dtype == PSM_U8) e = hipMalloc((void **)&c->fvol, V * sizeof(float));
@@ -438,6 +489,7 @@ int psm_upload_pair(psm_ctx *c, const void *l, const void *r, int channels, size
     c->have_valid = false;
     c->raw_rows[0] = c->raw_rows[1] = psm_ctx::RAW_ALL;   // nothing virtual survives a new pair
     c->fgf_virtual[0] = c->fgf_virtual[1] = 0;
+    c->gf_virtual[0] = c->gf_virtual[1] = false;
     return 0;
 }
 
@@ -449,6 +501,7 @@ int psm_cost_construct(psm_ctx *c)
     const double t0 = now_us();
     if (run_prep(c)) return 1;  // CVC::preprocess belongs to this stage (src/DispEst.cpp:232-233)
     c->fgf_virtual[0] = c->fgf_virtual[1] = 0;   // a new cost volume replaces whatever was pending
+    c->gf_virtual[0] = c->gf_virtual[1] = false;
     // Lazy cost volume: when the fused filter will consume the costs (float mode, marching kernels,
     // fusion not disabled) they are built inside that kernel and never written to HBM.
     const bool lazy = c->dtype == PSM_F32 && c->opt_variant == 0 && !(c->march.flags & (16 | 128)) && c->H >= 8;
@@ -459,6 +512,7 @@ int psm_cost_construct(psm_ctx *c)
         } else if (lazy) {
             c->raw_rows[s] = psm_ctx::RAW_NONE;
         } else {
+            if (ensure_vol(c, s)) return 1;
             launch_cvc_rows(c, s, 0, c->H);
             c->raw_rows[s] = psm_ctx::RAW_ALL;
         }
@@ -475,11 +529,37 @@ static int filter_side(psm_ctx *c, int side, bool stage_b)
     const int W = c->W, H = c->H;
     if (!c->have_g1 && run_prep(c)) return 1;  // volume came from psm_upload_volume
     if (fgf_flush(c, side)) return 1;
+    if (c->gf_virtual[side] && materialize(c, side)) return 1;   // filtering an already filtered (virtual) volume: make it real first
     if ((c->march.flags & 256) && !c->hs9) PSM_HIP(c, hipMalloc((void **)&c->hs9, (size_t)9 * W * H * sizeof(double)));
     {
         Prof p(c, PSM_K_GUIDE);
         launch_guidance(c->stream, c->g[side], c->hs9, W, H, (c->march.flags & 256) ? 1 : 0);
     }
+    // Default: the fused kernel in "select" mode - the WTA over the local slices runs inside the filter, the filtered
+    // volume stays virtual (flag 8192 forces the storing form; 16 / 512 / the direct variant select other filters)
+    if (stage_b && c->dtype == PSM_F32 && c->opt_variant == 0 && !(c->march.flags & (16 | 512 | 8192)) && H >= 8) {
+        const bool lazy = c->raw_rows[side] != psm_ctx::RAW_ALL;
+        // flag 16384: the two-columns-per-lane, channel-split form (k_cvf_q2, psm_q2.hip: 14 % fewer VALU instructions,
+        // but its four-stage workgroups keep the SIMDs less busy - measured slower, kept as a tested variant)
+        const bool q2 = lazy && (c->march.flags & 16384);
+        const PcPlan pl = q2 ? q2_plan(W, H, c->Dloc, c->march.seg_rows) : pc_plan(W, H, c->Dloc, c->march.seg_rows, 1);
+        if (ensure_gf_scratch(c, pl.scratch_bytes())) return 1;
+        const size_t HW = (size_t)W * H;
+        {
+            Prof p(c, PSM_K_CVF_F);
+            if (q2) launch_cvf_q2(c->stream, c->march, c->g[side], W, H, c->Dloc, c->g[1 - side].g1, c->d0, 1 + side, c->gf_scratch);
+            else launch_cvf_select(c->stream, c->march, lazy ? nullptr : (const float *)c->vol[side], c->g[side], W, H, c->Dloc, c->g[1 - side].g1,
+                                   c->d0, lazy ? 1 + side : 0, c->gf_scratch);
+        }
+        {
+            Prof p(c, PSM_K_WTA);
+            if (q2) launch_chunk_min2(c->stream, c->march, W, H, c->Dloc, c->gf_scratch, c->keys + side * HW, nullptr);
+            else launch_chunk_min(c->stream, c->march, W, H, c->Dloc, c->gf_scratch, c->keys + side * HW, nullptr);
+        }
+        c->gf_virtual[side] = true;
+        return check_launch(c, "cvf (fused, select mode)");
+    }
+    if (c->dtype == PSM_F32 && ensure_vol(c, side)) return 1;
     float *fv = (float *)c->vol[side];
     if (c->dtype == PSM_U8) {
         fv = c->fvol;
@@ -599,6 +679,8 @@ int psm_cost_filter_fgf(psm_ctx *c, int sub)
     // small planes: ism, msm, v1 (float4), v2 (float2) per pixel; ab (scratch) and one mab per side (float4) per small voxel
     const size_t n = (size_t)ws * hs, need = n * (3 * sizeof(float4) + sizeof(float2)) + 3 * n * c->Dloc * sizeof(float4);
     if (fgf_flush(c, 0) || fgf_flush(c, 1)) return 1;   // filtering an already FGF-filtered volume: make it real first
+    for (int side = 0; side < 2; ++side)
+        if (c->gf_virtual[side] && materialize(c, side)) return 1;
     if (c->fgf_bytes < need) {
         PSM_HIP(c, hipStreamSynchronize(c->stream));
         (void)hipFree(c->fgf);
@@ -622,6 +704,7 @@ int psm_cost_filter_fgf(psm_ctx *c, int sub)
         launch_fgf_model(c->stream, (const float *)c->vol[side], c->g[side].g1, c->g[1 - side].g1, c->W, c->H, c->Dloc, c->d0, sub, mode,
                          msm, v1, v2, ab, c->fgf_mab[side]);
         if (keep_virtual) c->fgf_virtual[side] = sub;
+        else if (ensure_vol(c, side)) return 1;
         else launch_fgf_apply(c->stream, (float *)c->vol[side], c->g[side].g1, c->W, c->H, c->Dloc, sub, c->fgf_mab[side]);
         c->raw_rows[side] = psm_ctx::RAW_ALL;   // vol[side] holds (or, while virtual, stands for) filtered data
     }
@@ -663,7 +746,12 @@ static int wta_side(psm_ctx *c, int s, long long *keys_s, uint8_t *map_s)
 {
     const size_t HW = (size_t)c->W * c->H;
     Prof p(c, PSM_K_WTA);
-    if (c->fgf_virtual[s]) {
+    if (c->gf_virtual[s]) {
+        // the select-mode filter already reduced this side: keys[s] holds the packed minima over the local slices
+        const long long *src = c->keys + s * HW;
+        if (keys_s && keys_s != src) PSM_HIP(c, hipMemcpyAsync(keys_s, src, HW * sizeof(long long), hipMemcpyDeviceToDevice, c->stream));
+        if (map_s) launch_merge(c->stream, src, HW, 1, (int)HW, map_s);
+    } else if (c->fgf_virtual[s]) {
         long long *k = keys_s ? keys_s : c->keys + s * HW;
         launch_fgf_apply_wta(c->stream, c->g[s].g1, c->W, c->H, c->Dloc, c->d0, c->fgf_virtual[s], c->fgf_mab[s], k);
         if (map_s) launch_merge(c->stream, k, HW, 1, (int)HW, map_s);
@@ -686,7 +774,7 @@ static int wta_launch(psm_ctx *c, long long *keys, uint8_t *maps)
 // the volume a WTA is about to read: real data, or a virtual FGF result (consumed without materialising it)
 static int wta_ready(psm_ctx *c, int side)
 {
-    return c->fgf_virtual[side] ? 0 : materialize(c, side);
+    return (c->fgf_virtual[side] || c->gf_virtual[side]) ? 0 : materialize(c, side);
 }
 
 int psm_disp_select(psm_ctx *c, uint8_t *lmap, uint8_t *rmap, size_t stride)
@@ -910,6 +998,8 @@ int psm_upload_volume(psm_ctx *c, int side, int d0, int d1, const void *host)
     if (bind(c)) return 1;
     if (c->have_cost && c->have_g1 && materialize(c, side)) return 1;   // a partial upload must not leave virtual slices
     if (fgf_flush(c, side)) return 1;
+    c->gf_virtual[side] = false;
+    if (ensure_vol(c, side)) return 1;
     const size_t S = (size_t)c->W * c->H * velem(c);
     PSM_HIP(c, hipMemcpyAsync((char *)c->vol[side] + (size_t)(d0 - c->d0) * S, host, (size_t)(d1 - d0) * S, hipMemcpyHostToDevice, c->stream));
     PSM_HIP(c, hipStreamSynchronize(c->stream));

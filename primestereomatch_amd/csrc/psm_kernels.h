@@ -42,6 +42,26 @@ void launch_cvf_b(hipStream_t s, int variant, March m, const float4 *ab, float *
 // cvc_mode 0: read the cost slices from vin; 1/2: build the left/right costs on the fly from the g1 planes
 void launch_cvf_fused(hipStream_t s, March m, const float *vin, float *vout, Guidance g, int W, int H, int Dloc,
                       int ybeg, int yend, const float4 *g1_other, int d_begin, int cvc_mode);
+// The same kernel with the winner-takes-all fused in ("select" mode): the filtered volume is never written; per pixel
+// the packed WTA key over the local slices goes to keys[H*W] and / or the disparity to map[H*W] (either may be NULL).
+// scratch: pc_plan(...).scratch_bytes() bytes (chunk planes).
+struct PcPlan {
+    int ngroups, nsegs, seg_rows, DC, nchunks, nbmax;
+    size_t rec_per_chunk;                                        // records per chunk plane
+    int rec_bytes;                                               // bytes per record (costs + disparities)
+    size_t scratch_bytes() const { return rec_per_chunk * (size_t)nchunks * rec_bytes; }
+};
+PcPlan pc_plan(int W, int rows, int Dloc, int seg_rows_opt, int mode);
+PcPlan pc_plan_cols(int W, int rows, int Dloc, int seg_rows_opt, int mode, int cols);
+void launch_cvf_select(hipStream_t s, March m, const float *vin, Guidance g, int W, int H, int Dloc, const float4 *g1_other,
+                       int d_begin, int cvc_mode, void *scratch);
+void launch_chunk_min(hipStream_t s, March m, int W, int H, int Dloc, void *scratch, long long *keys, uint8_t *map);
+// Select mode with two columns per lane and the channels split over the waves (psm_q2.hip): the default product kernel
+// when the costs are built on the fly (cvc_mode 1 / 2).  scratch: q2_plan(...).scratch_bytes() bytes.
+PcPlan q2_plan(int W, int H, int Dloc, int seg_rows_opt);
+void launch_cvf_q2(hipStream_t s, March m, Guidance g, int W, int H, int Dloc, const float4 *g1_other, int d_begin, int cvc_mode,
+                   void *scratch);
+void launch_chunk_min2(hipStream_t s, March m, int W, int H, int Dloc, void *scratch, long long *keys, uint8_t *map);
 // two-columns-per-lane form of the fused filter (psm_pc2.hip); reads planar copies of the guidance (launch_soa:
 // 14 planes of H*W floats per side; only_g1: planes 0..3 only).  Needs W % 4 == 0.
 void launch_soa(hipStream_t s, Guidance g, int W, int H, float *soa, int only_g1);

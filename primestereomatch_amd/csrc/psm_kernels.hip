@@ -573,291 +573,6 @@ __global__ __launch_bounds__(256) void k_cvf_b(const float4 *__restrict__ ab, fl
 #undef PSM_ISSUE_B
 }
 
-// ---- fused guided filter, producer/consumer form ---------------------------------------------------
-// Stage A and stage B of the guided filter chained without the (a0,a1,a2,b) round trip through HBM (16 B/voxel
-// written and read again by the two-stage kernels).  Both sliding trees in one wave need 250 VGPRs (1-2 waves per
-// SIMD; measured 8.3-9.3 ms per 1080p x 256 volume, latency bound), so the two halves run in DIFFERENT waves of
-// one workgroup and the linear models are handed over through LDS:
-//   producer waves ("A"): cost p (read, or built from the g1 planes), g1 -> window sums -> solve -> model rows
-//                         into an LDS ring of PC_RING batches of four rows
-//   consumer waves ("B"): model rows from the ring (REFLECT_101 of the model planes = ring index arithmetic,
-//                         columns and rows, so the image border needs no separate kernel) -> window sums -> q
-// One barrier per batch of four rows; B runs two batches behind A, the merged 16-byte-per-lane store of q one
-// batch behind B.  Each wave carries one set of trees (~146 VGPRs, 3 waves per SIMD, 3 workgroups per CU).
-// Default layout: 2 A waves x 52 model columns feed 2 B waves x 48 output columns = 96 outputs = three whole
-// 128-byte lines per row and workgroup (wider, unaligned layouts issue fewer instructions per voxel but write
-// slower).  The kernel is VALU-issue bound: 2.1e9 wave-instructions per 1080p x 256 launch at ~90 % of the
-// SIMDs' issue slots (rocprofv3 SQ_INSTS_VALU / GRBM_GUI_ACTIVE, profiles/); all of v_add_f64, v_cvt, v_ldexp_f64,
-// DPP moves and fp32 ops issue at the same rate (scripts/exp/rate.hip), ds_bpermute costs ~5 of them.
-#ifndef PSM_PC_ATTR
-#define PSM_PC_ATTR
-#endif
-constexpr int PC_RING = 4;   // batches of four model rows kept in LDS
-#ifndef PSM_PC_ABL
-#define PSM_PC_ABL 0   // ablation experiments (invalid results): 16 every lane loads column 0, 32 every step loads row 0
-#endif
-#ifndef PSM_PC_LAYOUT
-#define PSM_PC_LAYOUT 0
-#endif
-#ifndef PSM_PC_NT
-#define PSM_PC_NT 1        // 1: nontemporal stores of the output rows (the filtered volume is next read by the WTA pass, long after it left the L2)
-#endif
-#if PSM_PC_LAYOUT == 0      // 2 A + 2 B waves, 52 / 48 columns: 96 outputs = 3 full lines per workgroup
-constexpr int PC_NA = 2, PC_NB = 2, PC_OUT_A = 52, PC_OUT_B = 48, PC_COLS = 96;
-#elif PSM_PC_LAYOUT == 1    // 3 A + 3 B waves, 57 / 54,54,52 columns: 160 outputs = 5 full lines
-constexpr int PC_NA = 3, PC_NB = 3, PC_OUT_A = 57, PC_OUT_B = 54, PC_COLS = 160;
-#elif PSM_PC_LAYOUT == 2    // 2 A + 2 B waves, 57 / 52,52 columns (not line aligned)
-constexpr int PC_NA = 2, PC_NB = 2, PC_OUT_A = 57, PC_OUT_B = 52, PC_COLS = 104;
-#elif PSM_PC_LAYOUT == 3    // 4 A + 4 B waves, 50 / 48 columns: 192 outputs = 6 full lines
-constexpr int PC_NA = 4, PC_NB = 4, PC_OUT_A = 50, PC_OUT_B = 48, PC_COLS = 192;
-#elif PSM_PC_LAYOUT == 4    // 1 A + 1 B wave, 39 / 32 columns: 32 outputs = 1 full line
-constexpr int PC_NA = 1, PC_NB = 1, PC_OUT_A = 39, PC_OUT_B = 32, PC_COLS = 32;
-#endif
-constexpr int PC_MCOLS = PC_NA * PC_OUT_A;   // model columns per workgroup (>= PC_COLS + 7)
-static_assert(PC_MCOLS >= PC_COLS + 7 && (PC_COLS % 4) == 0 && PC_OUT_A <= 57 && PC_OUT_B <= 57, "bad producer/consumer layout");
-
-// CVC = 0: the cost slice is read from `vin`.  CVC = 1 (left volume) / 2 (right volume): the cost volume
-// is never materialised - the producer waves evaluate myCostGrd (src/CVC.cpp:18-39) for their input
-// column on the fly from the two g1 planes (`G1` = this side's image, `Gother` = the other one), exactly
-// as k_cvc does; saves the 4 B/voxel write of CostConst and the 4 B/voxel read here.
-typedef unsigned pc_u2 __attribute__((ext_vector_type(2)));
-typedef unsigned pc_u4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t pc_rsrc(const void *p, unsigned bytes)
-{
-    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p), 0, bytes, 0x00020000);
-}
-__device__ __forceinline__ float pc_load1(__amdgpu_buffer_rsrc_t r, int voff, int soff)
-{
-    return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
-}
-__device__ __forceinline__ float2 pc_load2(__amdgpu_buffer_rsrc_t r, int voff, int soff)
-{
-    const pc_u2 v = __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0);
-    return make_float2(__uint_as_float(v.x), __uint_as_float(v.y));
-}
-__device__ __forceinline__ float4 pc_load4(__amdgpu_buffer_rsrc_t r, int voff, int soff)
-{
-    const pc_u4 v = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
-    return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
-}
-
-template <bool VEC4, int CVC>
-__global__ __launch_bounds__(64 * (PC_NA + PC_NB)) PSM_PC_ATTR void k_cvf_pc(const float *__restrict__ vin, float *__restrict__ vout,
-                                               const float4 *__restrict__ G1, const float4 *__restrict__ G2,
-                                               const float4 *__restrict__ G3, const float2 *__restrict__ G4,
-                                               int W, int H, int Dloc, int ngroups, int nsegs, int seg_rows,
-                                               int ybeg, int yend, const float4 *__restrict__ Gother, int d_begin)
-{
-    // Model rows live in a ring of PC_RING batches of four rows; consumers run two batches behind the
-    // producers, so every model row the second box filter can ask for - including the REFLECT_101 rows at
-    // the top and bottom of the image, which are earlier/later rows of the same ring - is still present.
-    __shared__ __attribute__((aligned(16))) float4 ring[PC_RING][4][PC_MCOLS];
-    __shared__ __attribute__((aligned(16))) float qbuf[2][4][PC_COLS];     // output rows, two batches
-    // Workgroup -> (column group, segment, slice).  Blocks are observed to go round-robin over the 8 XCDs
-    // (block b -> XCD b%8): every XCD owns a contiguous range of (group, segment) pairs and walks the
-    // slices of one pair back to back, so the guidance rows its resident workgroups are reading (few
-    // pairs, neighbouring rows, many slices) fit its 4 MB L2 instead of coming from the MALL.  Speed only.
-    int id = blockIdx.x;
-    const int npairs = ngroups * nsegs;               // (column group, segment) pairs
-    const int ppx = (npairs + 7) >> 3;                // pairs per XCD (the launcher makes npairs % 8 == 0 if it can)
-    const int xcd = id & 7, jj = id >> 3;
-    const int d = jj % Dloc, pl = jj / Dloc;          // slices fastest within an XCD
-    const int pair = xcd * ppx + pl;
-    if (pl >= ppx || pair >= npairs) return;
-    const int g = pair % ngroups, seg = pair / ngroups;
-    // (which hardware wave takes which role does not matter: swapping / interleaving the producer and consumer
-    // waves, per workgroup or pseudo-randomly, changed nothing - the CU balances the SIMDs itself)
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const bool is_a = wave < PC_NA;
-    const int xg = g * PC_COLS;                       // first output column of the workgroup
-    const int xm0 = xg - 4;                           // first model column of the workgroup
-    const int y0 = ybeg + seg * seg_rows, y1 = min(yend, y0 + seg_rows);   // output rows [y0, y1)
-    const int mstart = max(0, y0 - 4);                // model rows produced: mstart .. mend
-    const int mend = min(H - 1, y1 + 2);
-    const int nbA = (mend - mstart + 1 + 3) >> 2;     // producer batches
-    const int nf = (y1 - y0) + 7;                     // consumer feeds (model rows y0-4 .. y1+2, reflected)
-    const int nbB = (nf + 3) >> 2;                    // consumer batches
-    const int iters = nbB + 3;                        // barriers executed by every wave
-    const int i1 = ((lane + 1) & 63) << 2, i2 = ((lane + 2) & 63) << 2, i4 = ((lane + 4) & 63) << 2;
-    (void)i1;
-    const size_t HW = (size_t)H * W;
-
-    if (is_a) {
-        // ---------------- producer: stage A ----------------
-        // step s reads input row mstart-5+s; from step 8 on it yields model row mstart+(s-8)
-        const int xa0 = xm0 + wave * PC_OUT_A;        // first model column of this wave
-        const int ci = r101c(xa0 - 4 + lane, W);      // input column of this lane
-        const int xa = xa0 + lane;                    // model column of this lane
-        const int xac = xa < 0 ? 0 : (xa > W - 1 ? W - 1 : xa);
-        const bool mvalid = lane < PC_OUT_A;
-        const float *vd = vin + (size_t)d * HW;
-        const int dg = d_begin + d;                   // global disparity of this slice
-        // buildCV_left: partner x-d while x >= d; buildCV_right: partner x+d while x < W-d (src/CVC.cpp:135-146,165-176)
-        const bool inb = CVC == 2 ? (ci < W - dg) : (ci >= dg);
-        const int cpart = CVC == 2 ? min(ci + dg, W - 1) : max(ci - dg, 0);
-        const bool any_border = CVC != 0 && __builtin_amdgcn_ballot_w64(!inb) != 0;
-        VTree t0 = {}, t1 = {}, t2 = {}, t3 = {};
-        float pin[2];
-        float4 oth[2], gin[2], o2[2], o3[2];
-        float2 o4[2];
-        // raw buffer loads: descriptors and row offsets in scalar registers, one constant 32-bit byte offset per lane
-        const __amdgpu_buffer_rsrc_t rG1 = pc_rsrc(G1, (unsigned)HW * 16u), rG2 = pc_rsrc(G2, (unsigned)HW * 16u);
-        const __amdgpu_buffer_rsrc_t rG3 = pc_rsrc(G3, (unsigned)HW * 16u), rG4 = pc_rsrc(G4, (unsigned)HW * 8u);
-        const __amdgpu_buffer_rsrc_t rGo = pc_rsrc(CVC == 0 ? G1 : Gother, (unsigned)HW * 16u);
-        const __amdgpu_buffer_rsrc_t rV = pc_rsrc(CVC == 0 ? (const void *)vd : (const void *)G1, (unsigned)HW * 4u);
-#if PSM_PC_ABL & 16   // experiment: every lane reads column 0 (same instruction count, minimal data movement; invalid results)
-        const int vci = 0, vcp = 0, vxa = 0;
-#elif PSM_PC_ABL & 32 // experiment: rows collapse to row 0 as well
-        const int vci = ci * 16, vcp = cpart * 16, vxa = xac * 16;
-#else
-        const int vci = ci * 16, vcp = cpart * 16, vxa = xac * 16;
-#endif
-#define PSM_ISSUE_PA(SLOT, STEP)                                                        \
-    {                                                                                   \
-        const int row_ = (PSM_PC_ABL & 32) ? 0 : r101c(mstart - 5 + (STEP), H) * W;     \
-        int ya_ = mstart - 8 + (STEP);                                                  \
-        ya_ = ya_ < 0 ? 0 : (ya_ > H - 1 ? H - 1 : ya_);                                \
-        const int oa_ = (PSM_PC_ABL & 32) ? 0 : ya_ * W;                                \
-        if (CVC == 0) pin[SLOT] = pc_load1(rV, vci >> 2, row_ * 4);                     \
-        else oth[SLOT] = pc_load4(rGo, vcp, row_ * 16);                                 \
-        gin[SLOT] = pc_load4(rG1, vci, row_ * 16);                                      \
-        o2[SLOT] = pc_load4(rG2, vxa, oa_ * 16);                                        \
-        o3[SLOT] = pc_load4(rG3, vxa, oa_ * 16);                                        \
-        o4[SLOT] = pc_load2(rG4, vxa >> 1, oa_ * 8);                                    \
-    }
-        // one step: consume the loads of step S (slot K&1), issue those of step S+1
-#define PSM_STEP_PA(K, S, DST)                                                                      \
-    {                                                                                               \
-        PSM_ISSUE_PA((K + 1) & 1, (S) + 1)                                                          \
-        float p;                                                                                    \
-        if (CVC == 0) p = pin[K & 1];                                                               \
-        else {                                                                                      \
-            p = cost_pair(gin[K & 1], oth[K & 1]);                                                  \
-            if (any_border) {   /* only where x < d (left) / x >= W-d (right) occurs in this wave */   \
-                asm volatile("; border cost");   /* keeps this a real branch */                     \
-                const float cb_ = cost_border(gin[K & 1]);                                          \
-                p = inb ? p : cb_;                                                                  \
-            }                                                                                       \
-        }                                                                                           \
-        double h0 = hsum8(p, i1, i2, i4);                                                           \
-        double h1 = hsum8(__fmul_rn(gin[K & 1].x, p), i1, i2, i4);                                  \
-        double h2 = hsum8(__fmul_rn(gin[K & 1].y, p), i1, i2, i4);                                  \
-        double h3 = hsum8(__fmul_rn(gin[K & 1].z, p), i1, i2, i4);                                  \
-        double n0 = vstep<K>(t0, h0), n1 = vstep<K>(t1, h1), n2 = vstep<K>(t2, h2), n3 = vstep<K>(t3, h3); \
-        float4 r = solve_ab(box_out(n0), box_out(n1), box_out(n2), box_out(n3), o2[K & 1], o3[K & 1], o4[K & 1]); \
-        if ((DST) != nullptr && mvalid) (DST)[K * PC_MCOLS] = r;                                    \
-        __builtin_amdgcn_sched_barrier(0);                                                          \
-    }
-        PSM_ISSUE_PA(0, 0) __builtin_amdgcn_sched_barrier(0);
-        {   // warm-up: 8 rows fill the tree (loop bodies stay free of conditionals around the tree updates:
-            // a conditional turns the trees into loop-carried phis and doubles their registers)
-            float4 *const none = nullptr;
-            PSM_STEP_PA(0, 0, none) PSM_STEP_PA(1, 1, none) PSM_STEP_PA(2, 2, none) PSM_STEP_PA(3, 3, none)
-            PSM_STEP_PA(0, 4, none) PSM_STEP_PA(1, 5, none) PSM_STEP_PA(2, 6, none) PSM_STEP_PA(3, 7, none)
-        }
-        for (int b = 0; b < nbA; ++b) {
-            const int s0 = 8 + b * 4;
-            float4 *dst = &ring[b & (PC_RING - 1)][0][wave * PC_OUT_A + lane];
-            PSM_STEP_PA(0, s0, dst) PSM_STEP_PA(1, s0 + 1, dst) PSM_STEP_PA(2, s0 + 2, dst) PSM_STEP_PA(3, s0 + 3, dst)
-            __syncthreads();
-        }
-        for (int b = nbA; b < iters; ++b) __syncthreads();
-#undef PSM_STEP_PA
-#undef PSM_ISSUE_PA
-    } else {
-        // ---------------- consumer: stage B ----------------
-        // feed j (j = 0 .. nf-1) is model row r101(y0-4+j); from feed 7 on the tree yields output row y0+j-7
-        const int wb = wave - PC_NA;
-        const int bwidth = wb < PC_NB - 1 ? PC_OUT_B : PC_COLS - (PC_NB - 1) * PC_OUT_B;
-        const int xb0 = xg + wb * PC_OUT_B;           // first output column of this wave
-        const int xmod = xb0 - 4 + lane;              // model column this lane consumes
-        int mc = r101(xmod, W) - xm0;                 // REFLECT_101 of the model planes, as ring column
-        mc = mc < 0 ? 0 : (mc > PC_MCOLS - 1 ? PC_MCOLS - 1 : mc);
-        const int xb = xb0 + lane;                    // output column of this lane
-        const int xbc = min(xb, W - 1);
-        float *od = vout + (size_t)d * HW;
-        const int amax = 4 * nbA - 1;
-        VTree t0 = {}, t1 = {}, t2 = {}, t3 = {};
-        float o1x[4], o1y[4], o1z[4];                 // g1.xyz at (output row, output column), one batch ahead
-        const __amdgpu_buffer_rsrc_t rG1 = pc_rsrc(G1, (unsigned)HW * 16u);
-        const int vxb = xbc * 16;
-#define PSM_ISSUE_PB(SLOT, J)                                                           \
-    {                                                                                   \
-        int yb_ = y0 + (J) - 7;                                                         \
-        yb_ = yb_ < 0 ? 0 : (yb_ > H - 1 ? H - 1 : yb_);                                \
-        const float4 g_ = pc_load4(rG1, vxb, yb_ * W * 16);                             \
-        o1x[SLOT] = g_.x; o1y[SLOT] = g_.y; o1z[SLOT] = g_.z;                           \
-    }
-        // ring address of the model row that feed J consumes (wave-uniform arithmetic)
-        auto model_of = [&](int J) -> const float4 * {
-            int a = r101(y0 - 4 + J, H) - mstart;
-            a = a < 0 ? 0 : (a > amax ? amax : a);
-            return &ring[(a >> 2) & (PC_RING - 1)][a & 3][mc];
-        };
-        // merged store of output batch `c` (rows parked in qbuf[c & 1] one iteration earlier)
-        auto store_batch = [&](int c) {
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {          // row k of the batch is stored by B wave k % PC_NB
-                const int j = 4 * c + k;
-                const int yo = y0 + j - 7;
-                if (k % PC_NB == wb && j >= 7 && yo < y1) {
-                    float *row = od + (size_t)yo * W + xg;
-                    const float *src = &qbuf[c & 1][k][0];
-                    if (VEC4) {
-                        const int cc = lane * 4;
-                        if (lane < PC_COLS / 4 && xg + cc < W) {
-#if PSM_PC_NT
-                            __builtin_nontemporal_store(*reinterpret_cast<const f4v *>(src + cc), reinterpret_cast<f4v *>(row + cc));
-#else
-                            *reinterpret_cast<float4 *>(row + cc) = *reinterpret_cast<const float4 *>(src + cc);
-#endif
-                        }
-                    } else {
-#pragma unroll
-                        for (int cc = lane; cc < PC_COLS; cc += 64)
-                            if (xg + cc < W) row[cc] = src[cc];
-                    }
-                }
-            }
-        };
-        PSM_ISSUE_PB(0, 0) PSM_ISSUE_PB(1, 1) PSM_ISSUE_PB(2, 2) PSM_ISSUE_PB(3, 3)
-        __syncthreads();                               // iteration 0
-        __syncthreads();                               // iteration 1
-        for (int b = 2; b <= nbB + 1; ++b) {           // iteration b: consume feed batch c = b-2
-            const int c = b - 2;
-            if (c >= 1) store_batch(c - 1);
-            {
-                const int j0 = 4 * c;
-                float4 a_cur = *model_of(j0), a_nxt;
-                float qv[4];
-#define PSM_STEP_PB(K)                                                                              \
-    {                                                                                               \
-        if (K < 3) a_nxt = *model_of(j0 + K + 1);     /* model row of the next feed, one step ahead */ \
-        double h0 = hsum8(a_cur.x, i1, i2, i4);                                                     \
-        double h1 = hsum8(a_cur.y, i1, i2, i4);                                                     \
-        double h2 = hsum8(a_cur.z, i1, i2, i4);                                                     \
-        double h3 = hsum8(a_cur.w, i1, i2, i4);                                                     \
-        double n0 = vstep<K>(t0, h0), n1 = vstep<K>(t1, h1), n2 = vstep<K>(t2, h2), n3 = vstep<K>(t3, h3); \
-        qv[K] = __fadd_rn(__fadd_rn(__fadd_rn(box_out(n3), __fmul_rn(box_out(n0), o1x[K])),        \
-                                    __fmul_rn(box_out(n1), o1y[K])), __fmul_rn(box_out(n2), o1z[K])); \
-        PSM_ISSUE_PB(K, j0 + K + 4)                                                                 \
-        a_cur = a_nxt;                                                                              \
-        __builtin_amdgcn_sched_barrier(0);                                                          \
-    }
-                PSM_STEP_PB(0) PSM_STEP_PB(1) PSM_STEP_PB(2) PSM_STEP_PB(3)
-#undef PSM_STEP_PB
-#pragma unroll
-                for (int k = 0; k < 4; ++k)
-                    if (lane < bwidth) qbuf[c & 1][k][wb * PC_OUT_B + lane] = qv[k];
-            }
-            __syncthreads();
-        }
-        store_batch(nbB - 1);                          // iteration nbB+2
-        __syncthreads();
-#undef PSM_ISSUE_PB
-    }
-}
-
 // ---- plain box filter of every slice ----------------------------------------------------------
 template <bool VEC4>
 __global__ __launch_bounds__(256) void k_box8(const float *__restrict__ vol, float *__restrict__ out, int W,
@@ -1057,47 +772,6 @@ void launch_cvf_b(hipStream_t s, int variant, March m, const float4 *ab, float *
         hipLaunchKernelGGL(k_cvf_b<true>, dim3(nblocks), dim3(256), 0, s, ab, vol, (const float4 *)gd.g1, W, H, Dloc, ngroups, g.nsegs, g.seg_rows, ybeg, yend);
     else
         hipLaunchKernelGGL(k_cvf_b<false>, dim3(nblocks), dim3(256), 0, s, ab, vol, (const float4 *)gd.g1, W, H, Dloc, ngroups, g.nsegs, g.seg_rows, ybeg, yend);
-}
-
-void launch_cvf_fused(hipStream_t s, March m, const float *vin, float *vout, Guidance gd, int W, int H, int Dloc,
-                      int ybeg, int yend, const float4 *g1_other, int d_begin, int cvc_mode)
-{
-    if (yend <= ybeg) return;
-    const int rows = yend - ybeg;
-    int seg_rows = m.seg_rows;
-    if (seg_rows <= 0) {
-        // Segment count k: every segment re-walks 14 halo rows, and the launch runs in rounds of resident
-        // workgroups - per XCD ceil(pairs/8) (column group, segment) pairs x Dloc slices over 32 CUs x 3 workgroups.
-        // Pick the k with the smallest (rounds x rows walked per workgroup); matters most for a disparity shard with
-        // few slices, where a poor k leaves a round mostly empty (Dloc = 32 at 1080p: k = 6 instead of 8, -7 %).
-        const int ng = (W + PC_COLS - 1) / PC_COLS;
-        const int kmax = rows / 64 > 1 ? rows / 64 : 1;
-        long best = -1;
-        int k = 1;
-        for (int kk = 1; kk <= kmax && kk <= 32; ++kk) {
-            const long per_xcd = (long)((ng * kk + 7) / 8) * Dloc;
-            const long rounds = (per_xcd + 95) / 96;
-            const long cost = rounds * ((rows + kk - 1) / kk + 14);
-            if (best < 0 || cost < best) { best = cost; k = kk; }
-        }
-        seg_rows = (rows + k - 1) / k;
-    }
-    if (seg_rows > rows) seg_rows = rows;
-    const int nsegs = (rows + seg_rows - 1) / seg_rows;
-    {
-        const int ngroups = (W + PC_COLS - 1) / PC_COLS;
-        const int nblocks = 8 * ((ngroups * nsegs + 7) / 8) * Dloc;
-        const dim3 blk(64 * (PC_NA + PC_NB));
-#define PSM_LAUNCH_PC(V4, CV)                                                                                              \
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_cvf_pc<V4, CV>), dim3(nblocks), blk, 0, s, vin, vout, (const float4 *)gd.g1,      \
-                       (const float4 *)gd.g2, (const float4 *)gd.g3, (const float2 *)gd.g4, W, H, Dloc, ngroups, nsegs,   \
-                       seg_rows, ybeg, yend, g1_other, d_begin)
-        const bool v4 = (W & 3) == 0;
-        if (cvc_mode == 1) { if (v4) PSM_LAUNCH_PC(true, 1); else PSM_LAUNCH_PC(false, 1); }
-        else if (cvc_mode == 2) { if (v4) PSM_LAUNCH_PC(true, 2); else PSM_LAUNCH_PC(false, 2); }
-        else { if (v4) PSM_LAUNCH_PC(true, 0); else PSM_LAUNCH_PC(false, 0); }
-#undef PSM_LAUNCH_PC
-    }
 }
 
 void launch_box8(hipStream_t s, int variant, March m, const float *vol, float *out, int W, int H, int Dloc)

@@ -1,0 +1,491 @@
+// psm_pc.hip - k_cvf_pc: the product kernel of the DispEst hot path on gfx950 - cost build (CVC) + both box-filter
+// rounds of the guided filter (CVF) + (optionally) the winner-takes-all (DispSel) in ONE kernel.
+// Arithmetic contract as in psm_kernels.hip: op-for-op fp32, fp64 balanced-tree box sums, no FMA contraction.
+// Reference arithmetic: src/CVC.cpp:18-39,122-179, src/CVF.cpp:72-165, src/DispSel.cpp:83-109.
+//
+// Stage A and stage B of the guided filter are chained without the (a0,a1,a2,b) round trip through HBM (16 B/voxel
+// written and read again by the two-stage kernels).  Both sliding trees in one wave need 250 VGPRs (1-2 waves per
+// SIMD; measured 8.3-9.3 ms per 1080p x 256 volume, latency bound), so the two halves run in DIFFERENT waves of
+// one workgroup and the linear models are handed over through LDS:
+//   producer waves ("A"): cost p (read, or built from the g1 planes), g1 -> window sums -> solve -> model rows
+//                         into an LDS ring of PC_RING batches of four rows
+//   consumer waves ("B"): model rows from the ring (REFLECT_101 of the model planes = ring index arithmetic,
+//                         columns and rows, so the image border needs no separate kernel) -> window sums -> q
+// One barrier per batch of four rows; B runs two batches behind A.
+//
+// MODE 0 ("store"): q is written to the filtered volume - merged 16-byte-per-lane rows one batch behind B; layout
+//   2 A waves x 52 model columns -> 2 B waves x 48 output columns = 96 outputs = three whole 128-byte lines per row.
+// MODE 1 ("select"): the filtered volume stays VIRTUAL.  A workgroup walks a chunk of DC consecutive slices of its
+//   (column group, segment) and the consumer waves keep the running strict-'<' minimum of q over the chunk in a
+//   per-chunk scratch plane private to the workgroup: per consumer wave and batch of four rows one 16-byte-per-lane
+//   record of costs and one 4-byte-per-lane record of disparities, laid out [wave][batch][lane] so that a wave reads
+//   and writes whole contiguous kilobytes (read - compare - store by the one lane that owns the pixel: no atomics, no
+//   races).  The planes are touched once per slice and live in L2 / MALL; k_chunk_min then reduces the Dloc/DC chunk
+//   planes to the packed WTA key (or the map) per pixel.  (First version: image-layout planes, one dword load + a
+//   dword and a byte store per row step - slower than storing q, 4.50 vs 4.20 + 0.32 ms: with DC = 8 nearly every row
+//   step improves some lane, and unaligned 4-byte-per-lane stores are the slowest thing the memory path can do.)  Per voxel this replaces a 4-byte HBM store + a 4-byte HBM read (k_wta) by a cached 4-byte
+//   read and a rare store, and - nothing being stored per row - the 128-byte alignment rule of MODE 0 no longer binds:
+//   2 x 57 model columns feed 54 + 53 output columns (84-89 % useful lanes instead of 75-81 %).
+// d = 0 is never a candidate, NaN never wins, the lowest d wins ties (src/DispSel.cpp:91-105): slices are visited in
+// ascending d with strict '<' inside a chunk, and k_chunk_min takes the signed minimum of pack_key_f32 across chunks.
+#include "psm_kernels.h"
+#include "psm_cost.h"
+#include "psm_dev.h"
+
+#include <cstdlib>
+
+namespace psm {
+
+typedef float f4v __attribute__((ext_vector_type(4)));
+
+#ifndef PSM_PC_ATTR
+#define PSM_PC_ATTR
+#endif
+constexpr int PC_RING = 4;   // batches of four model rows kept in LDS
+#ifndef PSM_PC_NT
+#define PSM_PC_NT 1          // MODE 0: nontemporal stores of the output rows (the volume is next read long after it left the L2)
+#endif
+
+template <int MODE> struct PcLayout;
+template <> struct PcLayout<0> { static constexpr int NA = 2, NB = 2, OUT_A = 52, OUT_B = 48, COLS = 96; };
+template <> struct PcLayout<1> { static constexpr int NA = 2, NB = 2, OUT_A = 57, OUT_B = 54, COLS = 107; };
+
+typedef unsigned pc_u2 __attribute__((ext_vector_type(2)));
+typedef unsigned pc_u4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t pc_rsrc(const void *p, unsigned bytes)
+{
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p), 0, bytes, 0x00020000);
+}
+__device__ __forceinline__ float pc_load1(__amdgpu_buffer_rsrc_t r, int voff, int soff)
+{
+    return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
+}
+__device__ __forceinline__ float pc_load1_l2(__amdgpu_buffer_rsrc_t r, int voff, int soff)
+{   // sc1: served by the L2, never by this CU's L1 (the line was last written by this same wave one slice earlier)
+    return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 16));
+}
+__device__ __forceinline__ float2 pc_load2(__amdgpu_buffer_rsrc_t r, int voff, int soff)
+{
+    const pc_u2 v = __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0);
+    return make_float2(__uint_as_float(v.x), __uint_as_float(v.y));
+}
+__device__ __forceinline__ float4 pc_load4(__amdgpu_buffer_rsrc_t r, int voff, int soff)
+{
+    const pc_u4 v = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
+    return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+}
+
+// CVC = 0: the cost slice is read from `vin`.  CVC = 1 (left volume) / 2 (right volume): the cost volume is never
+// materialised - the producer waves evaluate myCostGrd (src/CVC.cpp:18-39) for their input column on the fly from the
+// two g1 planes (`G1` = this side's image, `Gother` = the other one), exactly as k_cvc does.
+template <bool VEC4, int CVC, int MODE>
+__global__ __launch_bounds__(64 * (PcLayout<MODE>::NA + PcLayout<MODE>::NB)) PSM_PC_ATTR void k_cvf_pc(
+    const float *__restrict__ vin, float *__restrict__ vout, const float4 *__restrict__ G1, const float4 *__restrict__ G2,
+    const float4 *__restrict__ G3, const float2 *__restrict__ G4, int W, int H, int Dloc, int ngroups, int nsegs, int seg_rows,
+    int ybeg, int yend, const float4 *__restrict__ Gother, int d_begin, int DC, float *__restrict__ kcost, unsigned *__restrict__ kdisp, int nbmax)
+{
+    using L = PcLayout<MODE>;
+    constexpr int PC_NA = L::NA, PC_NB = L::NB, PC_OUT_A = L::OUT_A, PC_OUT_B = L::OUT_B, PC_COLS = L::COLS;
+    constexpr int PC_MCOLS = PC_NA * PC_OUT_A;   // model columns per workgroup (>= PC_COLS + 7)
+    static_assert(PC_MCOLS >= PC_COLS + 7 && PC_OUT_A <= 57 && PC_OUT_B <= 57 && (MODE != 0 || (PC_COLS % 4) == 0), "bad producer/consumer layout");
+    // Model rows live in a ring of PC_RING batches of four rows; consumers run two batches behind the
+    // producers, so every model row the second box filter can ask for - including the REFLECT_101 rows at
+    // the top and bottom of the image, which are earlier/later rows of the same ring - is still present.
+    __shared__ __attribute__((aligned(16))) float4 ring[PC_RING][4][PC_MCOLS];
+    __shared__ __attribute__((aligned(16))) float qbuf[MODE == 0 ? 2 : 1][MODE == 0 ? 4 : 1][MODE == 0 ? PC_COLS : 4];   // MODE 0: output rows, two batches
+    // Workgroup -> (column group, segment, slice chunk).  Blocks are observed to go round-robin over the 8 XCDs
+    // (block b -> XCD b%8): every XCD owns a contiguous range of (group, segment) pairs and walks the
+    // chunks of one pair back to back, so the guidance rows its resident workgroups are reading (few
+    // pairs, neighbouring rows, many slices) fit its 4 MB L2 instead of coming from the MALL.  Speed only.
+    const int nchunks = (Dloc + DC - 1) / DC;
+    int id = blockIdx.x;
+    const int npairs = ngroups * nsegs;               // (column group, segment) pairs
+    // work items (pair, chunk), pair-major; XCD x takes the x-th eighth of them: a contiguous range of pairs whose chunks
+    // run back to back, and equal work per XCD whatever the pair count
+    const int nitems = npairs * nchunks;
+    const int ipx = (nitems + 7) >> 3;
+    const int xcd = id & 7, jj = id >> 3;
+    const int item = xcd * ipx + jj;
+    if (jj >= ipx || item >= nitems) return;
+    const int pair = item / nchunks, ch = item % nchunks;
+    const int g = pair % ngroups, seg = pair / ngroups;
+    // (which hardware wave takes which role does not matter: swapping / interleaving the producer and consumer
+    // waves, per workgroup or pseudo-randomly, changed nothing - the CU balances the SIMDs itself)
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;   // wave index in an SGPR: everything derived from it is scalar
+    const bool is_a = wave < PC_NA;
+    const int xg = g * PC_COLS;                       // first output column of the workgroup
+    const int xm0 = xg - 4;                           // first model column of the workgroup
+    const int y0 = ybeg + seg * seg_rows, y1 = min(yend, y0 + seg_rows);   // output rows [y0, y1)
+    const int mstart = max(0, y0 - 4);                // model rows produced: mstart .. mend
+    const int mend = min(H - 1, y1 + 2);
+    const int nbA = (mend - mstart + 1 + 3) >> 2;     // producer batches
+    const int nf = (y1 - y0) + 7;                     // consumer feeds (model rows y0-4 .. y1+2, reflected)
+    const int nbB = (nf + 3) >> 2;                    // consumer batches
+    const int iters = nbB + 3;                        // barriers executed by every wave per slice
+    const int i1 = ((lane + 1) & 63) << 2, i2 = ((lane + 2) & 63) << 2, i4 = ((lane + 4) & 63) << 2;
+    (void)i1;
+    const size_t HW = (size_t)H * W;
+
+    const int nds = MODE == 0 ? 1 : DC;               // MODE 0 always runs with DC == 1 (one slice per workgroup)
+    for (int ds = 0; ds < nds; ++ds) {                // the slices of this chunk, ascending d
+    const int d = ch * DC + ds;
+    if (MODE != 0 && d >= Dloc) break;                // uniform over the workgroup
+    if (is_a) {
+        // ---------------- producer: stage A ----------------
+        // step s reads input row mstart-5+s; from step 8 on it yields model row mstart+(s-8)
+        const int xa0 = xm0 + wave * PC_OUT_A;        // first model column of this wave
+        const int ci = r101c(xa0 - 4 + lane, W);      // input column of this lane
+        const int xa = xa0 + lane;                    // model column of this lane
+        const int xac = xa < 0 ? 0 : (xa > W - 1 ? W - 1 : xa);
+        const bool mvalid = lane < PC_OUT_A;
+        const float *vd = vin + (size_t)d * HW;
+        const int dg = d_begin + d;                   // global disparity of this slice
+        // buildCV_left: partner x-d while x >= d; buildCV_right: partner x+d while x < W-d (src/CVC.cpp:135-146,165-176)
+        const bool inb = CVC == 2 ? (ci < W - dg) : (ci >= dg);
+        const int cpart = CVC == 2 ? min(ci + dg, W - 1) : max(ci - dg, 0);
+        const bool any_border = CVC != 0 && __builtin_amdgcn_ballot_w64(!inb) != 0;
+        VTree t0 = {}, t1 = {}, t2 = {}, t3 = {};
+        float pin[2];
+        float4 oth[2], gin[2], o2[2], o3[2];
+        float2 o4[2];
+        // raw buffer loads: descriptors and row offsets in scalar registers, one constant 32-bit byte offset per lane
+        // (psm_create keeps W*H < 2^27, so every byte offset into a 16-byte plane fits 31 bits)
+        const __amdgpu_buffer_rsrc_t rG1 = pc_rsrc(G1, (unsigned)HW * 16u), rG2 = pc_rsrc(G2, (unsigned)HW * 16u);
+        const __amdgpu_buffer_rsrc_t rG3 = pc_rsrc(G3, (unsigned)HW * 16u), rG4 = pc_rsrc(G4, (unsigned)HW * 8u);
+        const __amdgpu_buffer_rsrc_t rGo = pc_rsrc(CVC == 0 ? G1 : Gother, (unsigned)HW * 16u);
+        const __amdgpu_buffer_rsrc_t rV = pc_rsrc(CVC == 0 ? (const void *)vd : (const void *)G1, (unsigned)HW * 4u);
+        const int vci = ci * 16, vcp = cpart * 16, vxa = xac * 16;
+#define PSM_ISSUE_PA(SLOT, STEP)                                                        \
+    {                                                                                   \
+        const int row_ = r101c(mstart - 5 + (STEP), H) * W;                             \
+        int ya_ = mstart - 8 + (STEP);                                                  \
+        ya_ = ya_ < 0 ? 0 : (ya_ > H - 1 ? H - 1 : ya_);                                \
+        const int oa_ = ya_ * W;                                                        \
+        if (CVC == 0) pin[SLOT] = pc_load1(rV, vci >> 2, row_ * 4);                     \
+        else oth[SLOT] = pc_load4(rGo, vcp, row_ * 16);                                 \
+        gin[SLOT] = pc_load4(rG1, vci, row_ * 16);                                      \
+        o2[SLOT] = pc_load4(rG2, vxa, oa_ * 16);                                        \
+        o3[SLOT] = pc_load4(rG3, vxa, oa_ * 16);                                        \
+        o4[SLOT] = pc_load2(rG4, vxa >> 1, oa_ * 8);                                    \
+    }
+        // one step: consume the loads of step S (slot K&1), issue those of step S+1
+#define PSM_STEP_PA(K, S, DST)                                                                      \
+    {                                                                                               \
+        PSM_ISSUE_PA((K + 1) & 1, (S) + 1)                                                          \
+        float p;                                                                                    \
+        if (CVC == 0) p = pin[K & 1];                                                               \
+        else {                                                                                      \
+            p = cost_pair(gin[K & 1], oth[K & 1]);                                                  \
+            if (any_border) {   /* only where x < d (left) / x >= W-d (right) occurs in this wave */   \
+                asm volatile("; border cost");   /* keeps this a real branch */                     \
+                const float cb_ = cost_border(gin[K & 1]);                                          \
+                p = inb ? p : cb_;                                                                  \
+            }                                                                                       \
+        }                                                                                           \
+        double h0 = hsum8(p, i1, i2, i4);                                                           \
+        double h1 = hsum8(__fmul_rn(gin[K & 1].x, p), i1, i2, i4);                                  \
+        double h2 = hsum8(__fmul_rn(gin[K & 1].y, p), i1, i2, i4);                                  \
+        double h3 = hsum8(__fmul_rn(gin[K & 1].z, p), i1, i2, i4);                                  \
+        double n0 = vstep<K>(t0, h0), n1 = vstep<K>(t1, h1), n2 = vstep<K>(t2, h2), n3 = vstep<K>(t3, h3); \
+        float4 r = solve_ab(box_out(n0), box_out(n1), box_out(n2), box_out(n3), o2[K & 1], o3[K & 1], o4[K & 1]); \
+        if ((DST) != nullptr && mvalid) (DST)[K * PC_MCOLS] = r;                                    \
+        __builtin_amdgcn_sched_barrier(0);                                                          \
+    }
+        PSM_ISSUE_PA(0, 0) __builtin_amdgcn_sched_barrier(0);
+        {   // warm-up: 8 rows fill the tree (loop bodies stay free of conditionals around the tree updates:
+            // a conditional turns the trees into loop-carried phis and doubles their registers)
+            float4 *const none = nullptr;
+            PSM_STEP_PA(0, 0, none) PSM_STEP_PA(1, 1, none) PSM_STEP_PA(2, 2, none) PSM_STEP_PA(3, 3, none)
+            PSM_STEP_PA(0, 4, none) PSM_STEP_PA(1, 5, none) PSM_STEP_PA(2, 6, none) PSM_STEP_PA(3, 7, none)
+        }
+        for (int b = 0; b < nbA; ++b) {
+            const int s0 = 8 + b * 4;
+            float4 *dst = &ring[b & (PC_RING - 1)][0][wave * PC_OUT_A + lane];
+            PSM_STEP_PA(0, s0, dst) PSM_STEP_PA(1, s0 + 1, dst) PSM_STEP_PA(2, s0 + 2, dst) PSM_STEP_PA(3, s0 + 3, dst)
+            __syncthreads();
+        }
+        for (int b = nbA; b < iters; ++b) __syncthreads();
+#undef PSM_STEP_PA
+#undef PSM_ISSUE_PA
+    } else {
+        // ---------------- consumer: stage B ----------------
+        // feed j (j = 0 .. nf-1) is model row r101(y0-4+j); from feed 7 on the tree yields output row y0+j-7
+        const int wb = wave - PC_NA;
+        const int bwidth = wb < PC_NB - 1 ? PC_OUT_B : PC_COLS - (PC_NB - 1) * PC_OUT_B;
+        const int xb0 = xg + wb * PC_OUT_B;           // first output column of this wave
+        const int xmod = xb0 - 4 + lane;              // model column this lane consumes
+        int mc = r101(xmod, W) - xm0;                 // REFLECT_101 of the model planes, as ring column
+        mc = mc < 0 ? 0 : (mc > PC_MCOLS - 1 ? PC_MCOLS - 1 : mc);
+        const int xb = xb0 + lane;                    // output column of this lane
+        const int xbc = min(xb, W - 1);
+        float *od = vout + (MODE == 0 ? (size_t)d * HW : 0);
+        const int amax = 4 * nbA - 1;
+        VTree t0 = {}, t1 = {}, t2 = {}, t3 = {};
+        float o1x[4], o1y[4], o1z[4];                 // g1.xyz at (output row, output column), one batch ahead
+        // MODE 1: this wave's records of the chunk plane: [batch][lane] float4 costs / uchar4 disparities of the batch's four rows
+        const size_t krec = ((size_t)(ch * npairs + pair) * PC_NB + wb) * nbmax * 64;
+        // (own descriptors: offsets stay small, and the loads can carry sc1 = served by the L2, never by this CU's L1 -
+        // the record was last written by this same wave one slice earlier)
+        const __amdgpu_buffer_rsrc_t rKc = pc_rsrc(MODE == 1 ? (const void *)(reinterpret_cast<float4 *>(kcost) + krec) : (const void *)G1, (unsigned)nbmax * 1024u);
+        const __amdgpu_buffer_rsrc_t rKd = pc_rsrc(MODE == 1 ? (const void *)(kdisp + krec) : (const void *)G1, (unsigned)nbmax * 256u);
+#define PSM_K_LOAD(C)                                                                              \
+    {                                                                                              \
+        const pc_u4 v_ = __builtin_amdgcn_raw_buffer_load_b128(rKc, lane * 16, (C) * 1024, 16);    \
+        kq = make_float4(__uint_as_float(v_.x), __uint_as_float(v_.y), __uint_as_float(v_.z), __uint_as_float(v_.w)); \
+        kd4 = __builtin_amdgcn_raw_buffer_load_b32(rKd, lane * 4, (C) * 256, 16);                  \
+    }
+        float4 kq = make_float4(__builtin_inff(), __builtin_inff(), __builtin_inff(), __builtin_inff());   // running minima of the current batch
+        unsigned kd4 = 0;                                                                                  // and their disparities
+        const __amdgpu_buffer_rsrc_t rG1 = pc_rsrc(G1, (unsigned)HW * 16u);
+        const int vxb = xbc * 16;
+        const int dg = d_begin + d;
+        const bool lane_out = lane < bwidth && xb < W;   // this lane owns an output pixel
+#define PSM_ISSUE_PB(SLOT, J)                                                           \
+    {                                                                                   \
+        int yb_ = y0 + (J) - 7;                                                         \
+        yb_ = yb_ < 0 ? 0 : (yb_ > H - 1 ? H - 1 : yb_);                                \
+        const float4 g_ = pc_load4(rG1, vxb, yb_ * W * 16);                             \
+        o1x[SLOT] = g_.x; o1y[SLOT] = g_.y; o1z[SLOT] = g_.z;                           \
+    }
+        // ring address of the model row that feed J consumes (wave-uniform arithmetic)
+        auto model_of = [&](int J) -> const float4 * {
+            int a = r101(y0 - 4 + J, H) - mstart;
+            a = a < 0 ? 0 : (a > amax ? amax : a);
+            return &ring[(a >> 2) & (PC_RING - 1)][a & 3][mc];
+        };
+        // MODE 0: merged store of output batch `c` (rows parked in qbuf[c & 1] one iteration earlier)
+        auto store_batch = [&](int c) {
+            if constexpr (MODE == 0) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {          // row k of the batch is stored by B wave k % PC_NB
+                const int j = 4 * c + k;
+                const int yo = y0 + j - 7;
+                if (k % PC_NB == wb && j >= 7 && yo < y1) {
+                    float *row = od + (size_t)yo * W + xg;
+                    const float *src = &qbuf[c & 1][k][0];
+                    if (VEC4) {
+                        const int cc = lane * 4;
+                        if (lane < PC_COLS / 4 && xg + cc < W) {
+#if PSM_PC_NT
+                            __builtin_nontemporal_store(*reinterpret_cast<const f4v *>(src + cc), reinterpret_cast<f4v *>(row + cc));
+#else
+                            *reinterpret_cast<float4 *>(row + cc) = *reinterpret_cast<const float4 *>(src + cc);
+#endif
+                        }
+                    } else {
+#pragma unroll
+                        for (int cc = lane; cc < PC_COLS; cc += 64)
+                            if (xg + cc < W) row[cc] = src[cc];
+                    }
+                }
+            }
+            }
+        };
+        PSM_ISSUE_PB(0, 0) PSM_ISSUE_PB(1, 1) PSM_ISSUE_PB(2, 2) PSM_ISSUE_PB(3, 3)
+        if constexpr (MODE == 1) {
+            if (ds > 0) {                              // records of batch 0, written by this wave one slice earlier (L1 bypassed)
+                PSM_K_LOAD(0)
+            }
+        }
+        __syncthreads();                               // iteration 0
+        __syncthreads();                               // iteration 1
+        for (int b = 2; b <= nbB + 1; ++b) {           // iteration b: consume feed batch c = b-2
+            const int c = b - 2;
+            if (c >= 1) store_batch(c - 1);
+            {
+                const int j0 = 4 * c;
+                float4 a_cur = *model_of(j0), a_nxt;
+                float qv[4];
+#define PSM_STEP_PB(K)                                                                              \
+    {                                                                                               \
+        if (K < 3) a_nxt = *model_of(j0 + K + 1);     /* model row of the next feed, one step ahead */ \
+        double h0 = hsum8(a_cur.x, i1, i2, i4);                                                     \
+        double h1 = hsum8(a_cur.y, i1, i2, i4);                                                     \
+        double h2 = hsum8(a_cur.z, i1, i2, i4);                                                     \
+        double h3 = hsum8(a_cur.w, i1, i2, i4);                                                     \
+        double n0 = vstep<K>(t0, h0), n1 = vstep<K>(t1, h1), n2 = vstep<K>(t2, h2), n3 = vstep<K>(t3, h3); \
+        qv[K] = __fadd_rn(__fadd_rn(__fadd_rn(box_out(n3), __fmul_rn(box_out(n0), o1x[K])),        \
+                                    __fmul_rn(box_out(n1), o1y[K])), __fmul_rn(box_out(n2), o1z[K])); \
+        PSM_ISSUE_PB(K, j0 + K + 4)                                                                 \
+        a_cur = a_nxt;                                                                              \
+        __builtin_amdgcn_sched_barrier(0);                                                          \
+    }
+                PSM_STEP_PB(0) PSM_STEP_PB(1) PSM_STEP_PB(2) PSM_STEP_PB(3)
+#undef PSM_STEP_PB
+                if constexpr (MODE == 0) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        if (lane < bwidth) qbuf[c & 1][k][wb * PC_OUT_B + lane] = qv[k];
+                } else {
+                    // DispSel::CVSelect (src/DispSel.cpp:96-104) over the slices of this chunk: strict '<', d = 0 never a
+                    // candidate, NaN never wins.  Rows outside [y0, y1) and halo lanes keep (+inf, 0).
+                    float kn[4] = {kq.x, kq.y, kq.z, kq.w};
+                    unsigned dn = kd4;
+                    bool any = false;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const int j_ = j0 + k, yo_ = y0 + j_ - 7;
+                        const bool better_ = j_ >= 7 && yo_ < y1 && lane_out && dg != 0 && qv[k] < kn[k];
+                        kn[k] = better_ ? qv[k] : kn[k];
+                        dn = better_ ? ((dn & ~(0xffu << (8 * k))) | ((unsigned)dg << (8 * k))) : dn;
+                        any |= better_;
+                    }
+                    if (ds == 0 || __builtin_amdgcn_ballot_w64(any) != 0) {
+                        const pc_u4 kv = {__float_as_uint(kn[0]), __float_as_uint(kn[1]), __float_as_uint(kn[2]), __float_as_uint(kn[3])};
+                        __builtin_amdgcn_raw_buffer_store_b128(kv, rKc, lane * 16, c * 1024, 0);
+                        __builtin_amdgcn_raw_buffer_store_b32(dn, rKd, lane * 4, c * 256, 0);
+                    }
+                    if (ds > 0 && c + 1 < nbB) PSM_K_LOAD(c + 1)       // records of the next batch
+                }
+            }
+            __syncthreads();
+        }
+        store_batch(nbB - 1);                          // iteration nbB+2
+        __syncthreads();
+#undef PSM_ISSUE_PB
+#undef PSM_K_LOAD
+    }
+    if (MODE == 1) __builtin_amdgcn_s_waitcnt(0);      // the chunk planes of this slice are in the L2 before the next slice reads them
+    }   // slices of the chunk
+}
+
+// chunk planes -> packed WTA key and / or final map per pixel (minimum over the chunks; pack_key_f32 makes the signed
+// 64-bit minimum select (min cost, then lowest d) exactly as the sequential loop of src/DispSel.cpp:96-104).
+// One thread per record (pair, consumer wave, batch, lane) = four rows of one column, as the select kernel wrote them.
+__global__ __launch_bounds__(256) void k_chunk_min(const float4 *__restrict__ kcost, const unsigned *__restrict__ kdisp, int nchunks, int npairs,
+                                                  int nbmax, int ngroups, int seg_rows, int W, int H, long long *__restrict__ keys,
+                                                  uint8_t *__restrict__ map)
+{
+    using L = PcLayout<1>;
+    const size_t nrec = (size_t)npairs * L::NB * nbmax * 64;       // records per chunk plane
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= nrec) return;
+    const int lane = (int)(idx & 63);
+    size_t t = idx >> 6;
+    const int c = (int)(t % nbmax); t /= nbmax;
+    const int wb = (int)(t % L::NB);
+    const int pair = (int)(t / L::NB);
+    const int g = pair % ngroups, seg = pair / ngroups;
+    const int bwidth = wb < L::NB - 1 ? L::OUT_B : L::COLS - (L::NB - 1) * L::OUT_B;
+    const int x = g * L::COLS + wb * L::OUT_B + lane;
+    if (lane >= bwidth || x >= W) return;
+    const int y0 = seg * seg_rows, y1 = min(H, y0 + seg_rows);
+    const int ya = y0 + 4 * c - 7;                                  // output row of the record's first entry
+    if (ya + 3 < y0 || ya >= y1) return;
+    float4 kc = kcost[idx];
+    unsigned kd = kdisp[idx];
+    long long best[4] = {pack_key_f32(kc.x, kd & 0xff), pack_key_f32(kc.y, (kd >> 8) & 0xff), pack_key_f32(kc.z, (kd >> 16) & 0xff),
+                         pack_key_f32(kc.w, kd >> 24)};
+    for (int ch = 1; ch < nchunks; ++ch) {
+        kc = kcost[(size_t)ch * nrec + idx];
+        kd = kdisp[(size_t)ch * nrec + idx];
+        const long long k0 = pack_key_f32(kc.x, kd & 0xff), k1 = pack_key_f32(kc.y, (kd >> 8) & 0xff),
+                        k2 = pack_key_f32(kc.z, (kd >> 16) & 0xff), k3 = pack_key_f32(kc.w, kd >> 24);
+        best[0] = k0 < best[0] ? k0 : best[0];
+        best[1] = k1 < best[1] ? k1 : best[1];
+        best[2] = k2 < best[2] ? k2 : best[2];
+        best[3] = k3 < best[3] ? k3 : best[3];
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int yo = ya + k;
+        if (yo < y0 || yo >= y1) continue;
+        const size_t o = (size_t)yo * W + x;
+        if (keys) keys[o] = best[k];
+        if (map) map[o] = (uint8_t)((unsigned long long)best[k] & 0xffull);
+    }
+}
+
+// Segment count k (and, for MODE 1, slices per chunk DC): every segment re-walks 14 halo rows, and the launch runs in
+// rounds of resident workgroups - per XCD ceil(pairs/8) (column group, segment) pairs x chunks over 32 CUs x 3
+// workgroups.  Cost model, fitted to measurements at 1080p (DC = 1, 2, 4, 8, 16: 4.39, 4.41, 4.46, 4.71, 4.99 ms
+// for kernel + reduction): (rounds + 1/2) x rows walked per workgroup - the last round is on average half empty, which
+// is what makes long-running workgroups (large DC) expensive - plus two row-steps per chunk plane for the reduction.
+PcPlan pc_plan(int W, int H, int Dloc, int seg_rows_opt, int mode)
+{
+    return pc_plan_cols(W, H, Dloc, seg_rows_opt, mode, mode == 1 ? PcLayout<1>::COLS : PcLayout<0>::COLS);
+}
+
+PcPlan pc_plan_cols(int W, int H, int Dloc, int seg_rows_opt, int mode, int cols)
+{
+    const int rows = H;
+    PcPlan pl;
+    pl.ngroups = (W + cols - 1) / cols;
+    const int kmax = rows / 64 > 1 ? rows / 64 : 1;
+    int dcs[5] = {1, 2, 4, 8, 16};
+    int ndc = mode == 1 ? 5 : 1;
+    if (mode == 1) {   // tuning / experiments: PSM_PC_DC forces the slices per chunk
+        const char *e = getenv("PSM_PC_DC");
+        if (e && atoi(e) > 0) { dcs[0] = atoi(e); ndc = 1; }
+    }
+    auto cost_of = [&](int dc, int kk) -> long {
+        const int nch = (Dloc + dc - 1) / dc;
+        const long per_xcd = ((long)pl.ngroups * kk * nch + 7) / 8;
+        const long rounds2 = 2 * ((per_xcd + 95) / 96) + 1;                         // 2 x (rounds + 1/2)
+        return rounds2 * dc * ((rows + kk - 1) / kk + 14) / 2 + (mode == 1 ? 2L * nch : 0);
+    };
+    auto allowed = [&](int dc, int kk) { return (dc == dcs[0] || dc <= Dloc) && (seg_rows_opt <= 0 || kk == (rows + seg_rows_opt - 1) / seg_rows_opt); };
+    long best = -1;
+    for (int di = 0; di < ndc; ++di)
+        for (int kk = 1; kk <= kmax && kk <= 32; ++kk)
+            if (allowed(dcs[di], kk)) { const long c = cost_of(dcs[di], kk); if (best < 0 || c < best) best = c; }
+    int bk = seg_rows_opt > 0 ? (rows + seg_rows_opt - 1) / seg_rows_opt : 1, bdc = dcs[0];
+    for (int di = 0; di < ndc && best >= 0; ++di)
+        for (int kk = 1; kk <= kmax && kk <= 32; ++kk)
+            if (allowed(dcs[di], kk) && cost_of(dcs[di], kk) == best) { bk = kk; bdc = dcs[di]; di = ndc; break; }
+    pl.seg_rows = seg_rows_opt > 0 ? seg_rows_opt : (rows + bk - 1) / bk;
+    if (pl.seg_rows > rows) pl.seg_rows = rows;
+    pl.nsegs = (rows + pl.seg_rows - 1) / pl.seg_rows;
+    pl.DC = bdc;
+    pl.nchunks = (Dloc + bdc - 1) / bdc;
+    pl.nbmax = (pl.seg_rows + 7 + 3) / 4;                            // consumer batches of a full segment
+    pl.rec_per_chunk = (size_t)pl.ngroups * pl.nsegs * PcLayout<1>::NB * pl.nbmax * 64;
+    pl.rec_bytes = 20;                                               // 16 bytes of costs + 4 bytes of disparities
+    return pl;
+}
+
+void launch_cvf_fused(hipStream_t s, March m, const float *vin, float *vout, Guidance gd, int W, int H, int Dloc,
+                      int ybeg, int yend, const float4 *g1_other, int d_begin, int cvc_mode)
+{
+    if (yend <= ybeg) return;
+    const int rows = yend - ybeg;
+    const PcPlan pl = pc_plan(W, rows, Dloc, m.seg_rows, 0);
+    const int nblocks = 8 * ((pl.ngroups * pl.nsegs * Dloc + 7) / 8);
+    const dim3 blk(64 * (PcLayout<0>::NA + PcLayout<0>::NB));
+#define PSM_LAUNCH_PC(V4, CV)                                                                                              \
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_cvf_pc<V4, CV, 0>), dim3(nblocks), blk, 0, s, vin, vout, (const float4 *)gd.g1,   \
+                       (const float4 *)gd.g2, (const float4 *)gd.g3, (const float2 *)gd.g4, W, H, Dloc, pl.ngroups, pl.nsegs, \
+                       pl.seg_rows, ybeg, yend, g1_other, d_begin, 1, (float *)nullptr, (unsigned *)nullptr, 0)
+    const bool v4 = (W & 3) == 0;
+    if (cvc_mode == 1) { if (v4) PSM_LAUNCH_PC(true, 1); else PSM_LAUNCH_PC(false, 1); }
+    else if (cvc_mode == 2) { if (v4) PSM_LAUNCH_PC(true, 2); else PSM_LAUNCH_PC(false, 2); }
+    else { if (v4) PSM_LAUNCH_PC(true, 0); else PSM_LAUNCH_PC(false, 0); }
+#undef PSM_LAUNCH_PC
+}
+
+void launch_cvf_select(hipStream_t s, March m, const float *vin, Guidance gd, int W, int H, int Dloc, const float4 *g1_other,
+                       int d_begin, int cvc_mode, void *scratch)
+{
+    const PcPlan pl = pc_plan(W, H, Dloc, m.seg_rows, 1);
+    float *kcost = (float *)scratch;                                           // nchunks * rec_per_chunk float4
+    unsigned *kdisp = (unsigned *)(kcost + 4 * pl.rec_per_chunk * pl.nchunks);  // nchunks * rec_per_chunk uchar4
+    const int nblocks = 8 * ((pl.ngroups * pl.nsegs * pl.nchunks + 7) / 8);
+    const dim3 blk(64 * (PcLayout<1>::NA + PcLayout<1>::NB));
+#define PSM_LAUNCH_PC(CV)                                                                                                   \
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_cvf_pc<false, CV, 1>), dim3(nblocks), blk, 0, s, vin, (float *)nullptr, (const float4 *)gd.g1, \
+                       (const float4 *)gd.g2, (const float4 *)gd.g3, (const float2 *)gd.g4, W, H, Dloc, pl.ngroups, pl.nsegs, \
+                       pl.seg_rows, 0, H, g1_other, d_begin, pl.DC, kcost, kdisp, pl.nbmax)
+    if (cvc_mode == 1) PSM_LAUNCH_PC(1); else if (cvc_mode == 2) PSM_LAUNCH_PC(2); else PSM_LAUNCH_PC(0);
+#undef PSM_LAUNCH_PC
+}
+
+void launch_chunk_min(hipStream_t s, March m, int W, int H, int Dloc, void *scratch, long long *keys, uint8_t *map)
+{
+    const PcPlan pl = pc_plan(W, H, Dloc, m.seg_rows, 1);
+    const float *kcost = (const float *)scratch;
+    const unsigned *kdisp = (const unsigned *)(kcost + 4 * pl.rec_per_chunk * pl.nchunks);
+    hipLaunchKernelGGL(k_chunk_min, dim3((unsigned)((pl.rec_per_chunk + 255) / 256)), dim3(256), 0, s, (const float4 *)kcost, (const unsigned *)kdisp,
+                       pl.nchunks, pl.ngroups * pl.nsegs, pl.nbmax, pl.ngroups, pl.seg_rows, W, H, keys, map);
+}
+
+}  // namespace psm
