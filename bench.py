@@ -33,7 +33,12 @@ CONFIGS = {
     "c3": (1280, 720, 128, "synthetic 1280x720 pair, D=128, float32 (BASELINE configs[2])"),
     "c5": (3840, 2160, 256, "synthetic 3840x2160 pair, D=256, float32 (BASELINE configs[4])"),
     "c2": (450, 375, 64, "synthetic 450x375 pair, D=64, float32 (size of BASELINE configs[1])"),
+    # 8-bit char mode (BASELINE configs[0]): the shipped Cones size and the 384x288 the json quotes
+    "c1": (450, 375, 64, "synthetic 450x375 pair, D=64, 8-bit char mode (size of the shipped Cones pair, BASELINE configs[0])"),
+    "c1x": (384, 288, 64, "synthetic 384x288 pair, D=64, 8-bit char mode (the size BASELINE configs[0] quotes)"),
 }
+# algorithmic bytes per voxel of the staged 8-bit pipeline: CVC 1 W; CVF stage A 1 R + 16 W, stage B 16 R + 1 W; WTA 1 R
+ALG_BYTES_U8 = {"cvf_fused": 34.0, "cvc": 1.0, "wta": 1.0, "pipeline": 36.0}
 # algorithmic HBM bytes per voxel (SURVEY.md 8d / DESIGN.md): stage A 4 R + 16 W, stage B 16 R + 4 W
 ALG_BYTES = {"cvf_fused": 40.0, "cvf_a": 20.0, "cvf_b": 20.0, "cvc": 4.0, "wta": 4.0, "box8": 8.0, "pipeline": 48.0}
 
@@ -59,6 +64,7 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", default="c4", choices=sorted(CONFIGS))
+    ap.add_argument("--dtype", default="", choices=["", "f32", "u8"], help="volume element type (default: f32, u8 for the c1 configs)")
     ap.add_argument("--seg-rows", type=int, default=-1, help="marching-kernel y segment (-1: library default)")
     ap.add_argument("--waves", type=int, default=0, help="waves per workgroup (0: library default)")
     ap.add_argument("--variant", type=int, default=0)
@@ -121,6 +127,11 @@ def main():
     from primestereomatch_amd import capi, synth
 
     W, H, D, desc = CONFIGS[args.config]
+    dtype = args.dtype or ("u8" if args.config.startswith("c1") else "f32")
+    if dtype == "u8":
+        ALG_BYTES.update(ALG_BYTES_U8)
+        if not args.config.startswith("c1"):
+            desc = desc.replace("float32", "8-bit char mode")
     if use_dist:
         d0, d1 = D * rank // world, D * (rank + 1) // world
     elif args.shard_sim > 1:
@@ -128,7 +139,7 @@ def main():
     else:
         d0, d1 = 0, D
     l, r, _ = synth.make_pair(W, H, D, seed=0)
-    de = P.DispEst(l, r, D, 8, True, device=local_rank, d_range=(d0, d1))
+    de = P.DispEst(l, r, D, 8, True, device=local_rank, d_range=(d0, d1), dtype=dtype)
     if args.seg_rows >= 0:
         de.set_option(capi.PSM_OPT_SEG_ROWS, args.seg_rows)
     if args.waves:
@@ -292,14 +303,16 @@ def main():
         if n:
             kern[nm] = {"avg_ms": tot / n, "launches_per_step": n / prof_steps}
     de.set_option(capi.PSM_OPT_PROFILE, 0)
-    vox_per_launch = float(W) * H * (d1 - d0)   # one launch = all local slices of one side
+    vox_per_launch = float(W) * H * (d1 - d0)   # one launch = all local slices of one side ...
+    if kern.get("cvf_fused", {}).get("launches_per_step", 2) < 1.5:
+        vox_per_launch *= 2.0                    # ... or of both sides (psm_cost_filter's default: both volumes per launch)
     if args.fgf:   # per launch pair (setup + model + smooth + apply of one side): cost read at 1/s^2, model planes, q write
         ALG_BYTES["cvf_fgf"] = 4.0 + 68.0 / (args.fgf * args.fgf)
     # the default fused kernel also builds the costs and runs the WTA over its slices ("select" mode): it is credited
     # with the whole staged pipeline's algorithmic bytes (CVC 4 + CVF 40 + WTA 4); --flags 8192 is the storing form (CVF only)
     select_mode = not args.fgf and args.variant == 0 and not (max(args.flags, 0) & (16 | 512 | 8192))
     if select_mode:
-        ALG_BYTES["cvf_fused"] = 48.0
+        ALG_BYTES["cvf_fused"] = ALG_BYTES["pipeline"]
     dom = max(("cvf_fgf",) if args.fgf else ("cvf_fused", "cvf_a", "cvf_b"), key=lambda k: kern.get(k, {"avg_ms": 0})["avg_ms"])
     dom_ms = kern[dom]["avg_ms"]
     achieved = ALG_BYTES[dom] * vox_per_launch / (dom_ms * 1e-3) / 1e9
@@ -334,7 +347,7 @@ def main():
     if rank == 0 and args.shard_sim <= 1 and (use_dist or args.verify):
         got_l, got_r = (m.copy() for m in de.download_maps())
         de.set_option(capi.PSM_OPT_ASYNC, 0)
-        with P.DispEst(l, r, D, 8, True, device=local_rank) as ref:
+        with P.DispEst(l, r, D, 8, True, device=local_rank, dtype=dtype) as ref:
             if args.fgf:
                 ref.setSubsampleRate(args.fgf)
             ref.CostConst_GPU()
@@ -367,7 +380,7 @@ def main():
         sd = args.cpu_sample_d if args.cpu_sample_d > 0 else int(256.0 * (1920 * 1080) / (W * H))
         sd = max(2, min(sd, D))
         tcpu = time.perf_counter()
-        res = O.pipeline_f32(l, r, sd, threads=threads)
+        res = (O.pipeline_u8 if dtype == "u8" else O.pipeline_f32)(l, r, sd, threads=threads)
         tcpu = time.perf_counter() - tcpu
         stage_s = (res["cvc_ms"] + res["cvf_ms"] + res["dispsel_ms"]) * 1e-3
         cpu = {"value": round(2.0 * W * H * sd / stage_s, 1), "unit": "voxels/s", "cores": threads,
@@ -380,7 +393,7 @@ def main():
         # context only, the contract's cpu_baseline is the 8-thread figure above
         wide = min(64, cores)
         if args.cpu_wide and wide > threads:
-            resw = O.pipeline_f32(l, r, sd, threads=wide)
+            resw = (O.pipeline_u8 if dtype == "u8" else O.pipeline_f32)(l, r, sd, threads=wide)
             sw = (resw["cvc_ms"] + resw["cvf_ms"] + resw["dispsel_ms"]) * 1e-3
             cpu["wide"] = {"value": round(2.0 * W * H * sd / sw, 1), "cores": wide}
 
@@ -389,7 +402,7 @@ def main():
             "metric": "cost-volume voxels/s (CVC+CVF+WTA)" if not args.fgf else f"cost-volume voxels/s (CVC+CVF_FGF s={args.fgf}+WTA)",
             "value": value, "unit": "voxels/s",
             "n_gpus": N, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
-            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": dtype,
             "data": "synthetic",
             "config": {"workload": desc, "W": W, "H": H, "D": D, "voxels_per_step": voxels_per_step,
                        "parallelism": "1 GPU" if world == 1 else f"D sharded over {world} ranks + 1 RCCL {args.exchange} of packed minima",

@@ -64,7 +64,9 @@ enum {
                                    filtered volumes (default: the fused kernel runs the WTA over the local slices
                                    itself and the filtered volumes stay virtual - packed per-pixel minima - until
                                    something other than psm_disp_select* reads them); 16384 = two-columns-per-lane,
-                                   channel-split variant of that kernel (k_cvf_q2).  No flag changes any result. */
+                                   channel-split variant of that kernel (k_cvf_q2); 65536 = psm_cost_filter launches
+                                   every kernel once per volume (default: both volumes per launch).
+                                   No flag changes any result. */
 };
 
 /* Number of usable HIP devices; 0 if none.  Replaces openCLdevicepoll()

@@ -31,6 +31,8 @@ double now_us()
 
 }  // namespace
 
+extern "C" int filter_u8_stored(struct psm_ctx *c, int side);   // defined below; internal (not part of the ABI header)
+
 struct psm_ctx {
     int W = 0, H = 0, D = 0, d0 = 0, d1 = 0, Dloc = 0, dtype = PSM_F32, device = 0;
     hipStream_t own_stream = nullptr, stream = nullptr;
@@ -204,10 +206,13 @@ void free_all(psm_ctx *c)
 int run_prep(psm_ctx *c)
 {
     const size_t row = (size_t)c->W * 3 * (c->raw_depth == PSM_IMG_F32 ? 4 : 1);
-    for (int s = 0; s < 2; ++s) {
+    {   // both images in one launch
         Prof p(c, PSM_K_PREP);
-        launch_prep(c->stream, c->raw[s], row, c->raw_depth == PSM_IMG_F32, c->W, c->H, c->g[s].g1);
-        if (c->dtype == PSM_U8) launch_prep_u8(c->stream, (const uint8_t *)c->raw[s], row, c->W, c->H, c->p4[s]);
+        launch_prep(c->stream, c->raw[0], row, c->raw_depth == PSM_IMG_F32, c->W, c->H, c->g[0].g1, c->raw[1], c->g[1].g1);
+    }
+    for (int s = 0; s < 2 && c->dtype == PSM_U8; ++s) {
+        Prof p(c, PSM_K_PREP);
+        launch_prep_u8(c->stream, (const uint8_t *)c->raw[s], row, c->W, c->H, c->p4[s]);
     }
     if (check_launch(c, "prep")) return 1;
     c->soa_state[0] = c->soa_state[1] = 0;
@@ -292,6 +297,18 @@ int fgf_flush(psm_ctx *c, int side)
 int materialize(psm_ctx *c, int side)
 {
     if (fgf_flush(c, side)) return 1;
+    if (c->dtype == PSM_U8) {
+        if (c->raw_rows[side] != psm_ctx::RAW_ALL) {      // the 8-bit costs exist only as a recipe: build them
+            Prof p(c, PSM_K_CVC);
+            launch_cvc_u8(c->stream, c->p4[side], c->p4[1 - side], (uint8_t *)c->vol[side], c->W, c->H, c->d0, c->Dloc, side);
+            c->raw_rows[side] = psm_ctx::RAW_ALL;
+        }
+        if (c->gf_virtual[side]) {                         // ... and the filtered volume only as WTA keys: filter in the storing form
+            if (filter_u8_stored(c, side)) return 1;
+            c->gf_virtual[side] = false;
+        }
+        return check_launch(c, "8-bit volume (materialize)");
+    }
     if (c->gf_virtual[side]) {
         // the guided-filter result exists only as WTA keys: run the same fused kernel again, this time storing q
         if (ensure_vol(c, side)) return 1;
@@ -386,7 +403,7 @@ int psm_create_shard(psm_ctx **out, int width, int height, int max_disp, int d_b
         if (e == hipSuccess && dtype == PSM_U8) e = hipMalloc(&c->vol[s], V * velem(c));   // PSM_F32: on first use (ensure_vol)
         if (e == hipSuccess && dtype == PSM_U8) e = hipMalloc((void **)&c->p4[s], HW * 4);
     }
-    if (e == hipSuccess && dtype == PSM_U8) e = hipMalloc((void **)&c->fvol, V * sizeof(float));
+    // (fvol, the float work copy of the 8-bit storing path, is allocated on first use)
     if (e == hipSuccess) e = hipMalloc((void **)&c->keys, 2 * HW * sizeof(long long));
     if (e == hipSuccess) e = hipMalloc((void **)&c->maps, 2 * HW + 4);   // +4: psm_wgt_median reads/updates whole aligned dwords
     if (e == hipSuccess) e = hipMalloc((void **)&c->valid, 2 * HW);
@@ -504,11 +521,16 @@ int psm_cost_construct(psm_ctx *c)
     c->gf_virtual[0] = c->gf_virtual[1] = false;
     // Lazy cost volume: when the fused filter will consume the costs (float mode, marching kernels,
     // fusion not disabled) they are built inside that kernel and never written to HBM.
-    const bool lazy = c->dtype == PSM_F32 && c->opt_variant == 0 && !(c->march.flags & (16 | 128)) && c->H >= 8;
+    // (8-bit mode: lazy only when the select-mode kernel will consume the costs - its storing form reads a float copy)
+    const bool lazy = c->opt_variant == 0 && !(c->march.flags & (16 | 128)) && c->H >= 8 &&
+                      (c->dtype == PSM_F32 || !(c->march.flags & (512 | 8192)));
     for (int s = 0; s < 2; ++s) {
-        if (c->dtype == PSM_U8) {
+        if (lazy) {
+            c->raw_rows[s] = psm_ctx::RAW_NONE;
+        } else if (c->dtype == PSM_U8) {
             Prof p(c, PSM_K_CVC);
             launch_cvc_u8(c->stream, c->p4[s], c->p4[1 - s], (uint8_t *)c->vol[s], c->W, c->H, c->d0, c->Dloc, s);
+            c->raw_rows[s] = psm_ctx::RAW_ALL;
         } else if (lazy) {
             c->raw_rows[s] = psm_ctx::RAW_NONE;
         } else {
@@ -537,11 +559,12 @@ static int filter_side(psm_ctx *c, int side, bool stage_b)
     }
     // Default: the fused kernel in "select" mode - the WTA over the local slices runs inside the filter, the filtered
     // volume stays virtual (flag 8192 forces the storing form; 16 / 512 / the direct variant select other filters)
-    if (stage_b && c->dtype == PSM_F32 && c->opt_variant == 0 && !(c->march.flags & (16 | 512 | 8192)) && H >= 8) {
+    const bool sel8 = c->dtype == PSM_U8 && c->raw_rows[side] != psm_ctx::RAW_ALL;   // 8-bit mode: select form only with costs on the fly
+    if (stage_b && (c->dtype == PSM_F32 || sel8) && c->opt_variant == 0 && !(c->march.flags & (16 | 512 | 8192)) && H >= 8) {
         const bool lazy = c->raw_rows[side] != psm_ctx::RAW_ALL;
         // flag 16384: the two-columns-per-lane, channel-split form (k_cvf_q2, psm_q2.hip: 14 % fewer VALU instructions,
         // but its four-stage workgroups keep the SIMDs less busy - measured slower, kept as a tested variant)
-        const bool q2 = lazy && (c->march.flags & 16384);
+        const bool q2 = lazy && c->dtype == PSM_F32 && (c->march.flags & 16384);
         const PcPlan pl = q2 ? q2_plan(W, H, c->Dloc, c->march.seg_rows) : pc_plan(W, H, c->Dloc, c->march.seg_rows, 1);
         if (ensure_gf_scratch(c, pl.scratch_bytes())) return 1;
         const size_t HW = (size_t)W * H;
@@ -549,7 +572,7 @@ static int filter_side(psm_ctx *c, int side, bool stage_b)
             Prof p(c, PSM_K_CVF_F);
             if (q2) launch_cvf_q2(c->stream, c->march, c->g[side], W, H, c->Dloc, c->g[1 - side].g1, c->d0, 1 + side, c->gf_scratch);
             else launch_cvf_select(c->stream, c->march, lazy ? nullptr : (const float *)c->vol[side], c->g[side], W, H, c->Dloc, c->g[1 - side].g1,
-                                   c->d0, lazy ? 1 + side : 0, c->gf_scratch);
+                                   c->d0, lazy ? 1 + side : 0, c->gf_scratch, sel8 ? c->p4[side] : nullptr, sel8 ? c->p4[1 - side] : nullptr);
         }
         {
             Prof p(c, PSM_K_WTA);
@@ -560,8 +583,10 @@ static int filter_side(psm_ctx *c, int side, bool stage_b)
         return check_launch(c, "cvf (fused, select mode)");
     }
     if (c->dtype == PSM_F32 && ensure_vol(c, side)) return 1;
+    if (c->dtype == PSM_U8 && stage_b && c->raw_rows[side] != psm_ctx::RAW_ALL && materialize(c, side)) return 1;   // storing forms read the 8-bit volume
     float *fv = (float *)c->vol[side];
     if (c->dtype == PSM_U8) {
+        if (!c->fvol) PSM_HIP(c, hipMalloc((void **)&c->fvol, V * sizeof(float)));
         fv = c->fvol;
         launch_u8_to_f32(c->stream, (const uint8_t *)c->vol[side], fv, V);
     }
@@ -635,6 +660,53 @@ static int filter_side(psm_ctx *c, int side, bool stage_b)
     return check_launch(c, "cvf");
 }
 
+// 8-bit mode, storing form: float copy of the 8-bit cost volume -> fused filter (store mode, out of place) -> re-quantise
+// (what psm_download_volume etc. see; the default path never runs it).  Needs the guidance of `side`.
+int filter_u8_stored(psm_ctx *c, int side)
+{
+    const size_t V = (size_t)c->W * c->H * c->Dloc;
+    if (!c->fvol) PSM_HIP(c, hipMalloc((void **)&c->fvol, V * sizeof(float)));
+    if (ensure_spare(c)) return 1;
+    launch_u8_to_f32(c->stream, (const uint8_t *)c->vol[side], c->fvol, V);
+    {
+        Prof p(c, PSM_K_CVF_F);
+        launch_cvf_fused(c->stream, c->march, c->fvol, c->spare, c->g[side], c->W, c->H, c->Dloc, 0, c->H, c->g[1 - side].g1, c->d0, 0);
+    }
+    launch_f32_to_u8(c->stream, c->spare, (uint8_t *)c->vol[side], V);
+    return check_launch(c, "cvf (8-bit, storing form)");
+}
+
+// Both volumes per launch: guidance of both images, select-mode fused filter of both volumes, chunk reduction of both - three
+// launches per frame instead of six (shorter ramp / tail per launch; matters most for a disparity shard and for small
+// images).  Only for the default path (float mode, costs built on the fly); flag 65536 turns it off.
+static bool can_filter_both(const psm_ctx *c)
+{
+    return c->opt_variant == 0 && !(c->march.flags & (16 | 256 | 512 | 8192 | 16384 | 65536)) && c->H >= 8 &&
+           c->raw_rows[0] != psm_ctx::RAW_ALL && c->raw_rows[1] != psm_ctx::RAW_ALL && !c->gf_virtual[0] && !c->gf_virtual[1] &&
+           !c->fgf_virtual[0] && !c->fgf_virtual[1];
+}
+
+static int filter_both(psm_ctx *c)
+{
+    if (!c->have_g1 && run_prep(c)) return 1;
+    {
+        Prof p(c, PSM_K_GUIDE);
+        launch_guidance(c->stream, c->g[0], nullptr, c->W, c->H, 0, &c->g[1]);
+    }
+    const PcPlan pl = pc_plan(c->W, c->H, c->Dloc, c->march.seg_rows, 1);
+    if (ensure_gf_scratch(c, 2 * pl.scratch_bytes())) return 1;
+    {
+        Prof p(c, PSM_K_CVF_F);
+        launch_cvf_select2(c->stream, c->march, c->g, c->W, c->H, c->Dloc, c->d0, c->gf_scratch, c->dtype == PSM_U8 ? c->p4 : nullptr);
+    }
+    {
+        Prof p(c, PSM_K_WTA);
+        launch_chunk_min2sides(c->stream, c->march, c->W, c->H, c->Dloc, c->gf_scratch, c->keys, nullptr);
+    }
+    c->gf_virtual[0] = c->gf_virtual[1] = true;
+    return check_launch(c, "cvf (fused, select mode, both volumes)");
+}
+
 int psm_cost_filter(psm_ctx *c)
 {
     if (!c) return 1;
@@ -643,8 +715,12 @@ int psm_cost_filter(psm_ctx *c)
     if (bind(c)) return 1;
     const double t0 = now_us();
     // preprocess L, filter L, preprocess R, filter R (src/DispEst.cpp:302-305)
-    for (int s = 0; s < 2; ++s)
-        if (filter_side(c, s, true)) return 1;
+    if (can_filter_both(c)) {
+        if (filter_both(c)) return 1;
+    } else {
+        for (int s = 0; s < 2; ++s)
+            if (filter_side(c, s, true)) return 1;
+    }
     c->have_maps = false;
     return end_stage(c, PSM_STAGE_CVF, t0);
 }
@@ -766,6 +842,11 @@ static int wta_side(psm_ctx *c, int s, long long *keys_s, uint8_t *map_s)
 static int wta_launch(psm_ctx *c, long long *keys, uint8_t *maps)
 {
     const size_t HW = (size_t)c->W * c->H;
+    if (c->gf_virtual[0] && c->gf_virtual[1] && !keys && maps) {   // both sides already reduced to keys: one launch for both maps
+        Prof p(c, PSM_K_WTA);
+        launch_merge(c->stream, c->keys, 2 * HW, 1, (int)(2 * HW), maps);
+        return check_launch(c, "wta");
+    }
     for (int s = 0; s < 2; ++s)
         if (wta_side(c, s, keys ? keys + s * HW : nullptr, maps ? maps + s * HW : nullptr)) return 1;
     return check_launch(c, "wta");

@@ -26,9 +26,10 @@ struct March {       // geometry of the marching kernels
 };
 
 // image -> g1 (planarise, scale, gray, x-gradient).  src: device copy of the interleaved image.
-void launch_prep(hipStream_t s, const void *src, size_t pitch, int depth_f32, int W, int H, float4 *g1);
+void launch_prep(hipStream_t s, const void *src, size_t pitch, int depth_f32, int W, int H, float4 *g1, const void *src1 = nullptr,
+                 float4 *g11 = nullptr);
 // g1 -> g2,g3,g4.  hs9: scratch, 9*H*W doubles.
-void launch_guidance(hipStream_t s, Guidance g, double *hs9, int W, int H, int two_pass);
+void launch_guidance(hipStream_t s, Guidance g, double *hs9, int W, int H, int two_pass, const Guidance *second = nullptr);
 // cost volume slices [d_begin, d_begin+Dloc) of one side.  base: g1 of the side's own image.
 void launch_cvc(hipStream_t s, const float4 *g1_base, const float4 *g1_other, float *vol, int W, int H,
                 int d_begin, int Dloc, int right, int flags, int ybeg, int yend);
@@ -54,8 +55,13 @@ struct PcPlan {
 PcPlan pc_plan(int W, int rows, int Dloc, int seg_rows_opt, int mode);
 PcPlan pc_plan_cols(int W, int rows, int Dloc, int seg_rows_opt, int mode, int cols);
 void launch_cvf_select(hipStream_t s, March m, const float *vin, Guidance g, int W, int H, int Dloc, const float4 *g1_other,
-                       int d_begin, int cvc_mode, void *scratch);
+                       int d_begin, int cvc_mode, void *scratch, const uint8_t *p4_own = nullptr, const uint8_t *p4_other = nullptr);
 void launch_chunk_min(hipStream_t s, March m, int W, int H, int Dloc, void *scratch, long long *keys, uint8_t *map);
+// both volumes per launch (costs on the fly): g[0] / g[1] = guidance of the left / right image; scratch: 2 x scratch_bytes();
+// keys / map: [2][H][W]
+void launch_cvf_select2(hipStream_t s, March m, const Guidance *g, int W, int H, int Dloc, int d_begin, void *scratch,
+                        const uint8_t *const *p4 = nullptr);
+void launch_chunk_min2sides(hipStream_t s, March m, int W, int H, int Dloc, void *scratch, long long *keys, uint8_t *map);
 // Select mode with two columns per lane and the channels split over the waves (psm_q2.hip): the default product kernel
 // when the costs are built on the fly (cvc_mode 1 / 2).  scratch: q2_plan(...).scratch_bytes() bytes.
 PcPlan q2_plan(int W, int H, int Dloc, int seg_rows_opt);

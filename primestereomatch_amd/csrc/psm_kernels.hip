@@ -45,9 +45,10 @@ __device__ __forceinline__ void load_px(const void *src, size_t pitch, int y, in
 }
 
 template <bool F32>
-__global__ __launch_bounds__(256) void k_prep(const void *src, size_t pitch, int W, int H, float4 *g1)
+__global__ __launch_bounds__(256) void k_prep(const void *src, size_t pitch, int W, int H, float4 *g1, const void *src1, float4 *g11)
 {
     int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (blockIdx.z == 1) { src = src1; g1 = g11; }    // second image of a two-image launch
     if (x >= W) return;
     float c0, c1, c2, l0, l1, l2, r0, r1, r2;
     load_px<F32>(src, pitch, y, x, c0, c1, c2);
@@ -57,13 +58,13 @@ __global__ __launch_bounds__(256) void k_prep(const void *src, size_t pitch, int
     g1[(size_t)y * W + x] = make_float4(c0, c1, c2, grd);
 }
 
-void launch_prep(hipStream_t s, const void *src, size_t pitch, int depth_f32, int W, int H, float4 *g1)
-{
-    dim3 grid((W + 255) / 256, H);
+void launch_prep(hipStream_t s, const void *src, size_t pitch, int depth_f32, int W, int H, float4 *g1, const void *src1, float4 *g11)
+{   // src1 != NULL: both images in one launch
+    dim3 grid((W + 255) / 256, H, src1 ? 2 : 1);
     if (depth_f32)
-        hipLaunchKernelGGL(k_prep<true>, grid, dim3(256), 0, s, src, pitch, W, H, g1);
+        hipLaunchKernelGGL(k_prep<true>, grid, dim3(256), 0, s, src, pitch, W, H, g1, src1, g11);
     else
-        hipLaunchKernelGGL(k_prep<false>, grid, dim3(256), 0, s, src, pitch, W, H, g1);
+        hipLaunchKernelGGL(k_prep<false>, grid, dim3(256), 0, s, src, pitch, W, H, g1, src1, g11);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -174,9 +175,10 @@ __device__ __forceinline__ void guide_finish(const float *m, float4 &g2, float4 
     g4 = make_float2(A12, A22);
 }
 
-__global__ __launch_bounds__(64) void k_guide_march(const float4 *__restrict__ g1, int W, int H, int nstrips, int seg_rows,
-                                                   float4 *__restrict__ g2, float4 *__restrict__ g3, float2 *__restrict__ g4)
+__global__ __launch_bounds__(64) void k_guide_march(const float4 *g1, int W, int H, int nstrips, int seg_rows,
+                                                   float4 *g2, float4 *g3, float2 *g4, Guidance second)
 {
+    if (blockIdx.y == 1) { g1 = second.g1; g2 = second.g2; g3 = second.g3; g4 = second.g4; }   // second image of a two-image launch
     const int strip = blockIdx.x % nstrips, seg = blockIdx.x / nstrips;
     const int lane = threadIdx.x;
     const int x0 = strip * 56;
@@ -210,15 +212,16 @@ __global__ __launch_bounds__(64) void k_guide_march(const float4 *__restrict__ g
     }
 }
 
-void launch_guidance(hipStream_t s, Guidance g, double *hs9, int W, int H, int two_pass)
-{
+void launch_guidance(hipStream_t s, Guidance g, double *hs9, int W, int H, int two_pass, const Guidance *second)
+{   // second != NULL (single-pass form only): the guidance of both images in one launch
     if (!two_pass) {
         // one wave per (strip, segment): aim for ~2000 waves (two per SIMD at 178 VGPRs), 16..64 rows each
         const int nstrips = (W + 55) / 56;
         int seg_rows = (int)(((long)H * nstrips + 2047) / 2048);
         seg_rows = seg_rows < 16 ? 16 : (seg_rows > 64 ? 64 : seg_rows);
         const int nsegs = (H + seg_rows - 1) / seg_rows;
-        hipLaunchKernelGGL(k_guide_march, dim3(nstrips * nsegs), dim3(64), 0, s, (const float4 *)g.g1, W, H, nstrips, seg_rows, g.g2, g.g3, g.g4);
+        hipLaunchKernelGGL(k_guide_march, dim3(nstrips * nsegs, second ? 2 : 1), dim3(64), 0, s, (const float4 *)g.g1, W, H, nstrips, seg_rows, g.g2, g.g3, g.g4,
+                           second ? *second : Guidance{});
         return;
     }
     dim3 grid((W + 255) / 256, H);
@@ -1040,7 +1043,8 @@ __global__ __launch_bounds__(256) void k_wta_u8(const uint8_t *__restrict__ vol,
             minDis = d_begin + dl;
         }
     }
-    if (keys) keys[i] = ((long long)minCost << 32) | (long long)minDis;
+    // same key format as the float path / the fused select kernel (which carries q8 as a float): shards may mix both
+    if (keys) keys[i] = pack_key_f32(minCost == 256 ? __builtin_inff() : (float)minCost, minDis);
     if (map) map[i] = (uint8_t)minDis;
 }
 void launch_wta_u8(hipStream_t s, const uint8_t *vol, int W, int H, int d_begin, int Dloc, long long *keys, uint8_t *map)

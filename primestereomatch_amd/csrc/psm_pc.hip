@@ -75,15 +75,38 @@ __device__ __forceinline__ float4 pc_load4(__amdgpu_buffer_rsrc_t r, int voff, i
     return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
 }
 
+// Second set of plane pointers for CVC == 3: one launch filters BOTH volumes (blockIdx.y = side; side 0 = left volume with
+// the kernel's own arguments, side 1 = right volume with these) - twice the workgroups per launch, half the launches.
+struct PcSide {
+    const float4 *G1, *G2, *G3;
+    const float2 *G4;
+    const float4 *Gother;
+    float *kcost;
+    unsigned *kdisp;
+};
+
 // CVC = 0: the cost slice is read from `vin`.  CVC = 1 (left volume) / 2 (right volume): the cost volume is never
 // materialised - the producer waves evaluate myCostGrd (src/CVC.cpp:18-39) for their input column on the fly from the
 // two g1 planes (`G1` = this side's image, `Gother` = the other one), exactly as k_cvc does.
-template <bool VEC4, int CVC, int MODE>
+// U8 (8-bit char mode, select mode with costs on the fly only): the producer waves build the 8-bit matching cost of
+// assets/cvc.cl:279-301 (oracle: cost_u8) from the {c0,c1,c2,grad} byte planes handed over in `vin` (this side) and `vout`
+// (other side) and filter cost * (1/255.0f); the consumer waves re-quantise q8 = sat_u8(rintf(q * 255)) before the
+// strict-'<' selection (assets/dispsel.cl:41-62 with the initial minimum above 255) - the build-defined 8-bit contract
+// of oracle/psm_oracle.h, in one pass and without an 8-bit volume in memory.
+template <bool VEC4, int CVC, int MODE, bool U8 = false>
 __global__ __launch_bounds__(64 * (PcLayout<MODE>::NA + PcLayout<MODE>::NB)) PSM_PC_ATTR void k_cvf_pc(
-    const float *__restrict__ vin, float *__restrict__ vout, const float4 *__restrict__ G1, const float4 *__restrict__ G2,
-    const float4 *__restrict__ G3, const float2 *__restrict__ G4, int W, int H, int Dloc, int ngroups, int nsegs, int seg_rows,
-    int ybeg, int yend, const float4 *__restrict__ Gother, int d_begin, int DC, float *__restrict__ kcost, unsigned *__restrict__ kdisp, int nbmax)
+    const float *__restrict__ vin, float *__restrict__ vout, const float4 *__restrict__ G1a, const float4 *__restrict__ G2a,
+    const float4 *__restrict__ G3a, const float2 *__restrict__ G4a, int W, int H, int Dloc, int ngroups, int nsegs, int seg_rows,
+    int ybeg, int yend, const float4 *__restrict__ Gothera, int d_begin, int DC, float *__restrict__ kcosta, unsigned *__restrict__ kdispa, int nbmax,
+    PcSide side1)
 {
+    const bool right = CVC == 2 || (CVC == 3 && blockIdx.y == 1);      // buildCV_right arithmetic (uniform)
+    const bool s1 = CVC == 3 && blockIdx.y == 1;
+    const float4 *const G1 = s1 ? side1.G1 : G1a, *const G2 = s1 ? side1.G2 : G2a, *const G3 = s1 ? side1.G3 : G3a;
+    const float2 *const G4 = s1 ? side1.G4 : G4a;
+    const float4 *const Gother = s1 ? side1.Gother : Gothera;
+    float *const kcost = s1 ? side1.kcost : kcosta;
+    unsigned *const kdisp = s1 ? side1.kdisp : kdispa;
     using L = PcLayout<MODE>;
     constexpr int PC_NA = L::NA, PC_NB = L::NB, PC_OUT_A = L::OUT_A, PC_OUT_B = L::OUT_B, PC_COLS = L::COLS;
     constexpr int PC_MCOLS = PC_NA * PC_OUT_A;   // model columns per workgroup (>= PC_COLS + 7)
@@ -141,8 +164,8 @@ __global__ __launch_bounds__(64 * (PcLayout<MODE>::NA + PcLayout<MODE>::NB)) PSM
         const float *vd = vin + (size_t)d * HW;
         const int dg = d_begin + d;                   // global disparity of this slice
         // buildCV_left: partner x-d while x >= d; buildCV_right: partner x+d while x < W-d (src/CVC.cpp:135-146,165-176)
-        const bool inb = CVC == 2 ? (ci < W - dg) : (ci >= dg);
-        const int cpart = CVC == 2 ? min(ci + dg, W - 1) : max(ci - dg, 0);
+        const bool inb = right ? (ci < W - dg) : (ci >= dg);
+        const int cpart = right ? min(ci + dg, W - 1) : max(ci - dg, 0);
         const bool any_border = CVC != 0 && __builtin_amdgcn_ballot_w64(!inb) != 0;
         VTree t0 = {}, t1 = {}, t2 = {}, t3 = {};
         float pin[2];
@@ -154,6 +177,10 @@ __global__ __launch_bounds__(64 * (PcLayout<MODE>::NA + PcLayout<MODE>::NB)) PSM
         const __amdgpu_buffer_rsrc_t rG3 = pc_rsrc(G3, (unsigned)HW * 16u), rG4 = pc_rsrc(G4, (unsigned)HW * 8u);
         const __amdgpu_buffer_rsrc_t rGo = pc_rsrc(CVC == 0 ? G1 : Gother, (unsigned)HW * 16u);
         const __amdgpu_buffer_rsrc_t rV = pc_rsrc(CVC == 0 ? (const void *)vd : (const void *)G1, (unsigned)HW * 4u);
+        // U8: byte planes {c0,c1,c2,grad} of this side's / the other side's image (swapped for the right volume of a two-side launch)
+        const __amdgpu_buffer_rsrc_t rP = pc_rsrc(U8 ? (s1 ? (const void *)vout : (const void *)vin) : (const void *)G1, (unsigned)HW * 4u);
+        const __amdgpu_buffer_rsrc_t rPo = pc_rsrc(U8 ? (s1 ? (const void *)vin : (const void *)vout) : (const void *)G1, (unsigned)HW * 4u);
+        unsigned pu[2], po[2];
         const int vci = ci * 16, vcp = cpart * 16, vxa = xac * 16;
 #define PSM_ISSUE_PA(SLOT, STEP)                                                        \
     {                                                                                   \
@@ -162,7 +189,10 @@ __global__ __launch_bounds__(64 * (PcLayout<MODE>::NA + PcLayout<MODE>::NB)) PSM
         ya_ = ya_ < 0 ? 0 : (ya_ > H - 1 ? H - 1 : ya_);                                \
         const int oa_ = ya_ * W;                                                        \
         if (CVC == 0) pin[SLOT] = pc_load1(rV, vci >> 2, row_ * 4);                     \
-        else oth[SLOT] = pc_load4(rGo, vcp, row_ * 16);                                 \
+        else if (U8) {                                                                  \
+            pu[SLOT] = __builtin_amdgcn_raw_buffer_load_b32(rP, vci >> 2, row_ * 4, 0); \
+            po[SLOT] = __builtin_amdgcn_raw_buffer_load_b32(rPo, vcp >> 2, row_ * 4, 0); \
+        } else oth[SLOT] = pc_load4(rGo, vcp, row_ * 16);                               \
         gin[SLOT] = pc_load4(rG1, vci, row_ * 16);                                      \
         o2[SLOT] = pc_load4(rG2, vxa, oa_ * 16);                                        \
         o3[SLOT] = pc_load4(rG3, vxa, oa_ * 16);                                        \
@@ -174,7 +204,13 @@ __global__ __launch_bounds__(64 * (PcLayout<MODE>::NA + PcLayout<MODE>::NB)) PSM
         PSM_ISSUE_PA((K + 1) & 1, (S) + 1)                                                          \
         float p;                                                                                    \
         if (CVC == 0) p = pin[K & 1];                                                               \
-        else {                                                                                      \
+        else if (U8) {                                                                              \
+            const unsigned b_ = inb ? po[K & 1] : 0xffffffffu;        /* border: the other image reads as 255 */ \
+            const unsigned clr_ = __builtin_amdgcn_sad_u8(pu[K & 1] & 0xffffffu, b_ & 0xffffffu, 0u); \
+            const int gd_ = (int)(pu[K & 1] >> 24) - (int)(b_ >> 24);                               \
+            const float f_ = __fadd_rn(__fmul_rn(0.9f, (float)(clr_ / 3u)), __fmul_rn(__fsub_rn(1.0f, 0.9f), (float)(gd_ < 0 ? -gd_ : gd_))); \
+            p = __fmul_rn((float)(unsigned)(unsigned char)f_, 1 / 255.0f);                          \
+        } else {                                                                                    \
             p = cost_pair(gin[K & 1], oth[K & 1]);                                                  \
             if (any_border) {   /* only where x < d (left) / x >= W-d (right) occurs in this wave */   \
                 asm volatile("; border cost");   /* keeps this a real branch */                     \
@@ -319,6 +355,13 @@ __global__ __launch_bounds__(64 * (PcLayout<MODE>::NA + PcLayout<MODE>::NB)) PSM
                 } else {
                     // DispSel::CVSelect (src/DispSel.cpp:96-104) over the slices of this chunk: strict '<', d = 0 never a
                     // candidate, NaN never wins.  Rows outside [y0, y1) and halo lanes keep (+inf, 0).
+                    if (U8) {   // q8 = sat_u8(rintf(q * 255)), NaN -> 0 (oracle: quant_u8); kept as a float: the selection below is unchanged
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            const float r_ = rintf(__fmul_rn(qv[k], 255.0f));
+                            qv[k] = !(r_ > 0.0f) ? 0.0f : (r_ > 255.0f ? 255.0f : r_);
+                        }
+                    }
                     float kn[4] = {kq.x, kq.y, kq.z, kq.w};
                     unsigned dn = kd4;
                     bool any = false;
@@ -352,11 +395,17 @@ __global__ __launch_bounds__(64 * (PcLayout<MODE>::NA + PcLayout<MODE>::NB)) PSM
 // chunk planes -> packed WTA key and / or final map per pixel (minimum over the chunks; pack_key_f32 makes the signed
 // 64-bit minimum select (min cost, then lowest d) exactly as the sequential loop of src/DispSel.cpp:96-104).
 // One thread per record (pair, consumer wave, batch, lane) = four rows of one column, as the select kernel wrote them.
-__global__ __launch_bounds__(256) void k_chunk_min(const float4 *__restrict__ kcost, const unsigned *__restrict__ kdisp, int nchunks, int npairs,
-                                                  int nbmax, int ngroups, int seg_rows, int W, int H, long long *__restrict__ keys,
-                                                  uint8_t *__restrict__ map)
+__global__ __launch_bounds__(256) void k_chunk_min(const float4 *kcost, const unsigned *kdisp, int nchunks, int npairs,
+                                                  int nbmax, int ngroups, int seg_rows, int W, int H, long long *keys,
+                                                  uint8_t *map, const float4 *__restrict__ kcost1, const unsigned *__restrict__ kdisp1)
 {
     using L = PcLayout<1>;
+    if (blockIdx.y == 1) {   // second volume of a two-side launch: its own planes, keys / map one image further
+        kcost = kcost1;
+        kdisp = kdisp1;
+        if (keys) keys += (size_t)W * H;
+        if (map) map += (size_t)W * H;
+    }
     const size_t nrec = (size_t)npairs * L::NB * nbmax * 64;       // records per chunk plane
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= nrec) return;
@@ -455,7 +504,7 @@ void launch_cvf_fused(hipStream_t s, March m, const float *vin, float *vout, Gui
 #define PSM_LAUNCH_PC(V4, CV)                                                                                              \
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_cvf_pc<V4, CV, 0>), dim3(nblocks), blk, 0, s, vin, vout, (const float4 *)gd.g1,   \
                        (const float4 *)gd.g2, (const float4 *)gd.g3, (const float2 *)gd.g4, W, H, Dloc, pl.ngroups, pl.nsegs, \
-                       pl.seg_rows, ybeg, yend, g1_other, d_begin, 1, (float *)nullptr, (unsigned *)nullptr, 0)
+                       pl.seg_rows, ybeg, yend, g1_other, d_begin, 1, (float *)nullptr, (unsigned *)nullptr, 0, PcSide{})
     const bool v4 = (W & 3) == 0;
     if (cvc_mode == 1) { if (v4) PSM_LAUNCH_PC(true, 1); else PSM_LAUNCH_PC(false, 1); }
     else if (cvc_mode == 2) { if (v4) PSM_LAUNCH_PC(true, 2); else PSM_LAUNCH_PC(false, 2); }
@@ -464,8 +513,8 @@ void launch_cvf_fused(hipStream_t s, March m, const float *vin, float *vout, Gui
 }
 
 void launch_cvf_select(hipStream_t s, March m, const float *vin, Guidance gd, int W, int H, int Dloc, const float4 *g1_other,
-                       int d_begin, int cvc_mode, void *scratch)
-{
+                       int d_begin, int cvc_mode, void *scratch, const uint8_t *p4_own, const uint8_t *p4_other)
+{   // p4_own != NULL (cvc_mode 1 / 2 only): 8-bit char mode
     const PcPlan pl = pc_plan(W, H, Dloc, m.seg_rows, 1);
     float *kcost = (float *)scratch;                                           // nchunks * rec_per_chunk float4
     unsigned *kdisp = (unsigned *)(kcost + 4 * pl.rec_per_chunk * pl.nchunks);  // nchunks * rec_per_chunk uchar4
@@ -474,8 +523,15 @@ void launch_cvf_select(hipStream_t s, March m, const float *vin, Guidance gd, in
 #define PSM_LAUNCH_PC(CV)                                                                                                   \
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_cvf_pc<false, CV, 1>), dim3(nblocks), blk, 0, s, vin, (float *)nullptr, (const float4 *)gd.g1, \
                        (const float4 *)gd.g2, (const float4 *)gd.g3, (const float2 *)gd.g4, W, H, Dloc, pl.ngroups, pl.nsegs, \
-                       pl.seg_rows, 0, H, g1_other, d_begin, pl.DC, kcost, kdisp, pl.nbmax)
-    if (cvc_mode == 1) PSM_LAUNCH_PC(1); else if (cvc_mode == 2) PSM_LAUNCH_PC(2); else PSM_LAUNCH_PC(0);
+                       pl.seg_rows, 0, H, g1_other, d_begin, pl.DC, kcost, kdisp, pl.nbmax, PcSide{})
+    if (p4_own && cvc_mode != 0) {
+#define PSM_LAUNCH_PC8(CV)                                                                                                  \
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_cvf_pc<false, CV, 1, true>), dim3(nblocks), blk, 0, s, (const float *)p4_own, (float *)const_cast<uint8_t *>(p4_other), \
+                       (const float4 *)gd.g1, (const float4 *)gd.g2, (const float4 *)gd.g3, (const float2 *)gd.g4, W, H, Dloc, pl.ngroups, pl.nsegs, \
+                       pl.seg_rows, 0, H, g1_other, d_begin, pl.DC, kcost, kdisp, pl.nbmax, PcSide{})
+        if (cvc_mode == 1) PSM_LAUNCH_PC8(1); else PSM_LAUNCH_PC8(2);
+#undef PSM_LAUNCH_PC8
+    } else if (cvc_mode == 1) PSM_LAUNCH_PC(1); else if (cvc_mode == 2) PSM_LAUNCH_PC(2); else PSM_LAUNCH_PC(0);
 #undef PSM_LAUNCH_PC
 }
 
@@ -485,7 +541,40 @@ void launch_chunk_min(hipStream_t s, March m, int W, int H, int Dloc, void *scra
     const float *kcost = (const float *)scratch;
     const unsigned *kdisp = (const unsigned *)(kcost + 4 * pl.rec_per_chunk * pl.nchunks);
     hipLaunchKernelGGL(k_chunk_min, dim3((unsigned)((pl.rec_per_chunk + 255) / 256)), dim3(256), 0, s, (const float4 *)kcost, (const unsigned *)kdisp,
-                       pl.nchunks, pl.ngroups * pl.nsegs, pl.nbmax, pl.ngroups, pl.seg_rows, W, H, keys, map);
+                       pl.nchunks, pl.ngroups * pl.nsegs, pl.nbmax, pl.ngroups, pl.seg_rows, W, H, keys, map, (const float4 *)nullptr, (const unsigned *)nullptr);
+}
+
+// Both volumes in one launch each (costs built on the fly): left volume = (g[0], other g[1].g1), right = (g[1], other g[0].g1);
+// scratch: 2 x pc_plan(...).scratch_bytes(); keys / map: [2][H][W].
+void launch_cvf_select2(hipStream_t s, March m, const Guidance *g, int W, int H, int Dloc, int d_begin, void *scratch, const uint8_t *const *p4)
+{   // p4 != NULL: 8-bit char mode, p4[0] / p4[1] = byte planes {c0,c1,c2,grad} of the left / right image
+    const PcPlan pl = pc_plan(W, H, Dloc, m.seg_rows, 1);
+    float *kcost0 = (float *)scratch;
+    unsigned *kdisp0 = (unsigned *)(kcost0 + 4 * pl.rec_per_chunk * pl.nchunks);
+    float *kcost1 = (float *)((char *)scratch + pl.scratch_bytes());
+    unsigned *kdisp1 = (unsigned *)(kcost1 + 4 * pl.rec_per_chunk * pl.nchunks);
+    const int nblocks = 8 * ((pl.ngroups * pl.nsegs * pl.nchunks + 7) / 8);
+    const dim3 blk(64 * (PcLayout<1>::NA + PcLayout<1>::NB));
+    const PcSide s1 = {(const float4 *)g[1].g1, (const float4 *)g[1].g2, (const float4 *)g[1].g3, (const float2 *)g[1].g4, (const float4 *)g[0].g1, kcost1, kdisp1};
+    if (p4)
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_cvf_pc<false, 3, 1, true>), dim3(nblocks, 2), blk, 0, s, (const float *)p4[0], (float *)const_cast<uint8_t *>(p4[1]),
+                           (const float4 *)g[0].g1, (const float4 *)g[0].g2, (const float4 *)g[0].g3, (const float2 *)g[0].g4, W, H, Dloc, pl.ngroups,
+                           pl.nsegs, pl.seg_rows, 0, H, (const float4 *)g[1].g1, d_begin, pl.DC, kcost0, kdisp0, pl.nbmax, s1);
+    else
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_cvf_pc<false, 3, 1>), dim3(nblocks, 2), blk, 0, s, (const float *)nullptr, (float *)nullptr, (const float4 *)g[0].g1,
+                           (const float4 *)g[0].g2, (const float4 *)g[0].g3, (const float2 *)g[0].g4, W, H, Dloc, pl.ngroups, pl.nsegs, pl.seg_rows, 0, H,
+                           (const float4 *)g[1].g1, d_begin, pl.DC, kcost0, kdisp0, pl.nbmax, s1);
+}
+
+void launch_chunk_min2sides(hipStream_t s, March m, int W, int H, int Dloc, void *scratch, long long *keys, uint8_t *map)
+{
+    const PcPlan pl = pc_plan(W, H, Dloc, m.seg_rows, 1);
+    const float *kcost0 = (const float *)scratch;
+    const unsigned *kdisp0 = (const unsigned *)(kcost0 + 4 * pl.rec_per_chunk * pl.nchunks);
+    const float *kcost1 = (const float *)((const char *)scratch + pl.scratch_bytes());
+    const unsigned *kdisp1 = (const unsigned *)(kcost1 + 4 * pl.rec_per_chunk * pl.nchunks);
+    hipLaunchKernelGGL(k_chunk_min, dim3((unsigned)((pl.rec_per_chunk + 255) / 256), 2), dim3(256), 0, s, (const float4 *)kcost0, kdisp0,
+                       pl.nchunks, pl.ngroups * pl.nsegs, pl.nbmax, pl.ngroups, pl.seg_rows, W, H, keys, map, (const float4 *)kcost1, kdisp1);
 }
 
 }  // namespace psm

@@ -25,3 +25,12 @@ for f in sorted(glob.glob("$OUT/bench_*.json")):
         print(f, "ERR", e)
 PY
 tail -5 $OUT/bench.err
+for cfg in "--config c1" "--config c1x" "--config c4 --dtype u8"; do
+  n=$(echo "$cfg" | tr -d ' -')
+  timeout 300 python bench.py --no-cpu-baseline --verify --steps 20 $cfg > $OUT/bench_u8_$n.json 2>> $OUT/bench.err
+  python -c "
+import json,sys
+j=json.loads(open('$OUT/bench_u8_$n.json').read().strip().splitlines()[-1])
+print('u8', '$n', '%.3e vox/s'%j['value'], '%.3f ms'%j['ms_per_step'], {k:v['avg_ms'] for k,v in j['kernels'].items()}, 'frac', j['roofline']['frac'], 'verified', j.get('verified_vs_single_gpu'))"
+done
+tail -3 $OUT/bench.err

@@ -470,7 +470,7 @@ def test_cpp_dispest_demo(psm, oracle, golden, tmp_path, mode, float_input):
     assert np.array_equal(lv, oracle.lr_check(ld, rd)[0])
 
 
-@pytest.mark.parametrize("flags", [0, 256, 128, 128 + 64, 16, 16 + 1, 16 + 2, 16 + 4, 512, 512 + 128, 4096, 8192, 8192 + 128, 16384, 16384 + 128])
+@pytest.mark.parametrize("flags", [0, 256, 128, 128 + 64, 16, 16 + 1, 16 + 2, 16 + 4, 512, 512 + 128, 4096, 8192, 8192 + 128, 16384, 16384 + 128, 65536])
 def test_tuning_flags_do_not_change_results(psm, oracle, flags):
     """PSM_OPT_FLAGS only changes store policy / block traversal / CVC store width."""
     from primestereomatch_amd import capi, synth
