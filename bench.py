@@ -6,8 +6,8 @@
 
 One "step" = one pass of the hot path over one synthetic stereo pair already resident in HBM:
 CostConst (gray/gradient + both cost volumes) -> CostFilter (guidance precompute + guided filter
-of both volumes) -> DispSel (WTA; for N > 1: local WTA -> one RCCL all-gather of the packed
-per-pixel minima -> final argmin).  Workload at N=1: BASELINE.json configs[3], 1920x1080, D=256,
+of both volumes) -> DispSel (WTA; for N > 1: the fused kernel's packed per-pixel minima over the local slices -> ONE RCCL
+all-reduce(MIN) per frame (or all-gather + device-side minimum) -> final maps).  Workload at N=1: BASELINE.json configs[3], 1920x1080, D=256,
 float32 - the configuration the metric is quoted on; for N > 1 the D slices of that same job are
 sharded over the ranks (total work fixed -> "scaling": "strong").
 
@@ -82,12 +82,10 @@ def main():
     ap.add_argument("--fgf", type=int, default=0, choices=[0, 2, 4, 8],
                     help="diagnostic: aggregate with the Fast Guided Filter variant (CostFilter_FGF) at this subsample "
                          "rate instead of the full guided filter; not the north-star metric")
-    ap.add_argument("--no-overlap", action="store_true",
-                    help="N>1: exchange both sides after both filters instead of overlapping the left exchange "
-                         "with the right filter")
+    ap.add_argument("--no-overlap", action="store_true", help="(kept for old command lines; same as --no-frame-pipeline)")
     ap.add_argument("--no-frame-pipeline", action="store_true",
                     help="N>1: finish the exchange + merge of a frame inside its own step instead of one step later "
-                         "(default: the right side's exchange overlaps the next frame's left filter; two key buffers)")
+                         "(default: a frame's all-reduce overlaps the next frame's filter; two key tensors)")
     ap.add_argument("--verify", action="store_true",
                     help="N=1: also compare the maps of the timed path with a fresh single-context run (always done for N>1)")
     ap.add_argument("--shard-sim", type=int, default=0,
@@ -95,6 +93,8 @@ def main():
                          "the JSON line is then NOT the headline metric")
     args = ap.parse_args()
 
+    if args.no_overlap:
+        args.no_frame_pipeline = True
     N = args.gpus
     if N < 1:
         raise SystemExit("bench.py: --gpus must be >= 1")
@@ -167,10 +167,10 @@ def main():
     if args.fgf:
         de.setSubsampleRate(args.fgf)
 
-    pipelined = use_dist and args.exchange == "allreduce" and not args.no_overlap and not args.no_frame_pipeline and not args.fgf
+    pipelined = use_dist and args.exchange == "allreduce" and not args.no_frame_pipeline and not args.fgf
 
     def finish_pending():
-        # exchange of an earlier frame -> final maps (the collectives ran on RCCL's stream meanwhile)
+        # exchange of an earlier frame -> final maps (the collective ran on RCCL's stream meanwhile)
         while pending:
             works, kb = pending.pop(0)
             for w_ in works:
@@ -191,37 +191,22 @@ def main():
                 de.DispSelect_device()
             return
         if pipelined:
-            # Frame pipeline: both exchanges are asynchronous; the merge of frame i is issued during frame i+1,
-            # after that frame's left filter, so no kernel of ours ever waits for a collective that has not had a
-            # whole filter pass to complete.  Keys alternate between two buffers.
-            HWk = H * W
+            # Frame pipeline, ONE collective per frame: the fused kernel leaves the packed minima of both volumes directly
+            # in this frame's key tensor; the all-reduce(MIN) over the ranks is asynchronous and has the whole next
+            # frame's filter to complete - its merge is issued after that filter, so no kernel of ours ever waits for a
+            # collective that is still running.  Keys alternate between two tensors.
             kb = kbuf[frame[0] & 1]
             frame[0] += 1
-            de.CostFilter_side(0)
-            de.DispSelect_partial_side(0, kb.data_ptr())
-            wl = dist.all_reduce(kb[:HWk], op=dist.ReduceOp.MIN, async_op=True)
+            de.set_key_buffer(kb.data_ptr())
+            de.CostFilter_GPU()
             finish_pending()
-            de.CostFilter_side(1)
-            de.DispSelect_partial_side(1, kb.data_ptr() + 8 * HWk)
-            wr = dist.all_reduce(kb[HWk:], op=dist.ReduceOp.MIN, async_op=True)
-            pending.append(((wl, wr), kb))
+            w_ = dist.all_reduce(kb, op=dist.ReduceOp.MIN, async_op=True)
+            pending.append(((w_,), kb))
             return
-        if use_dist and args.exchange == "allreduce" and not args.no_overlap:
-            # left volume: filter, local minima, start its exchange (RCCL runs on the process group's own
-            # stream, ordered after everything issued so far); the right volume is filtered meanwhile
-            HWk = H * W
-            de.CostFilter_side(0)
-            de.DispSelect_partial_side(0, keys_local.data_ptr())
-            work = dist.all_reduce(keys_local[:HWk], op=dist.ReduceOp.MIN, async_op=True)
-            de.CostFilter_side(1)
-            de.DispSelect_partial_side(1, keys_local.data_ptr() + 8 * HWk)
-            dist.all_reduce(keys_local[HWk:], op=dist.ReduceOp.MIN)
-            work.wait()
-            de.DispSelect_merge(keys_local.data_ptr(), 1, download=False)
-            return
+        if use_dist:
+            de.set_key_buffer(keys_local.data_ptr())
         de.CostFilter_GPU()
         if use_dist:
-            de.DispSelect_partial(keys_local.data_ptr())
             if args.exchange == "none":       # diagnostic only: cost of the torch collective call itself
                 de.DispSelect_merge(keys_local.data_ptr(), 1, download=False)
             elif args.exchange == "allreduce":

@@ -148,7 +148,12 @@ int psm_disp_select(psm_ctx *ctx, uint8_t *lmap, uint8_t *rmap, size_t stride);
 int psm_disp_select_partial(psm_ctx *ctx, void *dev_keys);
 /* The same for one side only: dev_keys_side = DEVICE pointer to H*W int64 (NULL: the context's buffer). */
 int psm_disp_select_partial_side(psm_ctx *ctx, int side, void *dev_keys_side);
-/* Device pointer / size of the context's own key buffer. */
+/* Let the context write its packed minima (both sides, 2*H*W int64) straight into a caller-owned DEVICE buffer - e.g. the
+ * torch tensor a collective is about to reduce - instead of its own (NULL: back to its own).  Call before
+ * psm_cost_filter of the frame whose minima should land there; psm_disp_select_partial(ctx, NULL) and psm_disp_merge
+ * then use that buffer.  Saves the device-to-device copy of the keys per frame on a sharded host. */
+int psm_set_key_buffer(psm_ctx *ctx, void *dev_keys);
+/* Device pointer / size of the context's current key buffer. */
 int psm_partial_keys(psm_ctx *ctx, void **dev_keys, size_t *bytes);
 /* Sharded DispSel, step 2: dev_keys_all = DEVICE pointer to nranks consecutive key buffers
  * (the all-gather result, rank-major).  Produces the two final maps as psm_disp_select. */

@@ -41,6 +41,7 @@ SYMBOLS = [
     ("psm_disp_select", _i, [_vp, _vp, _vp, _sz]),
     ("psm_disp_select_partial_side", _i, [_vp, _i, _vp]),
     ("psm_disp_select_partial", _i, [_vp, _vp]),
+    ("psm_set_key_buffer", _i, [_vp, _vp]),
     ("psm_partial_keys", _i, [_vp, C.POINTER(_vp), C.POINTER(_sz)]),
     ("psm_disp_merge", _i, [_vp, _vp, _i, _vp, _vp, _sz]),
     ("psm_disp_merge_ctx", _i, [_vp, C.POINTER(_vp), _i, _vp, _vp, _sz]),

@@ -48,6 +48,7 @@ struct psm_ctx {
     float *spare = nullptr;             // PSM_F32: output volume of the fused filter (ping-pong with vol[side])
     float4 *ab = nullptr;               // [Dloc][H][W] {a0,a1,a2,b}; also box8 output
     long long *keys = nullptr;          // [2][H][W]
+    long long *keys_cur = nullptr;      // where the packed minima go: `keys`, or the caller's buffer (psm_set_key_buffer)
     long long *gather = nullptr;        // [gather_ranks][2][H][W], psm_disp_merge_ctx
     int gather_ranks = 0;
     uint8_t *maps = nullptr;            // [2][H][W]
@@ -65,6 +66,7 @@ struct psm_ctx {
     // the packed per-pixel minima in keys[side].  vol[side] is then untouched (raw_rows[side] still describes the
     // UNFILTERED volume); any reader of the filtered volume re-runs the filter in "store" mode first (materialize()).
     bool gf_virtual[2] = {false, false};
+    bool have_guid[2] = {false, false};   // g2..g4 of a side are those of the current image pair
     void *gf_scratch = nullptr;         // chunk planes of the select-mode kernel (PcPlan::scratch_bytes)
     size_t gf_scratch_bytes = 0;
     float4 *fgf_mab[2] = {nullptr, nullptr};
@@ -216,6 +218,7 @@ int run_prep(psm_ctx *c)
     }
     if (check_launch(c, "prep")) return 1;
     c->soa_state[0] = c->soa_state[1] = 0;
+    c->have_guid[0] = c->have_guid[1] = false;
     c->have_g1 = true;
     return 0;
 }
@@ -405,6 +408,7 @@ int psm_create_shard(psm_ctx **out, int width, int height, int max_disp, int d_b
     }
     // (fvol, the float work copy of the 8-bit storing path, is allocated on first use)
     if (e == hipSuccess) e = hipMalloc((void **)&c->keys, 2 * HW * sizeof(long long));
+    c->keys_cur = c->keys;
     if (e == hipSuccess) e = hipMalloc((void **)&c->maps, 2 * HW + 4);   // +4: psm_wgt_median reads/updates whole aligned dwords
     if (e == hipSuccess) e = hipMalloc((void **)&c->valid, 2 * HW);
     if (e != hipSuccess) {
@@ -553,9 +557,15 @@ static int filter_side(psm_ctx *c, int side, bool stage_b)
     if (fgf_flush(c, side)) return 1;
     if (c->gf_virtual[side] && materialize(c, side)) return 1;   // filtering an already filtered (virtual) volume: make it real first
     if ((c->march.flags & 256) && !c->hs9) PSM_HIP(c, hipMalloc((void **)&c->hs9, (size_t)9 * W * H * sizeof(double)));
-    {
+    if (c->march.flags & (256 | 65536)) {
         Prof p(c, PSM_K_GUIDE);
         launch_guidance(c->stream, c->g[side], c->hs9, W, H, (c->march.flags & 256) ? 1 : 0);
+        c->have_guid[side] = true;
+    } else if (!c->have_guid[side]) {
+        // the guidance of BOTH images in one launch the first time either side asks (the other side's call then finds it)
+        Prof p(c, PSM_K_GUIDE);
+        launch_guidance(c->stream, c->g[0], nullptr, W, H, 0, &c->g[1]);
+        c->have_guid[0] = c->have_guid[1] = true;
     }
     // Default: the fused kernel in "select" mode - the WTA over the local slices runs inside the filter, the filtered
     // volume stays virtual (flag 8192 forces the storing form; 16 / 512 / the direct variant select other filters)
@@ -576,8 +586,8 @@ static int filter_side(psm_ctx *c, int side, bool stage_b)
         }
         {
             Prof p(c, PSM_K_WTA);
-            if (q2) launch_chunk_min2(c->stream, c->march, W, H, c->Dloc, c->gf_scratch, c->keys + side * HW, nullptr);
-            else launch_chunk_min(c->stream, c->march, W, H, c->Dloc, c->gf_scratch, c->keys + side * HW, nullptr);
+            if (q2) launch_chunk_min2(c->stream, c->march, W, H, c->Dloc, c->gf_scratch, c->keys_cur + side * HW, nullptr);
+            else launch_chunk_min(c->stream, c->march, W, H, c->Dloc, c->gf_scratch, c->keys_cur + side * HW, nullptr);
         }
         c->gf_virtual[side] = true;
         return check_launch(c, "cvf (fused, select mode)");
@@ -689,9 +699,10 @@ static bool can_filter_both(const psm_ctx *c)
 static int filter_both(psm_ctx *c)
 {
     if (!c->have_g1 && run_prep(c)) return 1;
-    {
+    if (!(c->have_guid[0] && c->have_guid[1])) {
         Prof p(c, PSM_K_GUIDE);
         launch_guidance(c->stream, c->g[0], nullptr, c->W, c->H, 0, &c->g[1]);
+        c->have_guid[0] = c->have_guid[1] = true;
     }
     const PcPlan pl = pc_plan(c->W, c->H, c->Dloc, c->march.seg_rows, 1);
     if (ensure_gf_scratch(c, 2 * pl.scratch_bytes())) return 1;
@@ -701,7 +712,7 @@ static int filter_both(psm_ctx *c)
     }
     {
         Prof p(c, PSM_K_WTA);
-        launch_chunk_min2sides(c->stream, c->march, c->W, c->H, c->Dloc, c->gf_scratch, c->keys, nullptr);
+        launch_chunk_min2sides(c->stream, c->march, c->W, c->H, c->Dloc, c->gf_scratch, c->keys_cur, nullptr);
     }
     c->gf_virtual[0] = c->gf_virtual[1] = true;
     return check_launch(c, "cvf (fused, select mode, both volumes)");
@@ -824,11 +835,11 @@ static int wta_side(psm_ctx *c, int s, long long *keys_s, uint8_t *map_s)
     Prof p(c, PSM_K_WTA);
     if (c->gf_virtual[s]) {
         // the select-mode filter already reduced this side: keys[s] holds the packed minima over the local slices
-        const long long *src = c->keys + s * HW;
+        const long long *src = c->keys_cur + s * HW;
         if (keys_s && keys_s != src) PSM_HIP(c, hipMemcpyAsync(keys_s, src, HW * sizeof(long long), hipMemcpyDeviceToDevice, c->stream));
         if (map_s) launch_merge(c->stream, src, HW, 1, (int)HW, map_s);
     } else if (c->fgf_virtual[s]) {
-        long long *k = keys_s ? keys_s : c->keys + s * HW;
+        long long *k = keys_s ? keys_s : c->keys_cur + s * HW;
         launch_fgf_apply_wta(c->stream, c->g[s].g1, c->W, c->H, c->Dloc, c->d0, c->fgf_virtual[s], c->fgf_mab[s], k);
         if (map_s) launch_merge(c->stream, k, HW, 1, (int)HW, map_s);
     } else if (c->dtype == PSM_U8) {
@@ -844,7 +855,7 @@ static int wta_launch(psm_ctx *c, long long *keys, uint8_t *maps)
     const size_t HW = (size_t)c->W * c->H;
     if (c->gf_virtual[0] && c->gf_virtual[1] && !keys && maps) {   // both sides already reduced to keys: one launch for both maps
         Prof p(c, PSM_K_WTA);
-        launch_merge(c->stream, c->keys, 2 * HW, 1, (int)(2 * HW), maps);
+        launch_merge(c->stream, c->keys_cur, 2 * HW, 1, (int)(2 * HW), maps);
         return check_launch(c, "wta");
     }
     for (int s = 0; s < 2; ++s)
@@ -880,7 +891,7 @@ int psm_disp_select_partial(psm_ctx *c, void *dev_keys)
     if (bind(c)) return 1;
     const double t0 = now_us();
     if (wta_ready(c, 0) || wta_ready(c, 1)) return 1;
-    if (wta_launch(c, dev_keys ? (long long *)dev_keys : c->keys, nullptr)) return 1;
+    if (wta_launch(c, dev_keys ? (long long *)dev_keys : c->keys_cur, nullptr)) return 1;
     return end_stage(c, PSM_STAGE_DISPSEL, t0);
 }
 
@@ -893,7 +904,7 @@ int psm_disp_select_partial_side(psm_ctx *c, int side, void *dev_keys_side)
     const double t0 = now_us();
     if (wta_ready(c, side)) return 1;
     const size_t HW = (size_t)c->W * c->H;
-    long long *keys = dev_keys_side ? (long long *)dev_keys_side : c->keys + side * HW;
+    long long *keys = dev_keys_side ? (long long *)dev_keys_side : c->keys_cur + side * HW;
     if (wta_side(c, side, keys, nullptr)) return 1;
     if (check_launch(c, "wta")) return 1;
     if (!c->opt_async) PSM_HIP(c, hipStreamSynchronize(c->stream));
@@ -901,10 +912,20 @@ int psm_disp_select_partial_side(psm_ctx *c, int side, void *dev_keys_side)
     return 0;
 }
 
+int psm_set_key_buffer(psm_ctx *c, void *dev_keys)
+{
+    if (!c) return 1;
+    long long *k = dev_keys ? (long long *)dev_keys : c->keys;
+    if (k != c->keys_cur && (c->gf_virtual[0] || c->gf_virtual[1]))
+        return fail(c, "psm_set_key_buffer: the current minima are still pending in the previous buffer (call before psm_cost_filter)");
+    c->keys_cur = k;
+    return 0;
+}
+
 int psm_partial_keys(psm_ctx *c, void **dev_keys, size_t *bytes)
 {
     if (!c) return 1;
-    if (dev_keys) *dev_keys = c->keys;
+    if (dev_keys) *dev_keys = c->keys_cur;
     if (bytes) *bytes = 2 * (size_t)c->W * c->H * sizeof(long long);
     return 0;
 }

@@ -34,7 +34,24 @@
 
 #include <cstdlib>
 
+#ifndef PSM_PC_TIMING
+#define PSM_PC_TIMING 0   // 1: every wave accumulates its cycles between barriers (work) and inside them (wait) per role
+#endif
+
 namespace psm {
+
+#if PSM_PC_TIMING
+__device__ unsigned long long g_pc_dbg[8];   // work cycles of waves A0, A1, B0, B1, then their barrier-wait cycles
+#define PC_SYNC()                                                                \
+    {                                                                            \
+        const unsigned long long a_ = __builtin_readcyclecounter();              \
+        __syncthreads();                                                         \
+        const unsigned long long b_ = __builtin_readcyclecounter();              \
+        q_work += a_ - q_mark; q_wait += b_ - a_; q_mark = b_;                   \
+    }
+#else
+#define PC_SYNC() __syncthreads()
+#endif
 
 typedef float f4v __attribute__((ext_vector_type(4)));
 
@@ -149,6 +166,9 @@ __global__ __launch_bounds__(64 * (PcLayout<MODE>::NA + PcLayout<MODE>::NB)) PSM
     (void)i1;
     const size_t HW = (size_t)H * W;
 
+#if PSM_PC_TIMING
+    unsigned long long q_work = 0, q_wait = 0, q_mark = __builtin_readcyclecounter();
+#endif
     const int nds = MODE == 0 ? 1 : DC;               // MODE 0 always runs with DC == 1 (one slice per workgroup)
     for (int ds = 0; ds < nds; ++ds) {                // the slices of this chunk, ascending d
     const int d = ch * DC + ds;
@@ -238,9 +258,9 @@ __global__ __launch_bounds__(64 * (PcLayout<MODE>::NA + PcLayout<MODE>::NB)) PSM
             const int s0 = 8 + b * 4;
             float4 *dst = &ring[b & (PC_RING - 1)][0][wave * PC_OUT_A + lane];
             PSM_STEP_PA(0, s0, dst) PSM_STEP_PA(1, s0 + 1, dst) PSM_STEP_PA(2, s0 + 2, dst) PSM_STEP_PA(3, s0 + 3, dst)
-            __syncthreads();
+            PC_SYNC();
         }
-        for (int b = nbA; b < iters; ++b) __syncthreads();
+        for (int b = nbA; b < iters; ++b) PC_SYNC();
 #undef PSM_STEP_PA
 #undef PSM_ISSUE_PA
     } else {
@@ -323,8 +343,8 @@ __global__ __launch_bounds__(64 * (PcLayout<MODE>::NA + PcLayout<MODE>::NB)) PSM
                 PSM_K_LOAD(0)
             }
         }
-        __syncthreads();                               // iteration 0
-        __syncthreads();                               // iteration 1
+        PC_SYNC();                               // iteration 0
+        PC_SYNC();                               // iteration 1
         for (int b = 2; b <= nbB + 1; ++b) {           // iteration b: consume feed batch c = b-2
             const int c = b - 2;
             if (c >= 1) store_batch(c - 1);
@@ -381,15 +401,21 @@ __global__ __launch_bounds__(64 * (PcLayout<MODE>::NA + PcLayout<MODE>::NB)) PSM
                     if (ds > 0 && c + 1 < nbB) PSM_K_LOAD(c + 1)       // records of the next batch
                 }
             }
-            __syncthreads();
+            PC_SYNC();
         }
         store_batch(nbB - 1);                          // iteration nbB+2
-        __syncthreads();
+        PC_SYNC();
 #undef PSM_ISSUE_PB
 #undef PSM_K_LOAD
     }
     if (MODE == 1) __builtin_amdgcn_s_waitcnt(0);      // the chunk planes of this slice are in the L2 before the next slice reads them
     }   // slices of the chunk
+#if PSM_PC_TIMING
+    if (lane == 0 && MODE == 1) {
+        atomicAdd(&g_pc_dbg[wave], q_work);
+        atomicAdd(&g_pc_dbg[4 + wave], q_wait);
+    }
+#endif
 }
 
 // chunk planes -> packed WTA key and / or final map per pixel (minimum over the chunks; pack_key_f32 makes the signed
@@ -444,6 +470,22 @@ __global__ __launch_bounds__(256) void k_chunk_min(const float4 *kcost, const un
         if (map) map[o] = (uint8_t)((unsigned long long)best[k] & 0xffull);
     }
 }
+
+}  // namespace psm
+
+// debug: read and clear the per-wave cycle counters of k_cvf_pc (all zero unless built with -DPSM_PC_TIMING=1)
+extern "C" int psm_debug_pc_cycles(unsigned long long *out8)
+{
+    for (int i = 0; i < 8; ++i) out8[i] = 0;
+#if PSM_PC_TIMING
+    if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(psm::g_pc_dbg), 8 * sizeof(unsigned long long)) != hipSuccess) return 1;
+    unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(psm::g_pc_dbg), z, sizeof z) != hipSuccess) return 1;
+#endif
+    return 0;
+}
+
+namespace psm {
 
 // Segment count k (and, for MODE 1, slices per chunk DC): every segment re-walks 14 halo rows, and the launch runs in
 // rounds of resident workgroups - per XCD ceil(pairs/8) (column group, segment) pairs x chunks over 32 CUs x 3
@@ -541,7 +583,8 @@ void launch_chunk_min(hipStream_t s, March m, int W, int H, int Dloc, void *scra
     const float *kcost = (const float *)scratch;
     const unsigned *kdisp = (const unsigned *)(kcost + 4 * pl.rec_per_chunk * pl.nchunks);
     hipLaunchKernelGGL(k_chunk_min, dim3((unsigned)((pl.rec_per_chunk + 255) / 256)), dim3(256), 0, s, (const float4 *)kcost, (const unsigned *)kdisp,
-                       pl.nchunks, pl.ngroups * pl.nsegs, pl.nbmax, pl.ngroups, pl.seg_rows, W, H, keys, map, (const float4 *)nullptr, (const unsigned *)nullptr);
+                       pl.nchunks, pl.ngroups * pl.nsegs, pl.nbmax, pl.ngroups, pl.seg_rows, W, H, keys, map, (const float4 *)nullptr,
+                       (const unsigned *)nullptr);
 }
 
 // Both volumes in one launch each (costs built on the fly): left volume = (g[0], other g[1].g1), right = (g[1], other g[0].g1);

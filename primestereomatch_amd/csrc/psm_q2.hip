@@ -22,7 +22,27 @@
 #include "psm_cost.h"
 #include "psm_dev.h"
 
+#ifndef PSM_Q2_ABL
+#define PSM_Q2_ABL 0      // ablation experiments (invalid results): 1 no model solve, 2 no guidance loads in A2
+#endif
+#ifndef PSM_Q2_TIMING
+#define PSM_Q2_TIMING 0   // 1: every wave accumulates its cycles between barriers (work) and inside them (wait) per role
+#endif
+
 namespace psm {
+
+#if PSM_Q2_TIMING
+__device__ unsigned long long g_q2_dbg[8];   // work cycles of roles A1, A2, B1, B2, then their barrier-wait cycles
+#define Q_SYNC()                                                                 \
+    {                                                                            \
+        const unsigned long long a_ = __builtin_readcyclecounter();              \
+        __syncthreads();                                                         \
+        const unsigned long long b_ = __builtin_readcyclecounter();              \
+        q_work += a_ - q_mark; q_wait += b_ - a_; q_mark = b_;                   \
+    }
+#else
+#define Q_SYNC() __syncthreads()
+#endif
 
 namespace {
 
@@ -125,6 +145,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     const size_t HW = (size_t)H * W;
     const unsigned plane16 = (unsigned)HW * 16u;
 
+#if PSM_Q2_TIMING
+    unsigned long long q_work = 0, q_wait = 0, q_mark = __builtin_readcyclecounter();
+#endif
     for (int ds = 0; ds < DC; ++ds) {                 // the slices of this chunk, ascending d
     const int d = ch * DC + ds;
     if (d >= Dloc) break;                             // uniform over the workgroup
@@ -173,9 +196,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         for (int t = 0; t < nA1; ++t) {
             const int s0 = 4 * t, par = t & 1;
             Q_STEP_A1(0, s0, par) Q_STEP_A1(1, s0 + 1, par) Q_STEP_A1(2, s0 + 2, par) Q_STEP_A1(3, s0 + 3, par)
-            __syncthreads();
+            Q_SYNC();
         }
-        for (int t = nA1; t < T; ++t) __syncthreads();
+        for (int t = nA1; t < T; ++t) Q_SYNC();
 #undef Q_STEP_A1
 #undef Q_ISSUE_A1
     } else if (wave == 1) {
@@ -191,8 +214,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         const int vE = cE * 16 + 4, vO = cO * 16 + 4;   // {I1, I2} of g1 = {I0, I1, I2, GrdX}
         const int vaE = xaE * 16, vaO = xaO * 16;
         QTree2 t2 = {}, t3 = {};
-        float2 gyzE[2], gyzO[2], o4E[2], o4O[2];
-        float4 o2E[2], o2O[2], o3E[2], o3O[2];
+        float2 gyzE[2], gyzO[2], o4E[2] = {}, o4O[2] = {};
+        float4 o2E[2] = {}, o2O[2] = {}, o3E[2] = {}, o3O[2] = {};
 #define Q_ISSUE_A2(SLOT, STEP)                                                          \
     {                                                                                   \
         const int row_ = r101c(mstart - 5 + (STEP), H) * W * 16;                        \
@@ -201,12 +224,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         const int oa_ = ya_ * W;                                                        \
         gyzE[SLOT] = q_load2(rG1, vE, row_);                                            \
         gyzO[SLOT] = q_load2(rG1, vO, row_);                                            \
+        if (!(PSM_Q2_ABL & 2)) {   /* ablation bit 2: no guidance loads (invalid results) */ \
         o2E[SLOT] = q_load4(rG2, vaE, oa_ * 16);                                        \
         o2O[SLOT] = q_load4(rG2, vaO, oa_ * 16);                                        \
         o3E[SLOT] = q_load4(rG3, vaE, oa_ * 16);                                        \
         o3O[SLOT] = q_load4(rG3, vaO, oa_ * 16);                                        \
         o4E[SLOT] = q_load2(rG4, vaE >> 1, oa_ * 8);                                    \
         o4O[SLOT] = q_load2(rG4, vaO >> 1, oa_ * 8);                                    \
+        }                                                                               \
     }
 #define Q_STEP_A2(K, S, PAR, DST)                                                                   \
     {                                                                                               \
@@ -218,8 +243,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         q_hsum8x2(__fmul_rn(gyzE[K & 1].y, p_.x), __fmul_rn(gyzO[K & 1].y, p_.y), i2, h3E, h3O);    \
         const float m1E = box_out(vstep<K>(t2.e, h2E)), m1O = box_out(vstep<K>(t2.o, h2O));         \
         const float m2E = box_out(vstep<K>(t3.e, h3E)), m2O = box_out(vstep<K>(t3.o, h3O));         \
-        const float4 rE = solve_ab(mp_.x, m0_.x, m1E, m2E, o2E[K & 1], o3E[K & 1], o4E[K & 1]);     \
-        const float4 rO = solve_ab(mp_.y, m0_.y, m1O, m2O, o2O[K & 1], o3O[K & 1], o4O[K & 1]);     \
+        float4 rE, rO;                                                                              \
+        if (PSM_Q2_ABL & 1) { rE = make_float4(mp_.x, m0_.x, m1E, m2E); rO = make_float4(mp_.y, m0_.y, m1O, m2O); } /* ablation: no solve (invalid results) */ \
+        else {                                                                                      \
+            rE = solve_ab(mp_.x, m0_.x, m1E, m2E, o2E[K & 1], o3E[K & 1], o4E[K & 1]);               \
+            rO = solve_ab(mp_.y, m0_.y, m1O, m2O, o2O[K & 1], o3O[K & 1], o4O[K & 1]);               \
+        }                                                                                           \
         if ((DST) != nullptr) {                                                                     \
             float *d_ = (DST) + K * 4 * Q_MPAD;                                                     \
             if (mvE) { d_[0] = rE.x; d_[Q_MPAD] = rE.y; d_[2 * Q_MPAD] = rE.z; d_[3 * Q_MPAD] = rE.w; } \
@@ -227,7 +256,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         }                                                                                           \
         __builtin_amdgcn_sched_barrier(0);                                                          \
     }
-        __syncthreads();                               // interval 0
+        Q_SYNC();                               // interval 0
         Q_ISSUE_A2(0, 0) __builtin_amdgcn_sched_barrier(0);
         float2 ap_, amp_, am0_;                        // A1's hand-over of the next step (read one step ahead)
 #define Q_PRE_A2(PAR) { ap_ = abuf[PAR][0][0][lane]; amp_ = abuf[PAR][0][1][lane]; am0_ = abuf[PAR][0][2][lane]; }
@@ -235,19 +264,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
             float *const none = nullptr;
             Q_PRE_A2(0)
             Q_STEP_A2(0, 0, 0, none) Q_STEP_A2(1, 1, 0, none) Q_STEP_A2(2, 2, 0, none) Q_STEP_A2(3, 3, 0, none)
-            __syncthreads();
+            Q_SYNC();
             Q_PRE_A2(1)
             Q_STEP_A2(0, 4, 1, none) Q_STEP_A2(1, 5, 1, none) Q_STEP_A2(2, 6, 1, none) Q_STEP_A2(3, 7, 1, none)
-            __syncthreads();
+            Q_SYNC();
         }
         for (int b = 0; b < nbA; ++b) {                // interval 3 + b: ring batch b
             const int s0 = 8 + 4 * b, par = b & 1;     // A1 wrote these steps in interval 2 + b
             Q_PRE_A2(par)
             float *dst = &ring[b & (Q_RING - 1)][0][0][2 * lane];
             Q_STEP_A2(0, s0, par, dst) Q_STEP_A2(1, s0 + 1, par, dst) Q_STEP_A2(2, s0 + 2, par, dst) Q_STEP_A2(3, s0 + 3, par, dst)
-            __syncthreads();
+            Q_SYNC();
         }
-        for (int t = 3 + nbA; t < T; ++t) __syncthreads();
+        for (int t = 3 + nbA; t < T; ++t) Q_SYNC();
 #undef Q_STEP_A2
 #undef Q_PRE_A2
 #undef Q_ISSUE_A2
@@ -278,7 +307,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     }
         if (!is_b2) {
             // ---- B1 ----
-            for (int t = 0; t < 5; ++t) __syncthreads();
+            for (int t = 0; t < 5; ++t) Q_SYNC();
             for (int c = 0; c < nbB; ++c) {            // interval 5 + c
                 const int j0 = 4 * c, par = c & 1;
 #define Q_STEP_B1(K)                                                                                \
@@ -294,9 +323,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     }
                 Q_STEP_B1(0) Q_STEP_B1(1) Q_STEP_B1(2) Q_STEP_B1(3)
 #undef Q_STEP_B1
-                __syncthreads();
+                Q_SYNC();
             }
-            __syncthreads();                           // interval 5 + nbB
+            Q_SYNC();                           // interval 5 + nbB
         } else {
             // ---- B2 ----
             const int xoE = xg + 2 * lane, xoO = xoE + 1;          // output columns of this lane
@@ -364,7 +393,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
             __builtin_amdgcn_raw_buffer_store_b64(dd_, rKd, lane * 8, (C) * 512, 0);                \
         }                                                                                           \
     }
-            for (int t = 0; t < 5; ++t) __syncthreads();
+            for (int t = 0; t < 5; ++t) Q_SYNC();
             for (int c = 0; c < nbB; ++c) {            // interval 5 + c: recombine feed batch c-1, filter feed batch c
                 const int j0 = 4 * c;
                 if (c > 0) {
@@ -388,10 +417,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     }
                 Q_STEP_B2(0) Q_STEP_B2(1) Q_STEP_B2(2) Q_STEP_B2(3)
 #undef Q_STEP_B2
-                __syncthreads();
+                Q_SYNC();
             }
             Q_SELECT_B2(nbB - 1)                       // interval 5 + nbB
-            __syncthreads();
+            Q_SYNC();
             __builtin_amdgcn_s_waitcnt(0);             // the chunk plane of this slice is in the L2 before the next slice reads it
 #undef Q_SELECT_B2
 #undef Q_ISSUE_B2
@@ -399,6 +428,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
 #undef Q_READ_B
     }
     }   // slices of the chunk
+#if PSM_Q2_TIMING
+    if (lane == 0) {
+        atomicAdd(&g_q2_dbg[wave], q_work);
+        atomicAdd(&g_q2_dbg[4 + wave], q_wait);
+    }
+#endif
 }
 
 // chunk planes of k_cvf_q2 -> packed WTA key and / or final map per pixel; one thread per record (pair, batch, lane) =
@@ -448,6 +483,22 @@ __global__ __launch_bounds__(256) void k_chunk_min2(const float4 *__restrict__ k
         }
     }
 }
+
+}  // namespace psm
+
+// debug: read and clear the per-role cycle counters of k_cvf_q2 (all zero unless built with -DPSM_Q2_TIMING=1)
+extern "C" int psm_debug_q2_cycles(unsigned long long *out8)
+{
+    for (int i = 0; i < 8; ++i) out8[i] = 0;
+#if PSM_Q2_TIMING
+    if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(psm::g_q2_dbg), 8 * sizeof(unsigned long long)) != hipSuccess) return 1;
+    unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(psm::g_q2_dbg), z, sizeof z) != hipSuccess) return 1;
+#endif
+    return 0;
+}
+
+namespace psm {
 
 PcPlan q2_plan(int W, int H, int Dloc, int seg_rows_opt)
 {

@@ -174,6 +174,10 @@ class DispEst:
         self._ck(self._lib.psm_disp_select_partial_side(self._h, int(side), C.c_void_p(dev_keys_ptr or 0)),
                  "DispSelect_partial_side")
 
+    def set_key_buffer(self, dev_keys_ptr: int | None):
+        """The packed minima of the following frames go straight into this device buffer (2*H*W int64); None: own buffer."""
+        self._ck(self._lib.psm_set_key_buffer(self._h, C.c_void_p(dev_keys_ptr or 0)), "set_key_buffer")
+
     def partial_keys(self):
         p, n = C.c_void_p(), C.c_size_t()
         self._ck(self._lib.psm_partial_keys(self._h, C.byref(p), C.byref(n)), "partial_keys")
