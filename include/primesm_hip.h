@@ -65,7 +65,11 @@ enum {
                                    itself and the filtered volumes stay virtual - packed per-pixel minima - until
                                    something other than psm_disp_select* reads them); 16384 = two-columns-per-lane,
                                    channel-split variant of that kernel (k_cvf_q2); 65536 = psm_cost_filter launches
-                                   every kernel once per volume (default: both volumes per launch).
+                                   every kernel once per volume (default: both volumes per launch); 262144 = the
+                                   select-mode kernel updates one shared plane of packed keys per volume by 64-bit
+                                   atomicMin (default: private minima planes + a reduction kernel); 524288 = resident
+                                   workgroups take the slices of their (column group, segment) pair dynamically from a
+                                   device counter (default: static chunks of slices per workgroup).
                                    No flag changes any result. */
 };
 

@@ -69,6 +69,8 @@ struct psm_ctx {
     bool have_guid[2] = {false, false};   // g2..g4 of a side are those of the current image pair
     void *gf_scratch = nullptr;         // chunk planes of the select-mode kernel (PcPlan::scratch_bytes)
     size_t gf_scratch_bytes = 0;
+    int *gf_cnt = nullptr;              // slice counters of the dynamic select form (one per side and pair)
+    size_t gf_cnt_n = 0;
     float4 *fgf_mab[2] = {nullptr, nullptr};
     void *fgf = nullptr;                // psm_cost_filter_fgf scratch (small planes), fgf_bytes long
     size_t fgf_bytes = 0;
@@ -194,6 +196,7 @@ void free_all(psm_ctx *c)
     (void)hipFree(c->valid);
     (void)hipFree(c->wm);
     (void)hipFree(c->gf_scratch);
+    (void)hipFree(c->gf_cnt);
     (void)hipFree(c->fgf);
     for (auto &t : c->timers)
         for (auto &p : t.pending) {
@@ -242,6 +245,18 @@ int ensure_gf_scratch(psm_ctx *c, size_t bytes)
     c->gf_scratch_bytes = 0;
     PSM_HIP(c, hipMalloc(&c->gf_scratch, bytes));
     c->gf_scratch_bytes = bytes;
+    return 0;
+}
+
+int ensure_gf_cnt(psm_ctx *c, size_t n)
+{
+    if (c->gf_cnt && c->gf_cnt_n >= n) return 0;
+    PSM_HIP(c, hipStreamSynchronize(c->stream));
+    (void)hipFree(c->gf_cnt);
+    c->gf_cnt = nullptr;
+    c->gf_cnt_n = 0;
+    PSM_HIP(c, hipMalloc((void **)&c->gf_cnt, n * sizeof(int)));
+    c->gf_cnt_n = n;
     return 0;
 }
 
@@ -575,19 +590,31 @@ static int filter_side(psm_ctx *c, int side, bool stage_b)
         // flag 16384: the two-columns-per-lane, channel-split form (k_cvf_q2, psm_q2.hip: 14 % fewer VALU instructions,
         // but its four-stage workgroups keep the SIMDs less busy - measured slower, kept as a tested variant)
         const bool q2 = lazy && c->dtype == PSM_F32 && (c->march.flags & 16384);
-        const PcPlan pl = q2 ? q2_plan(W, H, c->Dloc, c->march.seg_rows) : pc_plan(W, H, c->Dloc, c->march.seg_rows, 1);
+        if (!q2 && (c->march.flags & 262144)) {
+            // flag 262144: shared key plane + atomicMin instead of minima planes (measured slower: ~100 atomics per pixel)
+            Prof p(c, PSM_K_CVF_F);
+            launch_cvf_select_keys(c->stream, c->march, lazy ? nullptr : (const float *)c->vol[side], c->g[side], W, H, c->Dloc, c->g[1 - side].g1,
+                                   c->d0, lazy ? 1 + side : 0, c->keys_cur + side * (size_t)W * H, sel8 ? c->p4[side] : nullptr,
+                                   sel8 ? c->p4[1 - side] : nullptr);
+            c->gf_virtual[side] = true;
+            return check_launch(c, "cvf (fused, select mode, shared keys)");
+        }
+        const bool dynsel = !q2 && (c->march.flags & 524288);    // flag 524288: dynamic slice distribution (measured slower)
+        const PcPlan pl = q2 ? q2_plan(W, H, c->Dloc, c->march.seg_rows) : pc_plan(W, H, c->Dloc, c->march.seg_rows, dynsel ? 5 : 1);
         if (ensure_gf_scratch(c, pl.scratch_bytes())) return 1;
+        if (dynsel && ensure_gf_cnt(c, 2 * (size_t)pl.ngroups * pl.nsegs)) return 1;
         const size_t HW = (size_t)W * H;
         {
             Prof p(c, PSM_K_CVF_F);
             if (q2) launch_cvf_q2(c->stream, c->march, c->g[side], W, H, c->Dloc, c->g[1 - side].g1, c->d0, 1 + side, c->gf_scratch);
             else launch_cvf_select(c->stream, c->march, lazy ? nullptr : (const float *)c->vol[side], c->g[side], W, H, c->Dloc, c->g[1 - side].g1,
-                                   c->d0, lazy ? 1 + side : 0, c->gf_scratch, sel8 ? c->p4[side] : nullptr, sel8 ? c->p4[1 - side] : nullptr);
+                                   c->d0, lazy ? 1 + side : 0, c->gf_scratch, dynsel ? c->gf_cnt : nullptr, sel8 ? c->p4[side] : nullptr,
+                                   sel8 ? c->p4[1 - side] : nullptr);
         }
         {
             Prof p(c, PSM_K_WTA);
             if (q2) launch_chunk_min2(c->stream, c->march, W, H, c->Dloc, c->gf_scratch, c->keys_cur + side * HW, nullptr);
-            else launch_chunk_min(c->stream, c->march, W, H, c->Dloc, c->gf_scratch, c->keys_cur + side * HW, nullptr);
+            else launch_chunk_min(c->stream, c->march, W, H, c->Dloc, c->gf_scratch, c->keys_cur + side * HW, nullptr, dynsel);
         }
         c->gf_virtual[side] = true;
         return check_launch(c, "cvf (fused, select mode)");
@@ -704,15 +731,24 @@ static int filter_both(psm_ctx *c)
         launch_guidance(c->stream, c->g[0], nullptr, c->W, c->H, 0, &c->g[1]);
         c->have_guid[0] = c->have_guid[1] = true;
     }
-    const PcPlan pl = pc_plan(c->W, c->H, c->Dloc, c->march.seg_rows, 1);
+    if (c->march.flags & 262144) {
+        Prof p(c, PSM_K_CVF_F);
+        launch_cvf_select_keys2(c->stream, c->march, c->g, c->W, c->H, c->Dloc, c->d0, c->keys_cur, c->dtype == PSM_U8 ? c->p4 : nullptr);
+        c->gf_virtual[0] = c->gf_virtual[1] = true;
+        return check_launch(c, "cvf (fused, select mode, shared keys, both volumes)");
+    }
+    const bool dynsel = (c->march.flags & 524288) != 0;
+    const PcPlan pl = pc_plan(c->W, c->H, c->Dloc, c->march.seg_rows, dynsel ? 6 : 2);
     if (ensure_gf_scratch(c, 2 * pl.scratch_bytes())) return 1;
+    if (dynsel && ensure_gf_cnt(c, 2 * (size_t)pl.ngroups * pl.nsegs)) return 1;
     {
         Prof p(c, PSM_K_CVF_F);
-        launch_cvf_select2(c->stream, c->march, c->g, c->W, c->H, c->Dloc, c->d0, c->gf_scratch, c->dtype == PSM_U8 ? c->p4 : nullptr);
+        launch_cvf_select2(c->stream, c->march, c->g, c->W, c->H, c->Dloc, c->d0, c->gf_scratch, dynsel ? c->gf_cnt : nullptr,
+                           c->dtype == PSM_U8 ? c->p4 : nullptr);
     }
     {
         Prof p(c, PSM_K_WTA);
-        launch_chunk_min2sides(c->stream, c->march, c->W, c->H, c->Dloc, c->gf_scratch, c->keys_cur, nullptr);
+        launch_chunk_min2sides(c->stream, c->march, c->W, c->H, c->Dloc, c->gf_scratch, c->keys_cur, nullptr, dynsel);
     }
     c->gf_virtual[0] = c->gf_virtual[1] = true;
     return check_launch(c, "cvf (fused, select mode, both volumes)");

@@ -48,6 +48,7 @@ void launch_cvf_fused(hipStream_t s, March m, const float *vin, float *vout, Gui
 // scratch: pc_plan(...).scratch_bytes() bytes (chunk planes).
 struct PcPlan {
     int ngroups, nsegs, seg_rows, DC, nchunks, nbmax;
+    int NW;                                                      // dynamic form: workgroups (= planes) per pair, else 0
     size_t rec_per_chunk;                                        // records per chunk plane
     int rec_bytes;                                               // bytes per record (costs + disparities)
     size_t scratch_bytes() const { return rec_per_chunk * (size_t)nchunks * rec_bytes; }
@@ -55,13 +56,20 @@ struct PcPlan {
 PcPlan pc_plan(int W, int rows, int Dloc, int seg_rows_opt, int mode);
 PcPlan pc_plan_cols(int W, int rows, int Dloc, int seg_rows_opt, int mode, int cols);
 void launch_cvf_select(hipStream_t s, March m, const float *vin, Guidance g, int W, int H, int Dloc, const float4 *g1_other,
-                       int d_begin, int cvc_mode, void *scratch, const uint8_t *p4_own = nullptr, const uint8_t *p4_other = nullptr);
-void launch_chunk_min(hipStream_t s, March m, int W, int H, int Dloc, void *scratch, long long *keys, uint8_t *map);
+                       int d_begin, int cvc_mode, void *scratch, int *cnt = nullptr, const uint8_t *p4_own = nullptr,
+                       const uint8_t *p4_other = nullptr);
+void launch_chunk_min(hipStream_t s, March m, int W, int H, int Dloc, void *scratch, long long *keys, uint8_t *map, int dynamic = 0);
+// Select mode with a shared key plane per volume (default): the packed minima over the local slices go straight to keys
+// (H*W per volume; both-volumes form: [2][H][W]) by 64-bit atomicMin - no chunk planes, no reduction kernel.
+void launch_cvf_select_keys(hipStream_t s, March m, const float *vin, Guidance g, int W, int H, int Dloc, const float4 *g1_other,
+                            int d_begin, int cvc_mode, long long *keys, const uint8_t *p4_own = nullptr, const uint8_t *p4_other = nullptr);
+void launch_cvf_select_keys2(hipStream_t s, March m, const Guidance *g, int W, int H, int Dloc, int d_begin, long long *keys,
+                             const uint8_t *const *p4 = nullptr);
 // both volumes per launch (costs on the fly): g[0] / g[1] = guidance of the left / right image; scratch: 2 x scratch_bytes();
 // keys / map: [2][H][W]
-void launch_cvf_select2(hipStream_t s, March m, const Guidance *g, int W, int H, int Dloc, int d_begin, void *scratch,
+void launch_cvf_select2(hipStream_t s, March m, const Guidance *g, int W, int H, int Dloc, int d_begin, void *scratch, int *cnt = nullptr,
                         const uint8_t *const *p4 = nullptr);
-void launch_chunk_min2sides(hipStream_t s, March m, int W, int H, int Dloc, void *scratch, long long *keys, uint8_t *map);
+void launch_chunk_min2sides(hipStream_t s, March m, int W, int H, int Dloc, void *scratch, long long *keys, uint8_t *map, int dynamic = 0);
 // Select mode with two columns per lane and the channels split over the waves (psm_q2.hip): the default product kernel
 // when the costs are built on the fly (cvc_mode 1 / 2).  scratch: q2_plan(...).scratch_bytes() bytes.
 PcPlan q2_plan(int W, int H, int Dloc, int seg_rows_opt);

@@ -26,6 +26,11 @@
 //   step improves some lane, and unaligned 4-byte-per-lane stores are the slowest thing the memory path can do.)  Per voxel this replaces a 4-byte HBM store + a 4-byte HBM read (k_wta) by a cached 4-byte
 //   read and a rare store, and - nothing being stored per row - the 128-byte alignment rule of MODE 0 no longer binds:
 //   2 x 57 model columns feed 54 + 53 output columns (84-89 % useful lanes instead of 75-81 %).
+// MODE 2 ("select, shared keys"): as MODE 1, but without chunk planes: one plane of packed WTA keys per volume (8 bytes per
+//   pixel, image layout - the final result), initialised to key(+inf, 0).  A consumer lane loads the current key of its
+//   pixel one batch ahead (a stale value only costs a redundant atomic), compares, and only where q beats it issues a 64-bit
+//   atomicMin - a handful per pixel over all 256 slices instead of a record per slice.  One slice per workgroup (the finest
+//   work granularity, shortest tail), no reduction kernel afterwards.
 // d = 0 is never a candidate, NaN never wins, the lowest d wins ties (src/DispSel.cpp:91-105): slices are visited in
 // ascending d with strict '<' inside a chunk, and k_chunk_min takes the signed minimum of pack_key_f32 across chunks.
 #include "psm_kernels.h"
@@ -66,6 +71,17 @@ constexpr int PC_RING = 4;   // batches of four model rows kept in LDS
 template <int MODE> struct PcLayout;
 template <> struct PcLayout<0> { static constexpr int NA = 2, NB = 2, OUT_A = 52, OUT_B = 48, COLS = 96; };
 template <> struct PcLayout<1> { static constexpr int NA = 2, NB = 2, OUT_A = 57, OUT_B = 54, COLS = 107; };
+template <> struct PcLayout<2> : PcLayout<1> {};
+#ifndef PSM_K_LD_AUX
+#define PSM_K_LD_AUX 0       // cache policy of MODE 1's record loads.  A record is only ever read by the lane that wrote it
+#endif                       // (one slice earlier), and a thread always observes its own stores: plain cached loads are
+                             // coherent here.  (16 = sc1 bypasses the L2 as well: measured 25 % slower kernel.)
+#ifndef PSM_KEY_NOATOMIC
+#define PSM_KEY_NOATOMIC 0   // experiment (invalid results): skip the atomics
+#endif
+#ifndef PSM_KEY_LD_AUX
+#define PSM_KEY_LD_AUX 16    // cache policy of MODE 2's key loads: 16 = sc1 (agent scope: never from this CU's L1)
+#endif
 
 typedef unsigned pc_u2 __attribute__((ext_vector_type(2)));
 typedef unsigned pc_u4 __attribute__((ext_vector_type(4)));
@@ -102,6 +118,15 @@ struct PcSide {
     unsigned *kdisp;
 };
 
+// MODE 1, dynamic form: NW workgroups per (column group, segment) pair, all resident at once, take the pair's slices one
+// after the other from a device counter (ascending d) and keep their running minima in ONE plane each - NW planes per
+// volume instead of Dloc / DC, all workgroups finish within one slice of each other (no tail), and stores to the plane
+// become rare (a lane rewrites its record only when one of its four rows improved).  cnt == NULL: static chunks of DC.
+struct PcDyn {
+    int *cnt;      // one zeroed counter per (side, pair)
+    int NW;
+};
+
 // CVC = 0: the cost slice is read from `vin`.  CVC = 1 (left volume) / 2 (right volume): the cost volume is never
 // materialised - the producer waves evaluate myCostGrd (src/CVC.cpp:18-39) for their input column on the fly from the
 // two g1 planes (`G1` = this side's image, `Gother` = the other one), exactly as k_cvc does.
@@ -115,7 +140,7 @@ __global__ __launch_bounds__(64 * (PcLayout<MODE>::NA + PcLayout<MODE>::NB)) PSM
     const float *__restrict__ vin, float *__restrict__ vout, const float4 *__restrict__ G1a, const float4 *__restrict__ G2a,
     const float4 *__restrict__ G3a, const float2 *__restrict__ G4a, int W, int H, int Dloc, int ngroups, int nsegs, int seg_rows,
     int ybeg, int yend, const float4 *__restrict__ Gothera, int d_begin, int DC, float *__restrict__ kcosta, unsigned *__restrict__ kdispa, int nbmax,
-    PcSide side1)
+    PcSide side1, PcDyn dyn)
 {
     const bool right = CVC == 2 || (CVC == 3 && blockIdx.y == 1);      // buildCV_right arithmetic (uniform)
     const bool s1 = CVC == 3 && blockIdx.y == 1;
@@ -137,7 +162,8 @@ __global__ __launch_bounds__(64 * (PcLayout<MODE>::NA + PcLayout<MODE>::NB)) PSM
     // (block b -> XCD b%8): every XCD owns a contiguous range of (group, segment) pairs and walks the
     // chunks of one pair back to back, so the guidance rows its resident workgroups are reading (few
     // pairs, neighbouring rows, many slices) fit its 4 MB L2 instead of coming from the MALL.  Speed only.
-    const int nchunks = (Dloc + DC - 1) / DC;
+    const bool dynamic = MODE == 1 && dyn.cnt != nullptr;
+    const int nchunks = dynamic ? dyn.NW : (Dloc + DC - 1) / DC;
     int id = blockIdx.x;
     const int npairs = ngroups * nsegs;               // (column group, segment) pairs
     // work items (pair, chunk), pair-major; XCD x takes the x-th eighth of them: a contiguous range of pairs whose chunks
@@ -169,10 +195,20 @@ __global__ __launch_bounds__(64 * (PcLayout<MODE>::NA + PcLayout<MODE>::NB)) PSM
 #if PSM_PC_TIMING
     unsigned long long q_work = 0, q_wait = 0, q_mark = __builtin_readcyclecounter();
 #endif
-    const int nds = MODE == 0 ? 1 : DC;               // MODE 0 always runs with DC == 1 (one slice per workgroup)
-    for (int ds = 0; ds < nds; ++ds) {                // the slices of this chunk, ascending d
-    const int d = ch * DC + ds;
-    if (MODE != 0 && d >= Dloc) break;                // uniform over the workgroup
+    const int nds = MODE == 1 ? DC : 1;               // MODE 0 / 2 always run with DC == 1 (one slice per workgroup)
+    __shared__ int s_next;
+    bool first = true;                                // no slice processed yet: the plane holds nothing
+    for (int ds = 0; ; ++ds) {                        // the slices of this chunk / this workgroup's share of the pair, ascending d
+    int d;
+    if (MODE == 1 && dynamic) {
+        if (threadIdx.x == 0) s_next = atomicAdd(dyn.cnt + (s1 ? npairs : 0) + pair, 1);
+        __syncthreads();                              // (the next write of s_next is many barriers away)
+        d = __builtin_amdgcn_readfirstlane(s_next);
+    } else {
+        if (ds >= nds) break;
+        d = ch * DC + ds;
+    }
+    if (MODE == 1 && d >= Dloc) break;                // uniform over the workgroup
     if (is_a) {
         // ---------------- producer: stage A ----------------
         // step s reads input row mstart-5+s; from step 8 on it yields model row mstart+(s-8)
@@ -286,12 +322,26 @@ __global__ __launch_bounds__(64 * (PcLayout<MODE>::NA + PcLayout<MODE>::NB)) PSM
         const __amdgpu_buffer_rsrc_t rKd = pc_rsrc(MODE == 1 ? (const void *)(kdisp + krec) : (const void *)G1, (unsigned)nbmax * 256u);
 #define PSM_K_LOAD(C)                                                                              \
     {                                                                                              \
-        const pc_u4 v_ = __builtin_amdgcn_raw_buffer_load_b128(rKc, lane * 16, (C) * 1024, 16);    \
+        const pc_u4 v_ = __builtin_amdgcn_raw_buffer_load_b128(rKc, lane * 16, (C) * 1024, PSM_K_LD_AUX); \
         kq = make_float4(__uint_as_float(v_.x), __uint_as_float(v_.y), __uint_as_float(v_.z), __uint_as_float(v_.w)); \
-        kd4 = __builtin_amdgcn_raw_buffer_load_b32(rKd, lane * 4, (C) * 256, 16);                  \
+        kd4 = __builtin_amdgcn_raw_buffer_load_b32(rKd, lane * 4, (C) * 256, PSM_K_LD_AUX);        \
     }
         float4 kq = make_float4(__builtin_inff(), __builtin_inff(), __builtin_inff(), __builtin_inff());   // running minima of the current batch
         unsigned kd4 = 0;                                                                                  // and their disparities
+        // MODE 2: the volume's key plane (handed over in the kcost argument), current keys of this lane's pixel one batch ahead
+        long long *const keyp = reinterpret_cast<long long *>(kcost);
+        const __amdgpu_buffer_rsrc_t rKy = pc_rsrc(MODE == 2 ? (const void *)keyp : (const void *)G1, (unsigned)HW * 8u);
+        long long kcur[4] = {0, 0, 0, 0};
+        float acc_dbg = 0.f; (void)acc_dbg;
+#define PSM_KEY_LOAD(C)                                                                            \
+    {                                                                                              \
+        _Pragma("unroll") for (int k_ = 0; k_ < 4; ++k_) {                                         \
+            int yk_ = y0 + 4 * (C) + k_ - 7;                                                       \
+            yk_ = yk_ < 0 ? 0 : (yk_ > H - 1 ? H - 1 : yk_);                                       \
+            const pc_u2 v_ = __builtin_amdgcn_raw_buffer_load_b64(rKy, xbc * 8, yk_ * W * 8, PSM_KEY_LD_AUX); \
+            kcur[k_] = (long long)(((unsigned long long)v_.y << 32) | v_.x);                       \
+        }                                                                                          \
+    }
         const __amdgpu_buffer_rsrc_t rG1 = pc_rsrc(G1, (unsigned)HW * 16u);
         const int vxb = xbc * 16;
         const int dg = d_begin + d;
@@ -339,10 +389,11 @@ __global__ __launch_bounds__(64 * (PcLayout<MODE>::NA + PcLayout<MODE>::NB)) PSM
         };
         PSM_ISSUE_PB(0, 0) PSM_ISSUE_PB(1, 1) PSM_ISSUE_PB(2, 2) PSM_ISSUE_PB(3, 3)
         if constexpr (MODE == 1) {
-            if (ds > 0) {                              // records of batch 0, written by this wave one slice earlier (L1 bypassed)
+            if (!first) {                              // records of batch 0, written by this wave one slice earlier (L1 bypassed)
                 PSM_K_LOAD(0)
             }
         }
+        if constexpr (MODE == 2) PSM_KEY_LOAD(0)
         PC_SYNC();                               // iteration 0
         PC_SYNC();                               // iteration 1
         for (int b = 2; b <= nbB + 1; ++b) {           // iteration b: consume feed batch c = b-2
@@ -372,6 +423,29 @@ __global__ __launch_bounds__(64 * (PcLayout<MODE>::NA + PcLayout<MODE>::NB)) PSM
 #pragma unroll
                     for (int k = 0; k < 4; ++k)
                         if (lane < bwidth) qbuf[c & 1][k][wb * PC_OUT_B + lane] = qv[k];
+                } else if constexpr (MODE == 2) {
+                    // DispSel::CVSelect (src/DispSel.cpp:96-104) against the volume's shared key plane: strict '<' / lowest d on
+                    // ties = signed minimum of pack_key_f32; d = 0 never a candidate; NaN never wins
+                    if (U8) {
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            const float r_ = rintf(__fmul_rn(qv[k], 255.0f));
+                            qv[k] = !(r_ > 0.0f) ? 0.0f : (r_ > 255.0f ? 255.0f : r_);
+                        }
+                    }
+#if PSM_KEY_NOATOMIC == 2   // experiment (invalid results): compute-only - the q values are summed into a register, one store per workgroup
+                    acc_dbg += (qv[0] + qv[1]) + (qv[2] + qv[3]);
+                    if (c == nbB - 1 && lane_out) keyp[(size_t)(y0 + lane % 4) * W + xb] = (long long)__float_as_int(acc_dbg);
+#else
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const int j_ = j0 + k, yo_ = y0 + j_ - 7;
+                        const long long key_ = pack_key_f32(qv[k], dg);
+                        if (j_ >= 7 && yo_ < y1 && lane_out && dg != 0 && qv[k] == qv[k] && key_ < kcur[k] && !PSM_KEY_NOATOMIC)
+                            (void)__hip_atomic_fetch_min(keyp + (size_t)yo_ * W + xb, key_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                    if (c + 1 < nbB) PSM_KEY_LOAD(c + 1)               // keys of the next batch's rows
+#endif
                 } else {
                     // DispSel::CVSelect (src/DispSel.cpp:96-104) over the slices of this chunk: strict '<', d = 0 never a
                     // candidate, NaN never wins.  Rows outside [y0, y1) and halo lanes keep (+inf, 0).
@@ -393,12 +467,16 @@ __global__ __launch_bounds__(64 * (PcLayout<MODE>::NA + PcLayout<MODE>::NB)) PSM
                         dn = better_ ? ((dn & ~(0xffu << (8 * k))) | ((unsigned)dg << (8 * k))) : dn;
                         any |= better_;
                     }
-                    if (ds == 0 || __builtin_amdgcn_ballot_w64(any) != 0) {
+#ifndef PSM_PC_MASKED_STORES
+#define PSM_PC_MASKED_STORES 1
+#endif
+                    // (per lane: only lanes with an improved row rewrite their record; 0: the whole wave whenever any lane improved)
+                    if (first || (PSM_PC_MASKED_STORES ? any : __builtin_amdgcn_ballot_w64(any) != 0)) {
                         const pc_u4 kv = {__float_as_uint(kn[0]), __float_as_uint(kn[1]), __float_as_uint(kn[2]), __float_as_uint(kn[3])};
                         __builtin_amdgcn_raw_buffer_store_b128(kv, rKc, lane * 16, c * 1024, 0);
                         __builtin_amdgcn_raw_buffer_store_b32(dn, rKd, lane * 4, c * 256, 0);
                     }
-                    if (ds > 0 && c + 1 < nbB) PSM_K_LOAD(c + 1)       // records of the next batch
+                    if (!first && c + 1 < nbB) PSM_K_LOAD(c + 1)       // records of the next batch
                 }
             }
             PC_SYNC();
@@ -406,10 +484,26 @@ __global__ __launch_bounds__(64 * (PcLayout<MODE>::NA + PcLayout<MODE>::NB)) PSM
         store_batch(nbB - 1);                          // iteration nbB+2
         PC_SYNC();
 #undef PSM_ISSUE_PB
+#undef PSM_KEY_LOAD
 #undef PSM_K_LOAD
     }
     if (MODE == 1) __builtin_amdgcn_s_waitcnt(0);      // the chunk planes of this slice are in the L2 before the next slice reads them
+    first = false;
     }   // slices of the chunk
+    if constexpr (MODE == 1) {
+        if (dynamic && first && !is_a) {
+            // this workgroup came too late for any slice: its plane must still read "no candidate"
+            const int wb = wave - PC_NA;
+            const size_t krec = ((size_t)(ch * npairs + pair) * PC_NB + wb) * nbmax * 64;
+            float4 *kc = reinterpret_cast<float4 *>(kcost) + krec;
+            unsigned *kd = kdisp + krec;
+            const float inf = __builtin_inff();
+            for (int c = 0; c < nbB; ++c) {
+                kc[c * 64 + lane] = make_float4(inf, inf, inf, inf);
+                kd[c * 64 + lane] = 0u;
+            }
+        }
+    }
 #if PSM_PC_TIMING
     if (lane == 0 && MODE == 1) {
         atomicAdd(&g_pc_dbg[wave], q_work);
@@ -487,6 +581,13 @@ extern "C" int psm_debug_pc_cycles(unsigned long long *out8)
 
 namespace psm {
 
+// key plane(s) <- key(+inf, 0): the "no candidate yet" value of MODE 2
+__global__ __launch_bounds__(256) void k_fill_keys(long long *__restrict__ keys, size_t n)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) keys[i] = pack_key_f32(__builtin_inff(), 0);
+}
+
 // Segment count k (and, for MODE 1, slices per chunk DC): every segment re-walks 14 halo rows, and the launch runs in
 // rounds of resident workgroups - per XCD ceil(pairs/8) (column group, segment) pairs x chunks over 32 CUs x 3
 // workgroups.  Cost model, fitted to measurements at 1080p (DC = 1, 2, 4, 8, 16: 4.39, 4.41, 4.46, 4.71, 4.99 ms
@@ -494,11 +595,44 @@ namespace psm {
 // is what makes long-running workgroups (large DC) expensive - plus two row-steps per chunk plane for the reduction.
 PcPlan pc_plan(int W, int H, int Dloc, int seg_rows_opt, int mode)
 {
-    return pc_plan_cols(W, H, Dloc, seg_rows_opt, mode, mode == 1 ? PcLayout<1>::COLS : PcLayout<0>::COLS);
+    return pc_plan_cols(W, H, Dloc, seg_rows_opt, mode, mode != 0 ? PcLayout<1>::COLS : PcLayout<0>::COLS);
 }
 
-PcPlan pc_plan_cols(int W, int H, int Dloc, int seg_rows_opt, int mode, int cols)
-{
+PcPlan pc_plan_cols(int W, int H, int Dloc, int seg_rows_opt, int mode_in, int cols)
+{   // mode_in: 0 store; 1 select with chunk planes, 2 the same with both volumes per launch (twice the work items per launch);
+    // 3 select with a shared key plane (one slice per workgroup, no reduction afterwards), 4 the same with both volumes per launch;
+    // 5 select with chunk planes and dynamic slice distribution (NW resident workgroups per pair), 6 the same with both volumes
+    const int mode = (mode_in == 1 || mode_in == 2) ? 1 : 0, sides = (mode_in == 2 || mode_in == 4 || mode_in == 6) ? 2 : 1;
+    if (mode_in == 5 || mode_in == 6) {
+        // all workgroups resident at once (256 CUs x 3): NW = slots / pairs per pair; a workgroup walks ~Dloc / NW slices of
+        // rows / k + 14 rows each.  Pick the k with the smallest makespan.
+        PcPlan pl;
+        pl.ngroups = (W + cols - 1) / cols;
+        const int slots = 768, kmax = H / 64 > 1 ? H / 64 : 1;
+        long best = -1;
+        int bk = 1, bnw = 1;
+        for (int kk = 1; kk <= kmax && kk <= 32; ++kk) {
+            if (seg_rows_opt > 0 && kk != (H + seg_rows_opt - 1) / seg_rows_opt) continue;
+            const int np = sides * pl.ngroups * kk;
+            int nw = slots / np;
+            nw = nw < 1 ? 1 : (nw > Dloc ? Dloc : nw);
+            const char *e = getenv("PSM_PC_NW");
+            if (e && atoi(e) > 0) nw = atoi(e) > Dloc ? Dloc : atoi(e);
+            const long rounds = ((long)np * nw + slots - 1) / slots;
+            const long c = rounds * ((Dloc + nw - 1) / nw) * ((H + kk - 1) / kk + 14);
+            if (best < 0 || c < best) { best = c; bk = kk; bnw = nw; }
+        }
+        pl.seg_rows = seg_rows_opt > 0 ? seg_rows_opt : (H + bk - 1) / bk;
+        if (pl.seg_rows > H) pl.seg_rows = H;
+        pl.nsegs = (H + pl.seg_rows - 1) / pl.seg_rows;
+        pl.DC = 1;
+        pl.NW = bnw;
+        pl.nchunks = bnw;
+        pl.nbmax = (pl.seg_rows + 7 + 3) / 4;
+        pl.rec_per_chunk = (size_t)pl.ngroups * pl.nsegs * PcLayout<1>::NB * pl.nbmax * 64;
+        pl.rec_bytes = 20;
+        return pl;
+    }
     const int rows = H;
     PcPlan pl;
     pl.ngroups = (W + cols - 1) / cols;
@@ -511,9 +645,9 @@ PcPlan pc_plan_cols(int W, int H, int Dloc, int seg_rows_opt, int mode, int cols
     }
     auto cost_of = [&](int dc, int kk) -> long {
         const int nch = (Dloc + dc - 1) / dc;
-        const long per_xcd = ((long)pl.ngroups * kk * nch + 7) / 8;
+        const long per_xcd = ((long)sides * pl.ngroups * kk * nch + 7) / 8;
         const long rounds2 = 2 * ((per_xcd + 95) / 96) + 1;                         // 2 x (rounds + 1/2)
-        return rounds2 * dc * ((rows + kk - 1) / kk + 14) / 2 + (mode == 1 ? 2L * nch : 0);
+        return rounds2 * dc * ((rows + kk - 1) / kk + 14) / 2 + (mode == 1 ? 2L * sides * nch : 0);
     };
     auto allowed = [&](int dc, int kk) { return (dc == dcs[0] || dc <= Dloc) && (seg_rows_opt <= 0 || kk == (rows + seg_rows_opt - 1) / seg_rows_opt); };
     long best = -1;
@@ -528,6 +662,7 @@ PcPlan pc_plan_cols(int W, int H, int Dloc, int seg_rows_opt, int mode, int cols
     if (pl.seg_rows > rows) pl.seg_rows = rows;
     pl.nsegs = (rows + pl.seg_rows - 1) / pl.seg_rows;
     pl.DC = bdc;
+    pl.NW = 0;
     pl.nchunks = (Dloc + bdc - 1) / bdc;
     pl.nbmax = (pl.seg_rows + 7 + 3) / 4;                            // consumer batches of a full segment
     pl.rec_per_chunk = (size_t)pl.ngroups * pl.nsegs * PcLayout<1>::NB * pl.nbmax * 64;
@@ -546,7 +681,7 @@ void launch_cvf_fused(hipStream_t s, March m, const float *vin, float *vout, Gui
 #define PSM_LAUNCH_PC(V4, CV)                                                                                              \
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_cvf_pc<V4, CV, 0>), dim3(nblocks), blk, 0, s, vin, vout, (const float4 *)gd.g1,   \
                        (const float4 *)gd.g2, (const float4 *)gd.g3, (const float2 *)gd.g4, W, H, Dloc, pl.ngroups, pl.nsegs, \
-                       pl.seg_rows, ybeg, yend, g1_other, d_begin, 1, (float *)nullptr, (unsigned *)nullptr, 0, PcSide{})
+                       pl.seg_rows, ybeg, yend, g1_other, d_begin, 1, (float *)nullptr, (unsigned *)nullptr, 0, PcSide{}, PcDyn{nullptr, 0})
     const bool v4 = (W & 3) == 0;
     if (cvc_mode == 1) { if (v4) PSM_LAUNCH_PC(true, 1); else PSM_LAUNCH_PC(false, 1); }
     else if (cvc_mode == 2) { if (v4) PSM_LAUNCH_PC(true, 2); else PSM_LAUNCH_PC(false, 2); }
@@ -555,9 +690,11 @@ void launch_cvf_fused(hipStream_t s, March m, const float *vin, float *vout, Gui
 }
 
 void launch_cvf_select(hipStream_t s, March m, const float *vin, Guidance gd, int W, int H, int Dloc, const float4 *g1_other,
-                       int d_begin, int cvc_mode, void *scratch, const uint8_t *p4_own, const uint8_t *p4_other)
-{   // p4_own != NULL (cvc_mode 1 / 2 only): 8-bit char mode
-    const PcPlan pl = pc_plan(W, H, Dloc, m.seg_rows, 1);
+                       int d_begin, int cvc_mode, void *scratch, int *cnt, const uint8_t *p4_own, const uint8_t *p4_other)
+{   // p4_own != NULL (cvc_mode 1 / 2 only): 8-bit char mode; cnt != NULL: dynamic slice distribution (npairs ints, zeroed here)
+    const PcPlan pl = pc_plan(W, H, Dloc, m.seg_rows, cnt ? 5 : 1);
+    const PcDyn dyn = {cnt, pl.NW};
+    if (cnt) (void)hipMemsetAsync(cnt, 0, sizeof(int) * pl.ngroups * pl.nsegs, s);
     float *kcost = (float *)scratch;                                           // nchunks * rec_per_chunk float4
     unsigned *kdisp = (unsigned *)(kcost + 4 * pl.rec_per_chunk * pl.nchunks);  // nchunks * rec_per_chunk uchar4
     const int nblocks = 8 * ((pl.ngroups * pl.nsegs * pl.nchunks + 7) / 8);
@@ -565,21 +702,64 @@ void launch_cvf_select(hipStream_t s, March m, const float *vin, Guidance gd, in
 #define PSM_LAUNCH_PC(CV)                                                                                                   \
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_cvf_pc<false, CV, 1>), dim3(nblocks), blk, 0, s, vin, (float *)nullptr, (const float4 *)gd.g1, \
                        (const float4 *)gd.g2, (const float4 *)gd.g3, (const float2 *)gd.g4, W, H, Dloc, pl.ngroups, pl.nsegs, \
-                       pl.seg_rows, 0, H, g1_other, d_begin, pl.DC, kcost, kdisp, pl.nbmax, PcSide{})
+                       pl.seg_rows, 0, H, g1_other, d_begin, pl.DC, kcost, kdisp, pl.nbmax, PcSide{}, dyn)
     if (p4_own && cvc_mode != 0) {
 #define PSM_LAUNCH_PC8(CV)                                                                                                  \
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_cvf_pc<false, CV, 1, true>), dim3(nblocks), blk, 0, s, (const float *)p4_own, (float *)const_cast<uint8_t *>(p4_other), \
                        (const float4 *)gd.g1, (const float4 *)gd.g2, (const float4 *)gd.g3, (const float2 *)gd.g4, W, H, Dloc, pl.ngroups, pl.nsegs, \
-                       pl.seg_rows, 0, H, g1_other, d_begin, pl.DC, kcost, kdisp, pl.nbmax, PcSide{})
+                       pl.seg_rows, 0, H, g1_other, d_begin, pl.DC, kcost, kdisp, pl.nbmax, PcSide{}, dyn)
         if (cvc_mode == 1) PSM_LAUNCH_PC8(1); else PSM_LAUNCH_PC8(2);
 #undef PSM_LAUNCH_PC8
     } else if (cvc_mode == 1) PSM_LAUNCH_PC(1); else if (cvc_mode == 2) PSM_LAUNCH_PC(2); else PSM_LAUNCH_PC(0);
 #undef PSM_LAUNCH_PC
 }
 
-void launch_chunk_min(hipStream_t s, March m, int W, int H, int Dloc, void *scratch, long long *keys, uint8_t *map)
+// Select mode with a shared key plane (MODE 2): keys[H*W] of this volume receives the packed minima over the local slices.
+void launch_cvf_select_keys(hipStream_t s, March m, const float *vin, Guidance gd, int W, int H, int Dloc, const float4 *g1_other,
+                            int d_begin, int cvc_mode, long long *keys, const uint8_t *p4_own, const uint8_t *p4_other)
 {
-    const PcPlan pl = pc_plan(W, H, Dloc, m.seg_rows, 1);
+    const PcPlan pl = pc_plan(W, H, Dloc, m.seg_rows, 3);
+    const size_t HW = (size_t)W * H;
+    hipLaunchKernelGGL(k_fill_keys, dim3((unsigned)((HW + 255) / 256)), dim3(256), 0, s, keys, HW);
+    const int nblocks = 8 * ((pl.ngroups * pl.nsegs * Dloc + 7) / 8);
+    const dim3 blk(64 * (PcLayout<2>::NA + PcLayout<2>::NB));
+#define PSM_LAUNCH_K(CV, U8V, A0, A1)                                                                                       \
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_cvf_pc<false, CV, 2, U8V>), dim3(nblocks), blk, 0, s, A0, A1, (const float4 *)gd.g1, \
+                       (const float4 *)gd.g2, (const float4 *)gd.g3, (const float2 *)gd.g4, W, H, Dloc, pl.ngroups, pl.nsegs, \
+                       pl.seg_rows, 0, H, g1_other, d_begin, 1, (float *)keys, (unsigned *)nullptr, 0, PcSide{}, PcDyn{nullptr, 0})
+    if (p4_own && cvc_mode != 0) {
+        if (cvc_mode == 1) PSM_LAUNCH_K(1, true, (const float *)p4_own, (float *)const_cast<uint8_t *>(p4_other));
+        else PSM_LAUNCH_K(2, true, (const float *)p4_own, (float *)const_cast<uint8_t *>(p4_other));
+    } else if (cvc_mode == 1) PSM_LAUNCH_K(1, false, (const float *)nullptr, (float *)nullptr);
+    else if (cvc_mode == 2) PSM_LAUNCH_K(2, false, (const float *)nullptr, (float *)nullptr);
+    else PSM_LAUNCH_K(0, false, vin, (float *)nullptr);
+#undef PSM_LAUNCH_K
+}
+
+// ... both volumes in one launch: keys[2][H][W]
+void launch_cvf_select_keys2(hipStream_t s, March m, const Guidance *g, int W, int H, int Dloc, int d_begin, long long *keys,
+                             const uint8_t *const *p4)
+{
+    const PcPlan pl = pc_plan(W, H, Dloc, m.seg_rows, 4);
+    const size_t HW = (size_t)W * H;
+    hipLaunchKernelGGL(k_fill_keys, dim3((unsigned)((2 * HW + 255) / 256)), dim3(256), 0, s, keys, 2 * HW);
+    const int nblocks = 8 * ((pl.ngroups * pl.nsegs * Dloc + 7) / 8);
+    const dim3 blk(64 * (PcLayout<2>::NA + PcLayout<2>::NB));
+    const PcSide s1 = {(const float4 *)g[1].g1, (const float4 *)g[1].g2, (const float4 *)g[1].g3, (const float2 *)g[1].g4, (const float4 *)g[0].g1,
+                       (float *)(keys + HW), nullptr};
+    if (p4)
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_cvf_pc<false, 3, 2, true>), dim3(nblocks, 2), blk, 0, s, (const float *)p4[0], (float *)const_cast<uint8_t *>(p4[1]),
+                           (const float4 *)g[0].g1, (const float4 *)g[0].g2, (const float4 *)g[0].g3, (const float2 *)g[0].g4, W, H, Dloc, pl.ngroups,
+                           pl.nsegs, pl.seg_rows, 0, H, (const float4 *)g[1].g1, d_begin, 1, (float *)keys, (unsigned *)nullptr, 0, s1, PcDyn{nullptr, 0});
+    else
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_cvf_pc<false, 3, 2, false>), dim3(nblocks, 2), blk, 0, s, (const float *)nullptr, (float *)nullptr,
+                           (const float4 *)g[0].g1, (const float4 *)g[0].g2, (const float4 *)g[0].g3, (const float2 *)g[0].g4, W, H, Dloc, pl.ngroups,
+                           pl.nsegs, pl.seg_rows, 0, H, (const float4 *)g[1].g1, d_begin, 1, (float *)keys, (unsigned *)nullptr, 0, s1, PcDyn{nullptr, 0});
+}
+
+void launch_chunk_min(hipStream_t s, March m, int W, int H, int Dloc, void *scratch, long long *keys, uint8_t *map, int dynamic)
+{
+    const PcPlan pl = pc_plan(W, H, Dloc, m.seg_rows, dynamic ? 5 : 1);
     const float *kcost = (const float *)scratch;
     const unsigned *kdisp = (const unsigned *)(kcost + 4 * pl.rec_per_chunk * pl.nchunks);
     hipLaunchKernelGGL(k_chunk_min, dim3((unsigned)((pl.rec_per_chunk + 255) / 256)), dim3(256), 0, s, (const float4 *)kcost, (const unsigned *)kdisp,
@@ -589,9 +769,13 @@ void launch_chunk_min(hipStream_t s, March m, int W, int H, int Dloc, void *scra
 
 // Both volumes in one launch each (costs built on the fly): left volume = (g[0], other g[1].g1), right = (g[1], other g[0].g1);
 // scratch: 2 x pc_plan(...).scratch_bytes(); keys / map: [2][H][W].
-void launch_cvf_select2(hipStream_t s, March m, const Guidance *g, int W, int H, int Dloc, int d_begin, void *scratch, const uint8_t *const *p4)
+void launch_cvf_select2(hipStream_t s, March m, const Guidance *g, int W, int H, int Dloc, int d_begin, void *scratch, int *cnt,
+                        const uint8_t *const *p4)
 {   // p4 != NULL: 8-bit char mode, p4[0] / p4[1] = byte planes {c0,c1,c2,grad} of the left / right image
-    const PcPlan pl = pc_plan(W, H, Dloc, m.seg_rows, 1);
+    // cnt != NULL: dynamic slice distribution (2 * npairs ints, zeroed here)
+    const PcPlan pl = pc_plan(W, H, Dloc, m.seg_rows, cnt ? 6 : 2);
+    const PcDyn dyn = {cnt, pl.NW};
+    if (cnt) (void)hipMemsetAsync(cnt, 0, sizeof(int) * 2 * pl.ngroups * pl.nsegs, s);
     float *kcost0 = (float *)scratch;
     unsigned *kdisp0 = (unsigned *)(kcost0 + 4 * pl.rec_per_chunk * pl.nchunks);
     float *kcost1 = (float *)((char *)scratch + pl.scratch_bytes());
@@ -602,16 +786,16 @@ void launch_cvf_select2(hipStream_t s, March m, const Guidance *g, int W, int H,
     if (p4)
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_cvf_pc<false, 3, 1, true>), dim3(nblocks, 2), blk, 0, s, (const float *)p4[0], (float *)const_cast<uint8_t *>(p4[1]),
                            (const float4 *)g[0].g1, (const float4 *)g[0].g2, (const float4 *)g[0].g3, (const float2 *)g[0].g4, W, H, Dloc, pl.ngroups,
-                           pl.nsegs, pl.seg_rows, 0, H, (const float4 *)g[1].g1, d_begin, pl.DC, kcost0, kdisp0, pl.nbmax, s1);
+                           pl.nsegs, pl.seg_rows, 0, H, (const float4 *)g[1].g1, d_begin, pl.DC, kcost0, kdisp0, pl.nbmax, s1, dyn);
     else
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_cvf_pc<false, 3, 1>), dim3(nblocks, 2), blk, 0, s, (const float *)nullptr, (float *)nullptr, (const float4 *)g[0].g1,
                            (const float4 *)g[0].g2, (const float4 *)g[0].g3, (const float2 *)g[0].g4, W, H, Dloc, pl.ngroups, pl.nsegs, pl.seg_rows, 0, H,
-                           (const float4 *)g[1].g1, d_begin, pl.DC, kcost0, kdisp0, pl.nbmax, s1);
+                           (const float4 *)g[1].g1, d_begin, pl.DC, kcost0, kdisp0, pl.nbmax, s1, dyn);
 }
 
-void launch_chunk_min2sides(hipStream_t s, March m, int W, int H, int Dloc, void *scratch, long long *keys, uint8_t *map)
+void launch_chunk_min2sides(hipStream_t s, March m, int W, int H, int Dloc, void *scratch, long long *keys, uint8_t *map, int dynamic)
 {
-    const PcPlan pl = pc_plan(W, H, Dloc, m.seg_rows, 1);
+    const PcPlan pl = pc_plan(W, H, Dloc, m.seg_rows, dynamic ? 6 : 2);
     const float *kcost0 = (const float *)scratch;
     const unsigned *kdisp0 = (const unsigned *)(kcost0 + 4 * pl.rec_per_chunk * pl.nchunks);
     const float *kcost1 = (const float *)((const char *)scratch + pl.scratch_bytes());

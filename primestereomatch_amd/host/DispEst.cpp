@@ -117,6 +117,12 @@ int DispEst::FillInvalid_GPU()
     return hipUtil::api().fill_invalid(ctx[0], lDisMap.data, rDisMap.data, lDisMap.step);
 }
 
+int DispEst::WgtMedian_GPU()
+{
+    if (ctx.empty()) return 1;
+    return hipUtil::api().wgt_median(ctx[0], lDisMap.data, rDisMap.data, lDisMap.step);
+}
+
 double DispEst::stageTimeUs(int stage) const
 {
     double us = 0;

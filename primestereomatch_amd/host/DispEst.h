@@ -73,6 +73,9 @@ public:
     int PostProcess_GPU();
     // fillInv (src/PP.cpp:52-143) on the device: fills the pixels PostProcess_GPU marked invalid
     int FillInvalid_GPU();
+    // wgtMedian (src/PP.cpp:145-247; the plain weighted-median stage of PP::processDM, :405-410) on the device, for the
+    // pixels PostProcess_GPU marked invalid; same result as the reference's sequential in-place form
+    int WgtMedian_GPU();
 
     bool ok() const { return !ctx.empty(); }
     double stageTimeUs(int stage) const;

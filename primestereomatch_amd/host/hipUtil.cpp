@@ -44,6 +44,7 @@ bool hipUtil::load(const char *path)
               bind(g_api.cost_filter_fgf, "psm_cost_filter_fgf") &&
               bind(g_api.disp_select, "psm_disp_select") && bind(g_api.disp_select_partial, "psm_disp_select_partial") &&
               bind(g_api.disp_merge_ctx, "psm_disp_merge_ctx") && bind(g_api.lr_check, "psm_lr_check") && bind(g_api.fill_invalid, "psm_fill_invalid") &&
+              bind(g_api.wgt_median, "psm_wgt_median") &&
               bind(g_api.stage_time_us, "psm_stage_time_us");
     if (!ok) {
         fprintf(stderr, "%s\n", g_error.c_str());

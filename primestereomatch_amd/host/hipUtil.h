@@ -27,6 +27,7 @@ struct HipApi {
     int (*disp_merge_ctx)(psm_ctx *, psm_ctx *const *, int, uint8_t *, uint8_t *, size_t) = nullptr;
     int (*lr_check)(psm_ctx *, uint8_t *, uint8_t *, size_t) = nullptr;
     int (*fill_invalid)(psm_ctx *, uint8_t *, uint8_t *, size_t) = nullptr;
+    int (*wgt_median)(psm_ctx *, uint8_t *, uint8_t *, size_t) = nullptr;
     int (*stage_time_us)(psm_ctx *, int, double *) = nullptr;
 };
 

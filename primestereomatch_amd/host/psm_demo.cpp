@@ -1,7 +1,9 @@
 // psm_demo - headless counterpart of the reference's StereoMatch::compute accelerator branch
 // (src/StereoMatch.cpp:193-262): raw B,G,R uint8 pair in, four timed stages, raw uint8 maps out.
-//   psm_demo <left.raw> <right.raw> <W> <H> <maxDis> <out_prefix> [ndev] [f32|u8] [float_input] [fgf_rate]
+//   psm_demo <left.raw> <right.raw> <W> <H> <maxDis> <out_prefix> [ndev] [f32|u8] [float_input] [fgf_rate] [pp]
 // fgf_rate 0 (default): CostFilter_GPU; 2/4/8: CostFilter_FGF_GPU with that subsample rate
+// pp 1: after the left-right check also fillInv + wgtMedian (the stages of PP::processDM, src/PP.cpp:405-410); the
+//       post-processed maps go to <out_prefix>_ldisp_pp.raw / _rdisp_pp.raw
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -30,7 +32,7 @@ static bool dump(const std::string &path, const unsigned char *p, size_t n)
 int main(int argc, char **argv)
 {
     if (argc < 7) {
-        fprintf(stderr, "usage: %s left.raw right.raw W H maxDis out_prefix [ndev] [f32|u8] [float_input] [fgf_rate]\n", argv[0]);
+        fprintf(stderr, "usage: %s left.raw right.raw W H maxDis out_prefix [ndev] [f32|u8] [float_input] [fgf_rate] [pp]\n", argv[0]);
         return 2;
     }
     const int W = atoi(argv[3]), H = atoi(argv[4]), D = atoi(argv[5]);
@@ -39,6 +41,7 @@ int main(int argc, char **argv)
     const int dtype = (argc > 8 && !strcmp(argv[8], "u8")) ? PSM_U8 : PSM_F32;
     const bool float_input = argc > 9 && atoi(argv[9]) != 0;
     const int fgf_rate = argc > 10 ? atoi(argv[10]) : 0;
+    const bool pp = argc > 11 && atoi(argv[11]) != 0;
     std::vector<unsigned char> lraw, rraw;
     if (!slurp(argv[1], lraw, (size_t)W * H * 3) || !slurp(argv[2], rraw, (size_t)W * H * 3)) {
         fprintf(stderr, "psm_demo: cannot read the input pair\n");
@@ -78,5 +81,9 @@ int main(int argc, char **argv)
            SMDE.stageTimeUs(PSM_STAGE_DISPSEL) / 1000, SMDE.stageTimeUs(PSM_STAGE_PP) / 1000);
     bool ok = dump(out + "_ldisp.raw", SMDE.lDisMap.data, (size_t)W * H) && dump(out + "_rdisp.raw", SMDE.rDisMap.data, (size_t)W * H) &&
               dump(out + "_lvalid.raw", SMDE.lValid.data, (size_t)W * H) && dump(out + "_rvalid.raw", SMDE.rValid.data, (size_t)W * H);
+    if (ok && pp) {
+        if (SMDE.FillInvalid_GPU() || SMDE.WgtMedian_GPU()) return 5;
+        ok = dump(out + "_ldisp_pp.raw", SMDE.lDisMap.data, (size_t)W * H) && dump(out + "_rdisp_pp.raw", SMDE.rDisMap.data, (size_t)W * H);
+    }
     return ok ? 0 : 6;
 }

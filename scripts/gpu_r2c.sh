@@ -8,7 +8,7 @@ python -c "import __graft_entry__ as g; g.build()" > $OUT/build.log 2>&1 || echo
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2
 timeout 1500 python -m pytest tests -m gpu -q -p no:cacheprovider --timeout=600 -x > $OUT/pytest_gpu.log 2>&1
 tail -5 $OUT/pytest_gpu.log
-for cfg in "" "--flags 8192"; do
+for cfg in "" "--flags 524288" "--flags 8192"; do
   n=$(echo "$cfg" | tr -d ' -')
   timeout 300 python bench.py --no-cpu-baseline --verify $cfg > $OUT/bench_c4_$n.json 2>> $OUT/bench.err
 done

@@ -1,5 +1,5 @@
-"""profiles/traffic.json from the rocprofv3 PMC summaries of scripts/gpu_run.sh (passes rd, wr).
-    python scripts/make_traffic.py gpurun_out/<tag> [kernel substring, default k_cvf_pc<true, 2>]
+"""profiles/traffic.json from the rocprofv3 PMC summaries of scripts/gpu_round.sh (passes rd, wr).
+    python scripts/make_traffic.py gpurun_out/<tag> [kernel substring] [source label]
 Fabric-side bytes per launch = TCC_EA0_RDREQ_sum*128 (these kernels issue no 32-byte requests; equals
 2*FETCH_SIZE*1024, the gfx950 correction of MI355X_MICROARCH.md) + WRITE_SIZE*1024."""
 import json
@@ -22,24 +22,34 @@ def counters(path, kernel):
     return out
 
 
-def main():
-    d = sys.argv[1]
-    kernel = sys.argv[2] if len(sys.argv) > 2 else "k_cvf_pc<true, 2>"
+def fabric_bytes(d, kernel):
     rd = counters(os.path.join(d, "pmc_rd.summary.txt"), kernel)
     wr = counters(os.path.join(d, "pmc_wr.summary.txt"), kernel)
     r32 = rd.get("TCC_EA0_RDREQ_32B_sum", 0.0)
-    rbytes = (rd["TCC_EA0_RDREQ_sum"] - r32) * 128 + r32 * 32
-    wbytes = wr["WRITE_SIZE"] * 1024
+    return (rd["TCC_EA0_RDREQ_sum"] - r32) * 128 + r32 * 32, wr["WRITE_SIZE"] * 1024
+
+
+def main():
+    d = sys.argv[1]
+    kernel = sys.argv[2] if len(sys.argv) > 2 else "k_cvf_pc<false, 3, 1"
+    source = sys.argv[3] if len(sys.argv) > 3 else "profiles/ (rocprofv3 --pmc passes)"
+    rbytes, wbytes = fabric_bytes(d, kernel)
     out = {
-        "_comment": "Fabric-side (L2 <-> Infinity Fabric) bytes per launch from rocprofv3 PMC passes (scripts/gpu_run.sh, "
+        "_comment": "Fabric-side (L2 <-> Infinity Fabric) bytes per launch from rocprofv3 PMC passes (scripts/gpu_round.sh, "
                     "scripts/make_traffic.py): TCC_EA0_RDREQ_sum*128 (+32 B per 32-byte request; equals 2*FETCH_SIZE*1024, the "
                     "gfx950 correction of MI355X_MICROARCH.md) + WRITE_SIZE*1024. Requests served by the Infinity cache (MALL) "
                     "are included, so this is an upper bound of the HBM bytes. "
-                    f"Kernel: {kernel} (right volume, costs built on the fly).",
+                    f"Kernel: {kernel} (select mode, both volumes in one launch, costs built on the fly).",
+        "_source": source,
         "c4:k_cvf_fused": round(rbytes + wbytes),
         "c4:k_cvf_fused_read": round(rbytes),
         "c4:k_cvf_fused_write": round(wbytes),
     }
+    try:
+        r2, w2 = fabric_bytes(d, "k_chunk_min")
+        out["c4:k_chunk_min"] = round(r2 + w2)
+    except Exception:
+        pass
     json.dump(out, open(os.path.join(ROOT, "profiles", "traffic.json"), "w"), indent=1)
     print(json.dumps(out, indent=1))
 

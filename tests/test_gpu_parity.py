@@ -459,7 +459,7 @@ def test_cpp_dispest_demo(psm, oracle, golden, tmp_path, mode, float_input):
     pair["r_bgr"].tofile(tmp_path / "r.raw")
     env = dict(os.environ, PRIMESM_HIP_LIB=psm.capi.LIB_PATH)
     p = subprocess.run([demo, str(tmp_path / "l.raw"), str(tmp_path / "r.raw"), str(W), str(H), "64",
-                        str(tmp_path / "o"), "1", mode, str(float_input)], env=env, capture_output=True, text=True, timeout=300)
+                        str(tmp_path / "o"), "1", mode, str(float_input), "0", "1"], env=env, capture_output=True, text=True, timeout=300)
     assert p.returncode == 0, p.stderr
     assert "CVF Time" in p.stdout
     ld = np.fromfile(tmp_path / "o_ldisp.raw", np.uint8).reshape(H, W)
@@ -468,9 +468,13 @@ def test_cpp_dispest_demo(psm, oracle, golden, tmp_path, mode, float_input):
     assert np.array_equal(ld, gold[key[0]]) and np.array_equal(rd, gold[key[1]])
     lv = np.fromfile(tmp_path / "o_lvalid.raw", np.uint8).reshape(H, W)
     assert np.array_equal(lv, oracle.lr_check(ld, rd)[0])
+    # pp = 1: fillInv + wgtMedian through the C++ mirror (PP::processDM's stages, src/PP.cpp:405-410)
+    lpp = np.fromfile(tmp_path / "o_ldisp_pp.raw", np.uint8).reshape(H, W)
+    exp = oracle.wgt_median(oracle.u8_to_f32(pair["l_bgr"]), oracle.fill_inv(ld, lv), lv, 64, right=False)
+    assert np.array_equal(lpp, exp)
 
 
-@pytest.mark.parametrize("flags", [0, 256, 128, 128 + 64, 16, 16 + 1, 16 + 2, 16 + 4, 512, 512 + 128, 4096, 8192, 8192 + 128, 16384, 16384 + 128, 65536])
+@pytest.mark.parametrize("flags", [0, 256, 128, 128 + 64, 16, 16 + 1, 16 + 2, 16 + 4, 512, 512 + 128, 4096, 8192, 8192 + 128, 16384, 16384 + 128, 65536, 262144, 262144 + 65536, 524288, 524288 + 65536])
 def test_tuning_flags_do_not_change_results(psm, oracle, flags):
     """PSM_OPT_FLAGS only changes store policy / block traversal / CVC store width."""
     from primestereomatch_amd import capi, synth
