@@ -315,16 +315,17 @@ __global__ __launch_bounds__(64 * (PcLayout<MODE>::NA + PcLayout<MODE>::NB)) PSM
         VTree t0 = {}, t1 = {}, t2 = {}, t3 = {};
         float o1x[4], o1y[4], o1z[4];                 // g1.xyz at (output row, output column), one batch ahead
         // MODE 1: this wave's records of the chunk plane: [batch][lane] float4 costs / uchar4 disparities of the batch's four rows
-        const size_t krec = ((size_t)(ch * npairs + pair) * PC_NB + wb) * nbmax * 64;
+        // (compact: PC_COLS records per batch, this wave's bwidth lanes at column offset wb * PC_OUT_B; halo lanes never store)
+        const size_t krec = (size_t)(ch * npairs + pair) * nbmax * PC_COLS + wb * PC_OUT_B;
         // (own descriptors: offsets stay small, and the loads can carry sc1 = served by the L2, never by this CU's L1 -
         // the record was last written by this same wave one slice earlier)
-        const __amdgpu_buffer_rsrc_t rKc = pc_rsrc(MODE == 1 ? (const void *)(reinterpret_cast<float4 *>(kcost) + krec) : (const void *)G1, (unsigned)nbmax * 1024u);
-        const __amdgpu_buffer_rsrc_t rKd = pc_rsrc(MODE == 1 ? (const void *)(kdisp + krec) : (const void *)G1, (unsigned)nbmax * 256u);
+        const __amdgpu_buffer_rsrc_t rKc = pc_rsrc(MODE == 1 ? (const void *)(reinterpret_cast<float4 *>(kcost) + krec) : (const void *)G1, (unsigned)nbmax * PC_COLS * 16u);
+        const __amdgpu_buffer_rsrc_t rKd = pc_rsrc(MODE == 1 ? (const void *)(kdisp + krec) : (const void *)G1, (unsigned)nbmax * PC_COLS * 4u);
 #define PSM_K_LOAD(C)                                                                              \
     {                                                                                              \
-        const pc_u4 v_ = __builtin_amdgcn_raw_buffer_load_b128(rKc, lane * 16, (C) * 1024, PSM_K_LD_AUX); \
+        const pc_u4 v_ = __builtin_amdgcn_raw_buffer_load_b128(rKc, lane * 16, (C) * (PC_COLS * 16), PSM_K_LD_AUX); \
         kq = make_float4(__uint_as_float(v_.x), __uint_as_float(v_.y), __uint_as_float(v_.z), __uint_as_float(v_.w)); \
-        kd4 = __builtin_amdgcn_raw_buffer_load_b32(rKd, lane * 4, (C) * 256, PSM_K_LD_AUX);        \
+        kd4 = __builtin_amdgcn_raw_buffer_load_b32(rKd, lane * 4, (C) * (PC_COLS * 4), PSM_K_LD_AUX); \
     }
         float4 kq = make_float4(__builtin_inff(), __builtin_inff(), __builtin_inff(), __builtin_inff());   // running minima of the current batch
         unsigned kd4 = 0;                                                                                  // and their disparities
@@ -471,10 +472,10 @@ __global__ __launch_bounds__(64 * (PcLayout<MODE>::NA + PcLayout<MODE>::NB)) PSM
 #define PSM_PC_MASKED_STORES 1
 #endif
                     // (per lane: only lanes with an improved row rewrite their record; 0: the whole wave whenever any lane improved)
-                    if (first || (PSM_PC_MASKED_STORES ? any : __builtin_amdgcn_ballot_w64(any) != 0)) {
+                    if (lane < bwidth && (first || (PSM_PC_MASKED_STORES ? any : __builtin_amdgcn_ballot_w64(any) != 0))) {
                         const pc_u4 kv = {__float_as_uint(kn[0]), __float_as_uint(kn[1]), __float_as_uint(kn[2]), __float_as_uint(kn[3])};
-                        __builtin_amdgcn_raw_buffer_store_b128(kv, rKc, lane * 16, c * 1024, 0);
-                        __builtin_amdgcn_raw_buffer_store_b32(dn, rKd, lane * 4, c * 256, 0);
+                        __builtin_amdgcn_raw_buffer_store_b128(kv, rKc, lane * 16, c * (PC_COLS * 16), 0);
+                        __builtin_amdgcn_raw_buffer_store_b32(dn, rKd, lane * 4, c * (PC_COLS * 4), 0);
                     }
                     if (!first && c + 1 < nbB) PSM_K_LOAD(c + 1)       // records of the next batch
                 }
@@ -494,13 +495,14 @@ __global__ __launch_bounds__(64 * (PcLayout<MODE>::NA + PcLayout<MODE>::NB)) PSM
         if (dynamic && first && !is_a) {
             // this workgroup came too late for any slice: its plane must still read "no candidate"
             const int wb = wave - PC_NA;
-            const size_t krec = ((size_t)(ch * npairs + pair) * PC_NB + wb) * nbmax * 64;
+            const int bw = wb < PC_NB - 1 ? PC_OUT_B : PC_COLS - (PC_NB - 1) * PC_OUT_B;
+            const size_t krec = (size_t)(ch * npairs + pair) * nbmax * PC_COLS + wb * PC_OUT_B;
             float4 *kc = reinterpret_cast<float4 *>(kcost) + krec;
             unsigned *kd = kdisp + krec;
             const float inf = __builtin_inff();
-            for (int c = 0; c < nbB; ++c) {
-                kc[c * 64 + lane] = make_float4(inf, inf, inf, inf);
-                kd[c * 64 + lane] = 0u;
+            for (int c = 0; c < nbB && lane < bw; ++c) {
+                kc[c * PC_COLS + lane] = make_float4(inf, inf, inf, inf);
+                kd[c * PC_COLS + lane] = 0u;
             }
         }
     }
@@ -514,7 +516,7 @@ __global__ __launch_bounds__(64 * (PcLayout<MODE>::NA + PcLayout<MODE>::NB)) PSM
 
 // chunk planes -> packed WTA key and / or final map per pixel (minimum over the chunks; pack_key_f32 makes the signed
 // 64-bit minimum select (min cost, then lowest d) exactly as the sequential loop of src/DispSel.cpp:96-104).
-// One thread per record (pair, consumer wave, batch, lane) = four rows of one column, as the select kernel wrote them.
+// One thread per record (pair, batch, column) = four rows of one column, as the select kernel wrote them.
 __global__ __launch_bounds__(256) void k_chunk_min(const float4 *kcost, const unsigned *kdisp, int nchunks, int npairs,
                                                   int nbmax, int ngroups, int seg_rows, int W, int H, long long *keys,
                                                   uint8_t *map, const float4 *__restrict__ kcost1, const unsigned *__restrict__ kdisp1)
@@ -526,18 +528,16 @@ __global__ __launch_bounds__(256) void k_chunk_min(const float4 *kcost, const un
         if (keys) keys += (size_t)W * H;
         if (map) map += (size_t)W * H;
     }
-    const size_t nrec = (size_t)npairs * L::NB * nbmax * 64;       // records per chunk plane
+    const size_t nrec = (size_t)npairs * nbmax * L::COLS;          // records per chunk plane
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= nrec) return;
-    const int lane = (int)(idx & 63);
-    size_t t = idx >> 6;
-    const int c = (int)(t % nbmax); t /= nbmax;
-    const int wb = (int)(t % L::NB);
-    const int pair = (int)(t / L::NB);
+    const int col = (int)(idx % L::COLS);
+    size_t t = idx / L::COLS;
+    const int c = (int)(t % nbmax);
+    const int pair = (int)(t / nbmax);
     const int g = pair % ngroups, seg = pair / ngroups;
-    const int bwidth = wb < L::NB - 1 ? L::OUT_B : L::COLS - (L::NB - 1) * L::OUT_B;
-    const int x = g * L::COLS + wb * L::OUT_B + lane;
-    if (lane >= bwidth || x >= W) return;
+    const int x = g * L::COLS + col;
+    if (x >= W) return;
     const int y0 = seg * seg_rows, y1 = min(H, y0 + seg_rows);
     const int ya = y0 + 4 * c - 7;                                  // output row of the record's first entry
     if (ya + 3 < y0 || ya >= y1) return;
@@ -629,7 +629,7 @@ PcPlan pc_plan_cols(int W, int H, int Dloc, int seg_rows_opt, int mode_in, int c
         pl.NW = bnw;
         pl.nchunks = bnw;
         pl.nbmax = (pl.seg_rows + 7 + 3) / 4;
-        pl.rec_per_chunk = (size_t)pl.ngroups * pl.nsegs * PcLayout<1>::NB * pl.nbmax * 64;
+        pl.rec_per_chunk = (size_t)pl.ngroups * pl.nsegs * pl.nbmax * PcLayout<1>::COLS;
         pl.rec_bytes = 20;
         return pl;
     }
@@ -665,7 +665,7 @@ PcPlan pc_plan_cols(int W, int H, int Dloc, int seg_rows_opt, int mode_in, int c
     pl.NW = 0;
     pl.nchunks = (Dloc + bdc - 1) / bdc;
     pl.nbmax = (pl.seg_rows + 7 + 3) / 4;                            // consumer batches of a full segment
-    pl.rec_per_chunk = (size_t)pl.ngroups * pl.nsegs * PcLayout<1>::NB * pl.nbmax * 64;
+    pl.rec_per_chunk = (size_t)pl.ngroups * pl.nsegs * pl.nbmax * PcLayout<1>::COLS;
     pl.rec_bytes = 20;                                               // 16 bytes of costs + 4 bytes of disparities
     return pl;
 }
