@@ -109,7 +109,13 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     use_dist = (N > 1) or args.force_dist
     torch = dist = None
+    json_fd = None
     if use_dist:
+        # RCCL prints a version banner on the C-level stdout (flushed at exit, i.e. after our line): keep stdout for the ONE
+        # JSON line only - everything else written to fd 1 by this process goes to stderr
+        sys.stdout.flush()
+        json_fd = os.dup(1)
+        os.dup2(2, 1)
         # torch first: libprimesm_hip.so then binds to the HIP runtime torch already loaded
         # (same SONAME libamdhip64.so.7), so device pointers are interchangeable.
         import torch
@@ -399,8 +405,11 @@ def main():
             out["verified_vs_single_gpu"] = verified
         if box:
             out["box_filter_pass"] = box
-        print(json.dumps(out))
-        sys.stdout.flush()
+        if json_fd is not None:
+            os.write(json_fd, (json.dumps(out) + "\n").encode())
+        else:
+            print(json.dumps(out))
+            sys.stdout.flush()
     de.close()
     if use_dist:
         dist.barrier()

@@ -76,6 +76,8 @@ struct psm_ctx {
     size_t fgf_bytes = 0;
 
     bool have_images = false, have_g1 = false, have_cost = false, have_maps = false, have_valid = false;
+    bool have_keys = false;             // keys_cur holds the packed minima of the current frame's local slices (both sides)
+    bool have_keys_side[2] = {false, false};
     // raw_rows[side]: which rows of the unfiltered cost volume exist in memory.  psm_cost_construct may
     // leave the volume virtual (RAW_NONE): the fused filter builds the costs on the fly from the g1
     // planes.  Anything else that reads the volume materialises it first (materialize()).
@@ -523,6 +525,7 @@ int psm_upload_pair(psm_ctx *c, const void *l, const void *r, int channels, size
     c->have_cost = false;
     c->have_maps = false;
     c->have_valid = false;
+    c->have_keys = c->have_keys_side[0] = c->have_keys_side[1] = false;
     c->raw_rows[0] = c->raw_rows[1] = psm_ctx::RAW_ALL;   // nothing virtual survives a new pair
     c->fgf_virtual[0] = c->fgf_virtual[1] = 0;
     c->gf_virtual[0] = c->gf_virtual[1] = false;
@@ -561,6 +564,7 @@ int psm_cost_construct(psm_ctx *c)
     if (check_launch(c, "cvc")) return 1;
     c->have_cost = true;
     c->have_maps = false;
+    c->have_keys = c->have_keys_side[0] = c->have_keys_side[1] = false;
     return end_stage(c, PSM_STAGE_CVC, t0);
 }
 
@@ -928,6 +932,7 @@ int psm_disp_select_partial(psm_ctx *c, void *dev_keys)
     const double t0 = now_us();
     if (wta_ready(c, 0) || wta_ready(c, 1)) return 1;
     if (wta_launch(c, dev_keys ? (long long *)dev_keys : c->keys_cur, nullptr)) return 1;
+    if (!dev_keys) c->have_keys = c->have_keys_side[0] = c->have_keys_side[1] = true;
     return end_stage(c, PSM_STAGE_DISPSEL, t0);
 }
 
@@ -943,6 +948,10 @@ int psm_disp_select_partial_side(psm_ctx *c, int side, void *dev_keys_side)
     long long *keys = dev_keys_side ? (long long *)dev_keys_side : c->keys_cur + side * HW;
     if (wta_side(c, side, keys, nullptr)) return 1;
     if (check_launch(c, "wta")) return 1;
+    if (!dev_keys_side) {
+        c->have_keys_side[side] = true;
+        c->have_keys = c->have_keys_side[0] && c->have_keys_side[1];
+    }
     if (!c->opt_async) PSM_HIP(c, hipStreamSynchronize(c->stream));
     c->stage_us[PSM_STAGE_DISPSEL] = (side == PSM_LEFT ? 0.0 : c->stage_us[PSM_STAGE_DISPSEL]) + (now_us() - t0);
     return 0;
@@ -991,11 +1000,20 @@ int psm_disp_merge_ctx(psm_ctx *root, psm_ctx *const *shards, int nshards, uint8
     if (!root) return 1;
     if (!shards || nshards < 1) return fail(root, "psm_disp_merge_ctx: bad arguments");
     const size_t bytes = 2 * (size_t)root->W * root->H * sizeof(long long);
+    std::vector<char> covered((size_t)root->D, 0);
     for (int i = 0; i < nshards; ++i) {
         const psm_ctx *s = shards[i];
         if (!s || s->W != root->W || s->H != root->H || s->D != root->D || s->dtype != root->dtype)
             return fail(root, "psm_disp_merge_ctx: shard %d does not belong to this job", i);
+        if (!s->have_keys)
+            return fail(root, "psm_disp_merge_ctx: shard %d has no partial minima for this frame (call psm_disp_select_partial(ctx, NULL) first)", i);
+        for (int d = s->d0; d < s->d1; ++d) {
+            if (covered[d]) return fail(root, "psm_disp_merge_ctx: slice %d is held by more than one shard", d);
+            covered[d] = 1;
+        }
     }
+    for (int d = 0; d < root->D; ++d)
+        if (!covered[d]) return fail(root, "psm_disp_merge_ctx: no shard holds slice %d", d);
     if (bind(root)) return 1;
     if (root->gather_ranks < nshards) {
         PSM_HIP(root, hipStreamSynchronize(root->stream));
@@ -1012,9 +1030,9 @@ int psm_disp_merge_ctx(psm_ctx *root, psm_ctx *const *shards, int nshards, uint8
         PSM_HIP(root, hipStreamSynchronize(s->stream));
         (void)hipSetDevice(root->device);
         if (s->device == root->device)
-            PSM_HIP(root, hipMemcpyAsync((char *)root->gather + bytes * i, s->keys, bytes, hipMemcpyDeviceToDevice, root->stream));
+            PSM_HIP(root, hipMemcpyAsync((char *)root->gather + bytes * i, s->keys_cur, bytes, hipMemcpyDeviceToDevice, root->stream));
         else
-            PSM_HIP(root, hipMemcpyPeerAsync((char *)root->gather + bytes * i, root->device, s->keys, s->device, bytes, root->stream));
+            PSM_HIP(root, hipMemcpyPeerAsync((char *)root->gather + bytes * i, root->device, s->keys_cur, s->device, bytes, root->stream));
     }
     return psm_disp_merge(root, root->gather, nshards, lmap, rmap, stride);
 }

@@ -91,6 +91,7 @@ __global__ __launch_bounds__(64) void k_wgt_median(uint8_t *dis, const float4 *_
     const int *qn = nxt + (size_t)qy_l * (W + 1);
     // tap t of this lane's k-th round: t = lane + 64 k  (k = 0..5, 361 taps)
     constexpr int WM_ROUNDS = (WM_TAPS + 63) / 64;
+    int prc = 0;                             // last value of prog[qy_l] this lane has seen
     int x = myn[0];
     while (x < W) {
         // ---- 361 weights, 64 at a time: they depend on the colours only, so they are evaluated BEFORE the wait - on a
@@ -115,14 +116,18 @@ __global__ __launch_bounds__(64) void k_wgt_median(uint8_t *dis, const float4 *_
             else if (hi >= W) { a0 = lo; b0 = W - 1; a1 = 0; b1 = hi - W; }
             else { a0 = lo; b0 = hi; }
             unsigned spins = 0;
+            auto clear = [&](int pr) {     // no unfinished invalid pixel of this lane's window row inside the column intervals
+                const int s0 = max(a0, pr), s1 = max(a1, pr);
+                return !(s0 <= b0 && qn[s0] <= b0) && !(s1 <= b1 && qn[s1] <= b1);
+            };
             for (;;) {
                 bool ok = true;
                 if (earlier) {
-                    const int pr = __hip_atomic_load(&prog[qy_l], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    int s0 = max(a0, pr);
-                    if (s0 <= b0 && qn[s0] <= b0) ok = false;
-                    int s1 = max(a1, pr);
-                    if (s1 <= b1 && qn[s1] <= b1) ok = false;
+                    ok = clear(prc);           // prog only grows: the value seen last time often already suffices (no round trip)
+                    if (!ok) {
+                        prc = __hip_atomic_load(&prog[qy_l], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        ok = clear(prc);
+                    }
                 }
                 if (__builtin_amdgcn_ballot_w64(!ok) == 0) break;
                 __builtin_amdgcn_s_sleep(1);
@@ -131,7 +136,8 @@ __global__ __launch_bounds__(64) void k_wgt_median(uint8_t *dis, const float4 *_
                     break;
                 }
             }
-            // (the loop exit depends on the prog values just loaded, so the map loads below are issued after them)
+            // (a prog value, cached or fresh, was loaded after the map bytes it vouches for were stored, and the loop exit
+            // depends on it: the map loads below are issued after it)
         }
         // ---- the window's current disparities; a pixel of disparity 0 does not vote (src/PP.cpp:167) ----
 #pragma unroll

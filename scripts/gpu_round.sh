@@ -38,7 +38,7 @@ python - <<PY
 import json,glob
 for f in sorted(glob.glob("$OUT/bench_*.json")):
     try:
-        j=json.loads(open(f).read().strip().splitlines()[-1])
+        j=json.loads([ln for ln in open(f).read().strip().splitlines() if ln.startswith("{")][-1])
         print(f.split('/')[-1], "%.3e vox/s"%j["value"], "%.3f ms"%j["ms_per_step"], {k:v["avg_ms"] for k,v in j["kernels"].items()}, "frac", j["roofline"]["frac"], "verified", j.get("verified_vs_single_gpu"), "cpu", (j.get("cpu_baseline") or {}).get("value"))
     except Exception as e:
         print(f, "ERR", e)

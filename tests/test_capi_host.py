@@ -83,7 +83,7 @@ def test_host_demo_builds_and_reports_no_device(built):
 
 
 def test_shard_bounds_cover():
-    from primestereomatch_amd.shard import shard_bounds
+    from shard_model import shard_bounds
     for D in (1, 5, 64, 255, 256):
         for G in (1, 2, 3, 8):
             b = shard_bounds(D, G)

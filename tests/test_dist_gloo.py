@@ -16,12 +16,13 @@ from conftest import ROOT
 
 def _worker(rank, world, port, D, H, W, q):
     sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from oracle import psm_oracle_py as O
-        from primestereomatch_amd.shard import pack_keys, shard_bounds, unpack_disp
+        from shard_model import pack_keys, shard_bounds, unpack_disp
         rng = np.random.default_rng(123)                       # same volume on every rank
         vol = rng.integers(0, 5, size=(2, D, H, W)).astype(np.float32)   # many ties
         vol[0, :, 0, 0] = np.nan
@@ -65,7 +66,7 @@ def test_allgather_min_reproduces_wta(world, D):
 
 
 def test_pack_keys_order():
-    from primestereomatch_amd.shard import pack_keys, unpack_disp
+    from shard_model import pack_keys, unpack_disp
     c = np.array([np.inf, 1.0, 1.0, -2.0, 0.0, -0.0, 3e-39], np.float32)
     d = np.array([0, 5, 4, 9, 7, 6, 2], np.int32)
     k = pack_keys(c, d)

@@ -105,6 +105,39 @@ def test_create_rejects_what_the_kernels_cannot_address(psm):
     assert b"too large" in lib.psm_last_error(None) or b"8192" in lib.psm_last_error(None)
 
 
+def test_merge_ctx_checks_the_shards(psm):
+    """psm_disp_merge_ctx must refuse shards that have not run their partial WTA for this frame or that do not
+    tile [0, D)."""
+    from primestereomatch_amd import capi
+    rng = np.random.default_rng(2)
+    l = rng.integers(0, 256, (24, 40, 3), dtype=np.uint8)
+    r = np.roll(l, 2, axis=1)
+    D = 12
+    shards = [psm.DispEst(l, r, D, d_range=(0, 5)), psm.DispEst(l, r, D, d_range=(5, 12))]
+    try:
+        for s in shards:
+            s.CostConst_GPU(); s.CostFilter_GPU()
+        shards[0].DispSelect_partial()
+        with pytest.raises(capi.PsmError):
+            shards[0].DispSelect_merge_ctx(shards)            # shard 1 has no minima yet
+        shards[1].DispSelect_partial()
+        with pytest.raises(capi.PsmError):
+            shards[0].DispSelect_merge_ctx(shards[:1])        # slices 5..11 missing
+        with pytest.raises(capi.PsmError):
+            shards[0].DispSelect_merge_ctx([shards[0], shards[1], shards[1]])   # slices held twice
+        shards[0].DispSelect_merge_ctx(shards)
+        with psm.DispEst(l, r, D) as whole:
+            whole.CostConst_GPU(); whole.CostFilter_GPU(); whole.DispSelect_GPU()
+            assert np.array_equal(whole.lDisMap, shards[0].lDisMap) and np.array_equal(whole.rDisMap, shards[0].rDisMap)
+        # a new frame invalidates the minima again
+        shards[1].CostConst_GPU()
+        with pytest.raises(capi.PsmError):
+            shards[0].DispSelect_merge_ctx(shards)
+    finally:
+        for s in shards:
+            s.close()
+
+
 # ------------------------------------------------------------------------------------------
 # HIP path vs the oracle in OpenCV's own summation order
 # ------------------------------------------------------------------------------------------
