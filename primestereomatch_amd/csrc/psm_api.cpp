@@ -53,6 +53,7 @@ struct psm_ctx {
     int gather_ranks = 0;
     uint8_t *maps = nullptr;            // [2][H][W]
     uint8_t *valid = nullptr;           // [2][H][W]
+    uint8_t *pinned = nullptr;          // [2][H][W] page-locked bounce buffer for map / mask downloads (on first use)
     int *wm = nullptr;                  // psm_wgt_median scratch: nxt[H][W+1], prog[H], err[1]; allocated on first use
     uint8_t *p4[2] = {nullptr, nullptr};  // PSM_U8 only: {c0,c1,c2,grad} words
     float *soa[2] = {nullptr, nullptr};   // planar copies of g1..g4 (14 planes) for the two-columns-per-lane filter
@@ -196,6 +197,7 @@ void free_all(psm_ctx *c)
     (void)hipFree(c->gather);
     (void)hipFree(c->maps);
     (void)hipFree(c->valid);
+    if (c->pinned) (void)hipHostFree(c->pinned);
     (void)hipFree(c->wm);
     (void)hipFree(c->gf_scratch);
     (void)hipFree(c->gf_cnt);
@@ -856,14 +858,30 @@ static int copy_maps_out(psm_ctx *c, const uint8_t *dev, uint8_t *lmap, uint8_t 
     const size_t HW = (size_t)c->W * c->H;
     if (stride == 0) stride = c->W;
     if (stride < (size_t)c->W) return fail(c, "map stride %zu < width %d", stride, c->W);
-    if (stride == (size_t)c->W) {   // dense host maps: one linear copy each (the 2-D path is several times slower to pageable memory)
-        if (lmap) PSM_HIP(c, hipMemcpyAsync(lmap, dev, HW, hipMemcpyDeviceToHost, c->stream));
-        if (rmap) PSM_HIP(c, hipMemcpyAsync(rmap, dev + HW, HW, hipMemcpyDeviceToHost, c->stream));
-    } else {
+    if (!lmap && !rmap) return 0;
+    // device -> page-locked bounce buffer (one DMA at link speed) -> the caller's (pageable, possibly strided) rows.
+    // A direct copy into pageable memory took 6-16 ms for two 1080p maps; this way it is ~0.5 ms.
+    if (!c->pinned && hipHostMalloc((void **)&c->pinned, 2 * HW, hipHostMallocDefault) != hipSuccess) {
+        (void)hipGetLastError();
+        c->pinned = nullptr;
+    }
+    if (!c->pinned) {   // no page-locked memory: plain copies
         if (lmap) PSM_HIP(c, hipMemcpy2DAsync(lmap, stride, dev, c->W, c->W, c->H, hipMemcpyDeviceToHost, c->stream));
         if (rmap) PSM_HIP(c, hipMemcpy2DAsync(rmap, stride, dev + HW, c->W, c->W, c->H, hipMemcpyDeviceToHost, c->stream));
+        PSM_HIP(c, hipStreamSynchronize(c->stream));
+        return 0;
     }
-    if (lmap || rmap) PSM_HIP(c, hipStreamSynchronize(c->stream));
+    if (lmap && rmap) PSM_HIP(c, hipMemcpyAsync(c->pinned, dev, 2 * HW, hipMemcpyDeviceToHost, c->stream));
+    else if (lmap) PSM_HIP(c, hipMemcpyAsync(c->pinned, dev, HW, hipMemcpyDeviceToHost, c->stream));
+    else PSM_HIP(c, hipMemcpyAsync(c->pinned + HW, dev + HW, HW, hipMemcpyDeviceToHost, c->stream));
+    PSM_HIP(c, hipStreamSynchronize(c->stream));
+    uint8_t *dst[2] = {lmap, rmap};
+    for (int s2 = 0; s2 < 2; ++s2) {
+        if (!dst[s2]) continue;
+        const uint8_t *src = c->pinned + s2 * HW;
+        if (stride == (size_t)c->W) memcpy(dst[s2], src, HW);
+        else for (int y = 0; y < c->H; ++y) memcpy(dst[s2] + (size_t)y * stride, src + (size_t)y * c->W, (size_t)c->W);
+    }
     return 0;
 }
 

@@ -40,6 +40,36 @@ def test_headline_line_has_the_contract_keys():
     assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["unit"] == j["unit"]
 
 
+def _line_r(rnd, name):
+    path = os.path.join(ROOT, "profiles", rnd, name)
+    if not os.path.exists(path):
+        pytest.skip(name + " not committed")
+    return json.loads([ln for ln in open(path).read().strip().splitlines() if ln.startswith("{")][-1])
+
+
+def test_round2_lines():
+    j = _line_r("r02", "bench_c4_n1.json")
+    W, H, D = j["config"]["W"], j["config"]["H"], j["config"]["D"]
+    assert (W, H, D) == (1920, 1080, 256) and j["dtype"] == "f32" and j["n_gpus"] == 1 and j["vs_baseline"] is None
+    assert abs(j["value"] - 2.0 * W * H * D / (j["ms_per_step"] * 1e-3)) / j["value"] < 1e-6
+    r = j["roofline"]
+    assert r["bound"] == "hbm" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    assert abs(r["achieved"] - r["alg_bytes_per_launch"] / (r["avg_launch_ms"] * 1e-3) / 1e9) / r["achieved"] < 1e-3
+    assert r["alg_bytes_per_launch"] == 48.0 * 2 * W * H * D          # select mode: one launch = both volumes, CVC + CVF + WTA
+    assert r["traffic"] > 0 and r["traffic"] < r["alg_bytes_per_launch"] and "traffic_source" in r and "note" in r
+    assert j["verified_vs_single_gpu"] is True and j["median_ms_per_step"] > 0
+    assert j["pcie"]["h2d_ms"] > 0 and j["pcie"]["d2h_ms"] > 0
+    c = j["cpu_baseline"]
+    assert c["kind"] == "port" and c["cores"] == 8 and c["unit"] == j["unit"] and c["value"] > 0
+    # every other config carries its CPU baseline too (VERDICT r1 missing #4), and the 8-bit configs exist
+    for name, dt in (("bench_c3_n1.json", "f32"), ("bench_c2_n1.json", "f32"), ("bench_c1_u8_n1.json", "u8"), ("bench_c1x_u8_n1.json", "u8")):
+        k = _line_r("r02", name)
+        assert k["dtype"] == dt and k["cpu_baseline"]["value"] > 0 and k["verified_vs_single_gpu"] is True, name
+    for name in ("bench_c4_dist_world1.json", "bench_c4_dist_world1_allgather.json", "bench_c4_dist_world1_nopipeline.json"):
+        k = _line_r("r02", name)
+        assert k["verified_vs_single_gpu"] is True and k["scaling"] == "strong", name
+
+
 def test_distributed_lines_were_checked_against_the_single_gpu_run():
     for name in ("bench_c4_dist_world1.json", "bench_c4_dist_world1_allgather.json", "bench_c4_dist_world1_nooverlap.json"):
         j = _line(name)
