@@ -272,6 +272,7 @@ def main():
         de.setInputImages(l, r)              # H2D of the u8 pair (blocking)
         h2d = 1e3 * (time.perf_counter() - ts)
         step(); sync()                       # maps of this pair on the device again
+        de.download_maps()                   # (first call allocates the library's page-locked bounce buffer)
         ts = time.perf_counter()
         de.download_maps()                   # D2H of the two u8 maps (blocking)
         d2h = 1e3 * (time.perf_counter() - ts)

@@ -69,7 +69,10 @@ enum {
                                    select-mode kernel updates one shared plane of packed keys per volume by 64-bit
                                    atomicMin (default: private minima planes + a reduction kernel); 524288 = resident
                                    workgroups take the slices of their (column group, segment) pair dynamically from a
-                                   device counter (default: static chunks of slices per workgroup).
+                                   device counter (default: static chunks of slices per workgroup); 1048576 / 2097152 =
+                                   force / disable the two-phase selection of psm_cost_filter (default: on from 160
+                                   local slices - every 6th slice through the minima planes, the rest against the
+                                   seeded key plane).
                                    No flag changes any result. */
 };
 

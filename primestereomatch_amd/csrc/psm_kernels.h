@@ -57,18 +57,19 @@ PcPlan pc_plan(int W, int rows, int Dloc, int seg_rows_opt, int mode);
 PcPlan pc_plan_cols(int W, int rows, int Dloc, int seg_rows_opt, int mode, int cols);
 void launch_cvf_select(hipStream_t s, March m, const float *vin, Guidance g, int W, int H, int Dloc, const float4 *g1_other,
                        int d_begin, int cvc_mode, void *scratch, int *cnt = nullptr, const uint8_t *p4_own = nullptr,
-                       const uint8_t *p4_other = nullptr);
+                       const uint8_t *p4_other = nullptr, int sel = 0, int step = 1);
 void launch_chunk_min(hipStream_t s, March m, int W, int H, int Dloc, void *scratch, long long *keys, uint8_t *map, int dynamic = 0);
 // Select mode with a shared key plane per volume (default): the packed minima over the local slices go straight to keys
 // (H*W per volume; both-volumes form: [2][H][W]) by 64-bit atomicMin - no chunk planes, no reduction kernel.
 void launch_cvf_select_keys(hipStream_t s, March m, const float *vin, Guidance g, int W, int H, int Dloc, const float4 *g1_other,
-                            int d_begin, int cvc_mode, long long *keys, const uint8_t *p4_own = nullptr, const uint8_t *p4_other = nullptr);
+                            int d_begin, int cvc_mode, long long *keys, const uint8_t *p4_own = nullptr, const uint8_t *p4_other = nullptr,
+                            int init = 1, int sel = 0, int step = 1);
 void launch_cvf_select_keys2(hipStream_t s, March m, const Guidance *g, int W, int H, int Dloc, int d_begin, long long *keys,
-                             const uint8_t *const *p4 = nullptr);
+                             const uint8_t *const *p4 = nullptr, int init = 1, int sel = 0, int step = 1);
 // both volumes per launch (costs on the fly): g[0] / g[1] = guidance of the left / right image; scratch: 2 x scratch_bytes();
 // keys / map: [2][H][W]
 void launch_cvf_select2(hipStream_t s, March m, const Guidance *g, int W, int H, int Dloc, int d_begin, void *scratch, int *cnt = nullptr,
-                        const uint8_t *const *p4 = nullptr);
+                        const uint8_t *const *p4 = nullptr, int sel = 0, int step = 1);
 void launch_chunk_min2sides(hipStream_t s, March m, int W, int H, int Dloc, void *scratch, long long *keys, uint8_t *map, int dynamic = 0);
 // Select mode with two columns per lane and the channels split over the waves (psm_q2.hip): the default product kernel
 // when the costs are built on the fly (cvc_mode 1 / 2).  scratch: q2_plan(...).scratch_bytes() bytes.

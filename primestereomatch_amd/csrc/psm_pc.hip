@@ -125,7 +125,16 @@ struct PcSide {
 struct PcDyn {
     int *cnt;      // one zeroed counter per (side, pair)
     int NW;
+    // Which local slices this launch covers (Dloc = their number): sel 0 all (index i = local slice i); sel 1 every
+    // step-th slice (i -> i * step); sel 2 the others (i -> (i / (step-1)) * step + i % (step-1) + 1).  Two-phase
+    // selection: a first launch reduces every step-th slice to the key plane, a MODE 2 launch then runs the rest
+    // against that plane - its consumer lanes find a tight bound there and issue an atomic only a few times per pixel.
+    int sel, step;
 };
+__device__ __forceinline__ int pc_slice(const PcDyn &o, int i)
+{
+    return o.sel == 1 ? i * o.step : (o.sel == 2 ? (i / (o.step - 1)) * o.step + i % (o.step - 1) + 1 : i);
+}
 
 // CVC = 0: the cost slice is read from `vin`.  CVC = 1 (left volume) / 2 (right volume): the cost volume is never
 // materialised - the producer waves evaluate myCostGrd (src/CVC.cpp:18-39) for their input column on the fly from the
@@ -217,8 +226,8 @@ __global__ __launch_bounds__(64 * (PcLayout<MODE>::NA + PcLayout<MODE>::NB)) PSM
         const int xa = xa0 + lane;                    // model column of this lane
         const int xac = xa < 0 ? 0 : (xa > W - 1 ? W - 1 : xa);
         const bool mvalid = lane < PC_OUT_A;
-        const float *vd = vin + (size_t)d * HW;
-        const int dg = d_begin + d;                   // global disparity of this slice
+        const float *vd = vin + (size_t)pc_slice(dyn, d) * HW;
+        const int dg = d_begin + pc_slice(dyn, d);    // global disparity of this slice
         // buildCV_left: partner x-d while x >= d; buildCV_right: partner x+d while x < W-d (src/CVC.cpp:135-146,165-176)
         const bool inb = right ? (ci < W - dg) : (ci >= dg);
         const int cpart = right ? min(ci + dg, W - 1) : max(ci - dg, 0);
@@ -310,7 +319,7 @@ __global__ __launch_bounds__(64 * (PcLayout<MODE>::NA + PcLayout<MODE>::NB)) PSM
         mc = mc < 0 ? 0 : (mc > PC_MCOLS - 1 ? PC_MCOLS - 1 : mc);
         const int xb = xb0 + lane;                    // output column of this lane
         const int xbc = min(xb, W - 1);
-        float *od = vout + (MODE == 0 ? (size_t)d * HW : 0);
+        float *od = vout + (MODE == 0 ? (size_t)pc_slice(dyn, d) * HW : 0);
         const int amax = 4 * nbA - 1;
         VTree t0 = {}, t1 = {}, t2 = {}, t3 = {};
         float o1x[4], o1y[4], o1z[4];                 // g1.xyz at (output row, output column), one batch ahead
@@ -345,7 +354,7 @@ __global__ __launch_bounds__(64 * (PcLayout<MODE>::NA + PcLayout<MODE>::NB)) PSM
     }
         const __amdgpu_buffer_rsrc_t rG1 = pc_rsrc(G1, (unsigned)HW * 16u);
         const int vxb = xbc * 16;
-        const int dg = d_begin + d;
+        const int dg = d_begin + pc_slice(dyn, d);
         const bool lane_out = lane < bwidth && xb < W;   // this lane owns an output pixel
 #define PSM_ISSUE_PB(SLOT, J)                                                           \
     {                                                                                   \
@@ -681,7 +690,7 @@ void launch_cvf_fused(hipStream_t s, March m, const float *vin, float *vout, Gui
 #define PSM_LAUNCH_PC(V4, CV)                                                                                              \
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_cvf_pc<V4, CV, 0>), dim3(nblocks), blk, 0, s, vin, vout, (const float4 *)gd.g1,   \
                        (const float4 *)gd.g2, (const float4 *)gd.g3, (const float2 *)gd.g4, W, H, Dloc, pl.ngroups, pl.nsegs, \
-                       pl.seg_rows, ybeg, yend, g1_other, d_begin, 1, (float *)nullptr, (unsigned *)nullptr, 0, PcSide{}, PcDyn{nullptr, 0})
+                       pl.seg_rows, ybeg, yend, g1_other, d_begin, 1, (float *)nullptr, (unsigned *)nullptr, 0, PcSide{}, PcDyn{nullptr, 0, 0, 1})
     const bool v4 = (W & 3) == 0;
     if (cvc_mode == 1) { if (v4) PSM_LAUNCH_PC(true, 1); else PSM_LAUNCH_PC(false, 1); }
     else if (cvc_mode == 2) { if (v4) PSM_LAUNCH_PC(true, 2); else PSM_LAUNCH_PC(false, 2); }
@@ -690,10 +699,11 @@ void launch_cvf_fused(hipStream_t s, March m, const float *vin, float *vout, Gui
 }
 
 void launch_cvf_select(hipStream_t s, March m, const float *vin, Guidance gd, int W, int H, int Dloc, const float4 *g1_other,
-                       int d_begin, int cvc_mode, void *scratch, int *cnt, const uint8_t *p4_own, const uint8_t *p4_other)
+                       int d_begin, int cvc_mode, void *scratch, int *cnt, const uint8_t *p4_own, const uint8_t *p4_other, int sel, int step)
 {   // p4_own != NULL (cvc_mode 1 / 2 only): 8-bit char mode; cnt != NULL: dynamic slice distribution (npairs ints, zeroed here)
+    // Dloc = number of slices of this launch, (sel, step) = which ones (PcDyn)
     const PcPlan pl = pc_plan(W, H, Dloc, m.seg_rows, cnt ? 5 : 1);
-    const PcDyn dyn = {cnt, pl.NW};
+    const PcDyn dyn = {cnt, pl.NW, sel, step};
     if (cnt) (void)hipMemsetAsync(cnt, 0, sizeof(int) * pl.ngroups * pl.nsegs, s);
     float *kcost = (float *)scratch;                                           // nchunks * rec_per_chunk float4
     unsigned *kdisp = (unsigned *)(kcost + 4 * pl.rec_per_chunk * pl.nchunks);  // nchunks * rec_per_chunk uchar4
@@ -716,17 +726,17 @@ void launch_cvf_select(hipStream_t s, March m, const float *vin, Guidance gd, in
 
 // Select mode with a shared key plane (MODE 2): keys[H*W] of this volume receives the packed minima over the local slices.
 void launch_cvf_select_keys(hipStream_t s, March m, const float *vin, Guidance gd, int W, int H, int Dloc, const float4 *g1_other,
-                            int d_begin, int cvc_mode, long long *keys, const uint8_t *p4_own, const uint8_t *p4_other)
-{
+                            int d_begin, int cvc_mode, long long *keys, const uint8_t *p4_own, const uint8_t *p4_other, int init, int sel, int step)
+{   // init: start from key(+inf, 0); otherwise continue from what `keys` holds (second phase of the two-phase selection)
     const PcPlan pl = pc_plan(W, H, Dloc, m.seg_rows, 3);
     const size_t HW = (size_t)W * H;
-    hipLaunchKernelGGL(k_fill_keys, dim3((unsigned)((HW + 255) / 256)), dim3(256), 0, s, keys, HW);
+    if (init) hipLaunchKernelGGL(k_fill_keys, dim3((unsigned)((HW + 255) / 256)), dim3(256), 0, s, keys, HW);
     const int nblocks = 8 * ((pl.ngroups * pl.nsegs * Dloc + 7) / 8);
     const dim3 blk(64 * (PcLayout<2>::NA + PcLayout<2>::NB));
 #define PSM_LAUNCH_K(CV, U8V, A0, A1)                                                                                       \
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_cvf_pc<false, CV, 2, U8V>), dim3(nblocks), blk, 0, s, A0, A1, (const float4 *)gd.g1, \
                        (const float4 *)gd.g2, (const float4 *)gd.g3, (const float2 *)gd.g4, W, H, Dloc, pl.ngroups, pl.nsegs, \
-                       pl.seg_rows, 0, H, g1_other, d_begin, 1, (float *)keys, (unsigned *)nullptr, 0, PcSide{}, PcDyn{nullptr, 0})
+                       pl.seg_rows, 0, H, g1_other, d_begin, 1, (float *)keys, (unsigned *)nullptr, 0, PcSide{}, PcDyn{nullptr, 0, sel, step})
     if (p4_own && cvc_mode != 0) {
         if (cvc_mode == 1) PSM_LAUNCH_K(1, true, (const float *)p4_own, (float *)const_cast<uint8_t *>(p4_other));
         else PSM_LAUNCH_K(2, true, (const float *)p4_own, (float *)const_cast<uint8_t *>(p4_other));
@@ -738,11 +748,11 @@ void launch_cvf_select_keys(hipStream_t s, March m, const float *vin, Guidance g
 
 // ... both volumes in one launch: keys[2][H][W]
 void launch_cvf_select_keys2(hipStream_t s, March m, const Guidance *g, int W, int H, int Dloc, int d_begin, long long *keys,
-                             const uint8_t *const *p4)
+                             const uint8_t *const *p4, int init, int sel, int step)
 {
     const PcPlan pl = pc_plan(W, H, Dloc, m.seg_rows, 4);
     const size_t HW = (size_t)W * H;
-    hipLaunchKernelGGL(k_fill_keys, dim3((unsigned)((2 * HW + 255) / 256)), dim3(256), 0, s, keys, 2 * HW);
+    if (init) hipLaunchKernelGGL(k_fill_keys, dim3((unsigned)((2 * HW + 255) / 256)), dim3(256), 0, s, keys, 2 * HW);
     const int nblocks = 8 * ((pl.ngroups * pl.nsegs * Dloc + 7) / 8);
     const dim3 blk(64 * (PcLayout<2>::NA + PcLayout<2>::NB));
     const PcSide s1 = {(const float4 *)g[1].g1, (const float4 *)g[1].g2, (const float4 *)g[1].g3, (const float2 *)g[1].g4, (const float4 *)g[0].g1,
@@ -750,11 +760,11 @@ void launch_cvf_select_keys2(hipStream_t s, March m, const Guidance *g, int W, i
     if (p4)
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_cvf_pc<false, 3, 2, true>), dim3(nblocks, 2), blk, 0, s, (const float *)p4[0], (float *)const_cast<uint8_t *>(p4[1]),
                            (const float4 *)g[0].g1, (const float4 *)g[0].g2, (const float4 *)g[0].g3, (const float2 *)g[0].g4, W, H, Dloc, pl.ngroups,
-                           pl.nsegs, pl.seg_rows, 0, H, (const float4 *)g[1].g1, d_begin, 1, (float *)keys, (unsigned *)nullptr, 0, s1, PcDyn{nullptr, 0});
+                           pl.nsegs, pl.seg_rows, 0, H, (const float4 *)g[1].g1, d_begin, 1, (float *)keys, (unsigned *)nullptr, 0, s1, PcDyn{nullptr, 0, sel, step});
     else
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_cvf_pc<false, 3, 2, false>), dim3(nblocks, 2), blk, 0, s, (const float *)nullptr, (float *)nullptr,
                            (const float4 *)g[0].g1, (const float4 *)g[0].g2, (const float4 *)g[0].g3, (const float2 *)g[0].g4, W, H, Dloc, pl.ngroups,
-                           pl.nsegs, pl.seg_rows, 0, H, (const float4 *)g[1].g1, d_begin, 1, (float *)keys, (unsigned *)nullptr, 0, s1, PcDyn{nullptr, 0});
+                           pl.nsegs, pl.seg_rows, 0, H, (const float4 *)g[1].g1, d_begin, 1, (float *)keys, (unsigned *)nullptr, 0, s1, PcDyn{nullptr, 0, sel, step});
 }
 
 void launch_chunk_min(hipStream_t s, March m, int W, int H, int Dloc, void *scratch, long long *keys, uint8_t *map, int dynamic)
@@ -770,11 +780,11 @@ void launch_chunk_min(hipStream_t s, March m, int W, int H, int Dloc, void *scra
 // Both volumes in one launch each (costs built on the fly): left volume = (g[0], other g[1].g1), right = (g[1], other g[0].g1);
 // scratch: 2 x pc_plan(...).scratch_bytes(); keys / map: [2][H][W].
 void launch_cvf_select2(hipStream_t s, March m, const Guidance *g, int W, int H, int Dloc, int d_begin, void *scratch, int *cnt,
-                        const uint8_t *const *p4)
+                        const uint8_t *const *p4, int sel, int step)
 {   // p4 != NULL: 8-bit char mode, p4[0] / p4[1] = byte planes {c0,c1,c2,grad} of the left / right image
     // cnt != NULL: dynamic slice distribution (2 * npairs ints, zeroed here)
     const PcPlan pl = pc_plan(W, H, Dloc, m.seg_rows, cnt ? 6 : 2);
-    const PcDyn dyn = {cnt, pl.NW};
+    const PcDyn dyn = {cnt, pl.NW, sel, step};
     if (cnt) (void)hipMemsetAsync(cnt, 0, sizeof(int) * 2 * pl.ngroups * pl.nsegs, s);
     float *kcost0 = (float *)scratch;
     unsigned *kdisp0 = (unsigned *)(kcost0 + 4 * pl.rec_per_chunk * pl.nchunks);

@@ -1,10 +1,9 @@
 #!/bin/bash
 cd $GRAFT_REPO_ROOT
-run() { echo "== $*"; "$@" 2>/dev/null | python -c "import json,sys; j=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('  %.3f ms med %.3f'%(j['ms_per_step'], j['median_ms_per_step']), {k:v['avg_ms'] for k,v in j['kernels'].items()})"; }
+run() { echo "== $*"; timeout 120 "$@" 2>/dev/null | python -c "import json,sys; j=json.loads([l for l in sys.stdin.read().strip().splitlines() if l.startswith('{')][-1]); print('  %.3f ms med %.3f'%(j['ms_per_step'], j['median_ms_per_step']), {k:v['avg_ms'] for k,v in j['kernels'].items()}, j.get('verified_vs_single_gpu'), j['roofline']['frac'])"; }
 B="python bench.py --no-cpu-baseline --steps 20 --warmup 3"
-run $B
-run $B --flags 1048576
-run $B
-run $B --flags 1048576
-run $B --config c3
-run $B --config c3 --flags 1048576
+timeout 1200 python -m pytest tests -m gpu -q -x -p no:cacheprovider --timeout=300 2>&1 | tail -4
+run $B --verify
+run $B --config c1x --verify
+run $B --config c1x --flags 2097152 --verify
+run $B --config c5 --steps 3 --verify

@@ -474,7 +474,8 @@ def test_cpp_dispest_demo(psm, oracle, golden, tmp_path, mode, float_input):
     assert np.array_equal(lpp, exp)
 
 
-@pytest.mark.parametrize("flags", [0, 256, 128, 128 + 64, 16, 16 + 1, 16 + 2, 16 + 4, 512, 512 + 128, 4096, 8192, 8192 + 128, 16384, 16384 + 128, 65536, 262144, 262144 + 65536, 524288, 524288 + 65536])
+@pytest.mark.parametrize("flags", [0, 256, 128, 128 + 64, 16, 16 + 1, 16 + 2, 16 + 4, 512, 512 + 128, 4096, 8192, 8192 + 128, 16384, 16384 + 128, 65536, 262144, 262144 + 65536, 524288, 524288 + 65536,
+                                   1048576, 1048576 + 128, 2097152])
 def test_tuning_flags_do_not_change_results(psm, oracle, flags):
     """PSM_OPT_FLAGS only changes store policy / block traversal / CVC store width."""
     from primestereomatch_amd import capi, synth
@@ -559,6 +560,47 @@ def test_per_side_calls_equal_whole_stage_calls(psm, oracle):
             s.CostConst_GPU()
             s.CostFilter_side(0); s.DispSelect_partial_side(0)
             s.CostFilter_side(1); s.DispSelect_partial_side(1)
+        shards[0].DispSelect_merge_ctx(shards)
+        assert np.array_equal(shards[0].lDisMap, ref["ldisp"]) and np.array_equal(shards[0].rDisMap, ref["rdisp"])
+    finally:
+        for s in shards:
+            s.close()
+
+
+@pytest.mark.parametrize("W,H,D,dtype,flags", [(260, 40, 200, "f32", 0), (260, 40, 200, "f32", 2097152), (230, 70, 37, "f32", 1048576),
+                                               (260, 40, 200, "u8", 0), (214, 33, 19, "u8", 1048576), (108, 90, 2, "f32", 1048576),
+                                               (108, 20, 7, "f32", 1048576)])
+def test_two_phase_selection(psm, oracle, W, H, D, dtype, flags):
+    """psm_cost_filter's two-phase selection (default from 160 local slices; flag 1048576 forces it, 2097152 disables it):
+    every 6th slice through the minima planes, the others against the seeded key plane.  Same maps as DispSel::CVSelect
+    over the whole volume (src/DispSel.cpp:96-104), and the volumes re-materialise bit-exactly afterwards."""
+    from primestereomatch_amd import capi, synth
+    l, r, _ = synth.make_pair(W, H, D, seed=W + D)
+    if dtype == "u8":
+        ref = oracle.pipeline_u8(l, r, D, threads=8)
+    else:
+        ref = oracle.pipeline_f32(l, r, D, threads=8, want_volumes=True)
+    with psm.DispEst(l, r, D, dtype=dtype) as de:
+        de.set_option(capi.PSM_OPT_FLAGS, flags)
+        de.CostConst_GPU(); de.CostFilter_GPU(); de.DispSelect_GPU()
+        assert np.array_equal(de.lDisMap, ref["ldisp"]) and np.array_equal(de.rDisMap, ref["rdisp"])
+        if dtype == "f32":
+            assert np.array_equal(de.download_volume(0), ref["lvol"]) and np.array_equal(de.download_volume(1), ref["rvol"])
+            de.DispSelect_GPU()             # WTA over the materialised volumes: same maps again
+            assert np.array_equal(de.lDisMap, ref["ldisp"]) and np.array_equal(de.rDisMap, ref["rdisp"])
+
+
+def test_two_phase_selection_on_shards(psm, oracle):
+    """Forced two-phase selection on disparity shards with d0 != 0: partial minima merge to the whole-volume maps."""
+    from primestereomatch_amd import capi, synth
+    W, H, D = 200, 48, 45
+    l, r, _ = synth.make_pair(W, H, D, seed=11)
+    ref = oracle.pipeline_f32(l, r, D, threads=8)
+    shards = [psm.DispEst(l, r, D, d_range=rg) for rg in ((0, 13), (13, 14), (14, 45))]
+    try:
+        for s in shards:
+            s.set_option(capi.PSM_OPT_FLAGS, 1048576)
+            s.CostConst_GPU(); s.CostFilter_GPU(); s.DispSelect_partial()
         shards[0].DispSelect_merge_ctx(shards)
         assert np.array_equal(shards[0].lDisMap, ref["ldisp"]) and np.array_equal(shards[0].rDisMap, ref["rdisp"])
     finally:
