@@ -295,9 +295,12 @@ def main():
         if n:
             kern[nm] = {"avg_ms": tot / n, "launches_per_step": n / prof_steps}
     de.set_option(capi.PSM_OPT_PROFILE, 0)
-    vox_per_launch = float(W) * H * (d1 - d0)   # one launch = all local slices of one side ...
-    if kern.get("cvf_fused", {}).get("launches_per_step", 2) < 1.5:
-        vox_per_launch *= 2.0                    # ... or of both sides (psm_cost_filter's default: both volumes per launch)
+    # voxels per launch of the filter kernel = the step's 2*W*H*Dloc over its launches per step: 1 (both volumes in one
+    # launch), 2 (one launch per volume - or, from 160 local slices up, the two phases of the select form: every 6th slice
+    # of both volumes through the minima planes, then the other slices of both volumes against the key plane; the two
+    # are instantiations of the same kernel, so avg_launch_ms is their mean and alg bytes / launch the mean as well)
+    lps = max(1, round(kern.get("cvf_fused", {}).get("launches_per_step", 2)))   # (other filter forms: one side per launch)
+    vox_per_launch = 2.0 * W * H * (d1 - d0) / lps
     if args.fgf:   # per launch pair (setup + model + smooth + apply of one side): cost read at 1/s^2, model planes, q write
         ALG_BYTES["cvf_fgf"] = 4.0 + 68.0 / (args.fgf * args.fgf)
     # the default fused kernel also builds the costs and runs the WTA over its slices ("select" mode): it is credited
@@ -305,10 +308,13 @@ def main():
     select_mode = not args.fgf and args.variant == 0 and not (max(args.flags, 0) & (16 | 512 | 8192))
     if select_mode:
         ALG_BYTES["cvf_fused"] = ALG_BYTES["pipeline"]
+    fl = max(args.flags, 0)
+    two_phase = select_mode and not (fl & (2097152 | 524288 | 262144 | 65536 | 16384)) and ((d1 - d0) >= 160 or (fl & 1048576))
     dom = max(("cvf_fgf",) if args.fgf else ("cvf_fused", "cvf_a", "cvf_b"), key=lambda k: kern.get(k, {"avg_ms": 0})["avg_ms"])
     dom_ms = kern[dom]["avg_ms"]
     achieved = ALG_BYTES[dom] * vox_per_launch / (dom_ms * 1e-3) / 1e9
-    roofline = {"bound": "hbm", "kernel": "k_cvf_pc (select mode: CVC+CVF+WTA fused)" if (select_mode and dom == "cvf_fused") else "k_" + dom,
+    roofline = {"bound": "hbm", "kernel": ("k_cvf_pc (select mode: CVC+CVF+WTA fused" + (", two phases = two launches per step)" if two_phase else ")"))
+                if (select_mode and dom == "cvf_fused") else "k_" + dom,
                 "alg_bytes_per_voxel": ALG_BYTES[dom], "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
                 "alg_bytes_per_launch": ALG_BYTES[dom] * vox_per_launch, "avg_launch_ms": round(dom_ms, 4),

@@ -189,12 +189,20 @@ __global__ __launch_bounds__(64) void k_guide_march(const float4 *g1, int W, int
     const int i1 = ((lane + 1) & 63) << 2, i2 = ((lane + 2) & 63) << 2, i4 = ((lane + 4) & 63) << 2;
     (void)i1;
     VTree t[9] = {};
-    float4 gn = g1[(size_t)r101c(ybase, H) * W + cs];
+    // the image rows of the next batch of four steps are in flight while this batch computes: one step is ~400 cycles of
+    // VALU work, less than the load latency, so a one-row lookahead left every step waiting for memory
+    float4 gq[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) gq[k] = g1[(size_t)r101c(ybase + k, H) * W + cs];
     for (int i = 0; i < n; i += 4) {
+        float4 gc[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) gc[k] = gq[k];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) gq[k] = g1[(size_t)r101c(ybase + i + 4 + k, H) * W + cs];
 #define PSM_STEP_G(K)                                                                              \
     {                                                                                              \
-        const float4 g = gn;                                                                       \
-        gn = g1[(size_t)r101c(ybase + i + K + 1, H) * W + cs];                                     \
+        const float4 g = gc[K];                                                                    \
         float v[9] = {g.x, g.y, g.z, __fmul_rn(g.x, g.x), __fmul_rn(g.x, g.y), __fmul_rn(g.x, g.z), \
                       __fmul_rn(g.y, g.y), __fmul_rn(g.y, g.z), __fmul_rn(g.z, g.z)};              \
         float m[9];                                                                                \
@@ -215,10 +223,11 @@ __global__ __launch_bounds__(64) void k_guide_march(const float4 *g1, int W, int
 void launch_guidance(hipStream_t s, Guidance g, double *hs9, int W, int H, int two_pass, const Guidance *second)
 {   // second != NULL (single-pass form only): the guidance of both images in one launch
     if (!two_pass) {
-        // one wave per (strip, segment): aim for ~2000 waves (two per SIMD at 178 VGPRs), 16..64 rows each
+        // one wave per (strip, segment): ~2048 waves over both images = one resident round (two per SIMD at 199 VGPRs), 8..64 rows each
         const int nstrips = (W + 55) / 56;
-        int seg_rows = (int)(((long)H * nstrips + 2047) / 2048);
-        seg_rows = seg_rows < 16 ? 16 : (seg_rows > 64 ? 64 : seg_rows);
+        const int waves = second ? 1024 : 2048;                  // per image
+        int seg_rows = 8;                                        // shortest segment whose waves fit one round
+        while (seg_rows < 64 && nstrips * ((H + seg_rows - 1) / seg_rows) > waves) ++seg_rows;
         const int nsegs = (H + seg_rows - 1) / seg_rows;
         hipLaunchKernelGGL(k_guide_march, dim3(nstrips * nsegs, second ? 2 : 1), dim3(64), 0, s, (const float4 *)g.g1, W, H, nstrips, seg_rows, g.g2, g.g3, g.g4,
                            second ? *second : Guidance{});
