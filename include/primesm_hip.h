@@ -72,7 +72,8 @@ enum {
                                    device counter (default: static chunks of slices per workgroup); 1048576 / 2097152 =
                                    force / disable the two-phase selection of psm_cost_filter (default: on from 160
                                    local slices - every 6th slice through the minima planes, the rest against the
-                                   seeded key plane).
+                                   seeded key plane); 4194304 = psm_wgt_median runs its row-dataflow form only;
+                                   8388608 = at most 2 sweeps of its parallel form (test hook for the fall-back).
                                    No flag changes any result. */
 };
 
@@ -192,9 +193,15 @@ int psm_fill_invalid(psm_ctx *ctx, uint8_t *lmap, uint8_t *rmap, size_t stride);
  * last psm_lr_check marked invalid (the sequence of PP::processDM: lrCheck, fillInv, wgtMedian, src/PP.cpp:405-410).
  * Left map with the left image and the squared distances (:169-175), right map with the right image and the
  * square-rooted ones (:216-224).  Same result as the reference's single-threaded form: the map is filtered in place in
- * raster order, a filtered pixel sees the filtered pixels before it (run here as a row-dataflow pipeline).
+ * raster order, a filtered pixel sees the filtered pixels before it.  Run as parallel sweeps to the fixed point of that
+ * recursion (every sweep evaluates all pixels whose earlier window taps changed; it stops, at the reference's map, when
+ * a sweep changes nothing); falls back to a row-dataflow pipeline with the reference's own dependency chain if 96
+ * sweeps do not reach it (PSM_OPT_FLAGS 4194304: dataflow form only).
  * Needs W, H >= 9 (the reference's modulo wrap is undefined below that).  lmap/rmap (optional) receive the maps. */
 int psm_wgt_median(psm_ctx *ctx, uint8_t *lmap, uint8_t *rmap, size_t stride);
+/* What the last psm_wgt_median did, per map {left, right}: sweeps until the fixed point (-1: dataflow form) and pixel
+ * evaluations in total.  Either pointer may be NULL. */
+int psm_wgt_median_stats(psm_ctx *ctx, int sweeps[2], long long evals[2]);
 
 /* ---- debug / bench entry points (no counterpart in the reference) ---- */
 

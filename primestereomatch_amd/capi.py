@@ -49,6 +49,7 @@ SYMBOLS = [
     ("psm_lr_check", _i, [_vp, _vp, _vp, _sz]),
     ("psm_fill_invalid", _i, [_vp, _vp, _vp, _sz]),
     ("psm_wgt_median", _i, [_vp, _vp, _vp, _sz]),
+    ("psm_wgt_median_stats", _i, [_vp, _vp, _vp]),
     ("psm_upload_maps", _i, [_vp, _vp, _vp, _vp, _vp, _sz]),
     ("psm_download_volume", _i, [_vp, _i, _i, _i, _vp]),
     ("psm_upload_volume", _i, [_vp, _i, _i, _i, _vp]),

@@ -55,6 +55,9 @@ struct psm_ctx {
     uint8_t *valid = nullptr;           // [2][H][W]
     uint8_t *pinned = nullptr;          // [2][H][W] page-locked bounce buffer for map / mask downloads (on first use)
     int *wm = nullptr;                  // psm_wgt_median scratch: nxt[H][W+1], prog[H], err[1]; allocated on first use
+    uint8_t *wm_par = nullptr;          // scratch of its parallel (sweep) form, per side: orig, newv (bytes), stamp, 2 active lists, changed list, counters
+    int wm_sweeps[2] = {0, 0};          // last call: sweeps until the fixed point (-1: dataflow form), evaluations
+    long long wm_evals[2] = {0, 0};
     uint8_t *p4[2] = {nullptr, nullptr};  // PSM_U8 only: {c0,c1,c2,grad} words
     float *soa[2] = {nullptr, nullptr};   // planar copies of g1..g4 (14 planes) for the two-columns-per-lane filter
     int soa_state[2] = {0, 0};            // 0 nothing, 1 g1 planes, 2 all planes (of the current image pair)
@@ -199,6 +202,7 @@ void free_all(psm_ctx *c)
     (void)hipFree(c->valid);
     if (c->pinned) (void)hipHostFree(c->pinned);
     (void)hipFree(c->wm);
+    (void)hipFree(c->wm_par);
     (void)hipFree(c->gf_scratch);
     (void)hipFree(c->gf_cnt);
     (void)hipFree(c->fgf);
@@ -1128,6 +1132,27 @@ int psm_fill_invalid(psm_ctx *c, uint8_t *lmap, uint8_t *rmap, size_t stride)
     return 0;
 }
 
+// The row-dataflow form of wgtMedian: exact for any input, but as sequential as the reference wherever invalid pixels chain
+static int wgt_median_dataflow(psm_ctx *c, int side)
+{
+    const size_t HW = (size_t)c->W * c->H, nn = (size_t)c->H * (c->W + 1);
+    if (!c->wm) PSM_HIP(c, hipMalloc((void **)&c->wm, (nn + c->H + 1) * sizeof(int)));
+    int *nxt = c->wm, *prog = c->wm + nn, *err = prog + c->H;
+    PSM_HIP(c, hipMemsetAsync(err, 0, sizeof(int), c->stream));
+    {
+        Prof p(c, PSM_K_WMF);
+        launch_wgt_median(c->stream, c->maps + side * HW, c->valid + side * HW, c->g[side].g1, c->W, c->H, c->D, side, nxt, prog, err);
+    }
+    if (check_launch(c, "wgt_median")) return 1;
+    int herr = 0;
+    PSM_HIP(c, hipMemcpyAsync(&herr, err, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    PSM_HIP(c, hipStreamSynchronize(c->stream));
+    if (herr) return fail(c, "psm_wgt_median: row pipeline stalled (watchdog); maps are not valid");
+    c->wm_sweeps[side] = -1;
+    c->wm_evals[side] = 0;
+    return 0;
+}
+
 int psm_wgt_median(psm_ctx *c, uint8_t *lmap, uint8_t *rmap, size_t stride)
 {
     if (!c) return 1;
@@ -1137,21 +1162,78 @@ int psm_wgt_median(psm_ctx *c, uint8_t *lmap, uint8_t *rmap, size_t stride)
     if (bind(c)) return 1;
     const double t0 = now_us();
     if (!c->have_g1 && run_prep(c)) return 1;
-    const size_t HW = (size_t)c->W * c->H, nn = (size_t)c->H * (c->W + 1);
-    if (!c->wm) PSM_HIP(c, hipMalloc((void **)&c->wm, (nn + c->H + 1) * sizeof(int)));
-    int *nxt = c->wm, *prog = c->wm + nn, *err = prog + c->H;
-    PSM_HIP(c, hipMemsetAsync(err, 0, sizeof(int), c->stream));
-    for (int s = 0; s < 2; ++s) {
-        Prof p(c, PSM_K_WMF);
-        launch_wgt_median(c->stream, c->maps + s * HW, c->valid + s * HW, c->g[s].g1, c->W, c->H, c->D, s, nxt, prog, err);
+    const size_t HW = (size_t)c->W * c->H;
+    // PSM_OPT_FLAGS 4194304: dataflow form only; 8388608: at most 2 sweeps (test hook for the fall-back)
+    const bool dataflow_only = (c->march.flags & 4194304) != 0;
+    const int CAP = (c->march.flags & 8388608) ? 2 : 96, CHK = 4;
+    bool done[2] = {false, false};
+    if (!dataflow_only) {
+        // parallel form: sweeps to the fixed point of the in-place recursion (psm_pp.hip), both maps side by side
+        const size_t nb = (HW + 255) / 256 * 256, ncnt = 2 * (size_t)(96 + 2);
+        const size_t per_side = 2 * nb + (4 * nb + ncnt) * sizeof(int);
+        if (!c->wm_par) PSM_HIP(c, hipMalloc((void **)&c->wm_par, 2 * per_side));
+        uint8_t *orig[2], *newv[2];
+        int *stamp[2], *list[2][2], *chg[2], *cnt[2];
+        for (int s = 0; s < 2; ++s) {
+            uint8_t *b = c->wm_par + s * per_side;
+            orig[s] = b; newv[s] = b + nb;
+            int *ip = reinterpret_cast<int *>(b + 2 * nb);
+            stamp[s] = ip; list[s][0] = ip + nb; list[s][1] = ip + 2 * nb; chg[s] = ip + 3 * nb; cnt[s] = ip + 4 * nb;
+            PSM_HIP(c, hipMemcpyAsync(orig[s], c->maps + s * HW, HW, hipMemcpyDeviceToDevice, c->stream));
+            PSM_HIP(c, hipMemsetAsync(stamp[s], 0, nb * sizeof(int), c->stream));
+            PSM_HIP(c, hipMemsetAsync(cnt[s], 0, ncnt * sizeof(int), c->stream));
+            launch_wm_seed(c->stream, c->valid + s * HW, c->W, c->H, list[s][0], cnt[s]);
+        }
+        std::vector<int> hc(2 * ncnt);
+        int sw = 0;
+        while (sw < CAP && !(done[0] && done[1])) {
+            const int upto = sw + CHK < CAP ? sw + CHK : CAP;
+            {
+                Prof p(c, PSM_K_WMF);
+                for (; sw < upto; ++sw)
+                    for (int s = 0; s < 2; ++s)
+                        if (!done[s])
+                            launch_wm_sweep(c->stream, c->maps + s * HW, orig[s], c->valid + s * HW, c->g[s].g1, c->W, c->H, c->D, s,
+                                            list[s][sw & 1], cnt[s] + 2 * sw, newv[s], chg[s], cnt[s] + 2 * sw + 1, stamp[s], sw + 1,
+                                            list[s][(sw + 1) & 1], cnt[s] + 2 * (sw + 1));
+            }
+            if (check_launch(c, "wgt_median (sweeps)")) return 1;
+            for (int s = 0; s < 2; ++s)
+                PSM_HIP(c, hipMemcpyAsync(hc.data() + s * ncnt, cnt[s], ncnt * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+            PSM_HIP(c, hipStreamSynchronize(c->stream));
+            for (int s = 0; s < 2; ++s) {
+                if (done[s]) continue;
+                long long ev = 0;
+                for (int k = 0; k < sw; ++k) {
+                    ev += hc[s * ncnt + 2 * k];
+                    if (hc[s * ncnt + 2 * k + 1] == 0) {      // sweep k changed nothing: fixed point
+                        done[s] = true;
+                        c->wm_sweeps[s] = k + 1;
+                        c->wm_evals[s] = ev;
+                        break;
+                    }
+                }
+            }
+        }
+        // no fixed point within CAP sweeps (long chains of pixels that keep flipping each other): start over from the input
+        // with the dataflow form, which is exact for any input
+        for (int s = 0; s < 2; ++s)
+            if (!done[s]) PSM_HIP(c, hipMemcpyAsync(c->maps + s * HW, orig[s], HW, hipMemcpyDeviceToDevice, c->stream));
     }
-    if (check_launch(c, "wgt_median")) return 1;
-    int herr = 0;
-    PSM_HIP(c, hipMemcpyAsync(&herr, err, sizeof(int), hipMemcpyDeviceToHost, c->stream));
-    PSM_HIP(c, hipStreamSynchronize(c->stream));
-    if (herr) return fail(c, "psm_wgt_median: row pipeline stalled (watchdog); maps are not valid");
+    for (int s = 0; s < 2; ++s)
+        if (!done[s] && wgt_median_dataflow(c, s)) return 1;
     if (copy_maps_out(c, c->maps, lmap, rmap, stride)) return 1;
     c->stage_us[PSM_STAGE_PP] += now_us() - t0;
+    return 0;
+}
+
+int psm_wgt_median_stats(psm_ctx *c, int *sweeps, long long *evals)
+{
+    if (!c) return 1;
+    for (int s = 0; s < 2; ++s) {
+        if (sweeps) sweeps[s] = c->wm_sweeps[s];
+        if (evals) evals[s] = c->wm_evals[s];
+    }
     return 0;
 }
 

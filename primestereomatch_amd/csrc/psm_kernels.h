@@ -101,6 +101,11 @@ void launch_fill_inv(hipStream_t s, uint8_t *dis, const uint8_t *valid, int W, i
 // nxt: scratch of H*(W+1) ints, prog: H ints, err: 1 int (set to 1 if the dataflow watchdog fired)
 void launch_wgt_median(hipStream_t s, uint8_t *dis, const uint8_t *valid, const float4 *g1, int W, int H, int maxDis, int right,
                        int *nxt, int *prog, int *err);
+// parallel form (sweeps to the fixed point of the in-place recursion; psm_pp.hip)
+void launch_wm_seed(hipStream_t s, const uint8_t *valid, int W, int H, int *list, int *cnt);
+void launch_wm_sweep(hipStream_t s, uint8_t *cur, const uint8_t *orig, const uint8_t *valid, const float4 *g1, int W, int H, int maxDis,
+                     int right, const int *act, const int *n_act, uint8_t *newv, int *chg, int *n_chg, int *stamp, int mark,
+                     int *next, int *n_next);
 
 // ---- Fast Guided Filter variant (psm_fgf.hip); sub = subsample rate, small planes are (H/sub) x (W/sub) ----
 // g1 -> subsampled guidance ism, its means msm and the inverse covariance planes v1 = {irr,irg,irb,igg}, v2 = {igb,ibb}

@@ -148,6 +148,13 @@ class DispEst:
         self._ck(self._lib.psm_wgt_median(self._h, _ptr(self.lDisMap), _ptr(self.rDisMap), self.wid), "WgtMedian_GPU")
         return 0
 
+    def wgt_median_stats(self):
+        """(sweeps, evaluations) of the last WgtMedian_GPU per map [left, right]; sweeps = -1: the dataflow form ran."""
+        import ctypes as C
+        sw, ev = (C.c_int * 2)(), (C.c_longlong * 2)()
+        self._ck(self._lib.psm_wgt_median_stats(self._h, sw, ev), "wgt_median_stats")
+        return list(sw), list(ev)
+
     def upload_maps(self, lmap=None, rmap=None, lvalid=None, rvalid=None):
         arrs = [None if a is None else np.ascontiguousarray(a, dtype=np.uint8) for a in (lmap, rmap, lvalid, rvalid)]
         for a in arrs:

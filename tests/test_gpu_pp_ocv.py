@@ -36,15 +36,28 @@ def _wm_inputs(H, W, D, seed, frac_invalid, smooth=True):
     return img, lm, rm, lv, rv
 
 
+WM_FORMS = {"sweeps": 0, "dataflow": 4194304, "fallback": 8388608}   # PSM_OPT_FLAGS: parallel form (default) / row-dataflow
+#                                                                     form only / 2 sweeps, then the dataflow form from the input
+
+
+@pytest.mark.parametrize("form", sorted(WM_FORMS))
 @pytest.mark.parametrize("H,W,D,frac", [(21, 26, 16, 0.3), (40, 70, 64, 0.6), (33, 210, 200, 1.0), (12, 9, 8, 0.5),
                                         (48, 256, 256, 0.15)])
-def test_wgt_median_random_maps(psm, oracle, H, W, D, frac):
+def test_wgt_median_random_maps(psm, oracle, H, W, D, frac, form):
+    from primestereomatch_amd import capi
     l, lm, rm, lv, rv = _wm_inputs(H, W, D, seed=H * W + D, frac_invalid=frac)
     r = np.roll(l, 3, axis=1)
     with psm.DispEst(l, r, D) as de:
+        de.set_option(capi.PSM_OPT_FLAGS, WM_FORMS[form])
         de.upload_maps(lm, rm, lv, rv)
         de.WgtMedian_GPU()
         gl, gr = de.lDisMap.copy(), de.rDisMap.copy()
+        sweeps, evals = de.wgt_median_stats()
+    print(f"[wmf] {form}: sweeps {sweeps}, evaluations {evals}")
+    if form == "dataflow":
+        assert sweeps == [-1, -1]
+    elif form == "sweeps":
+        assert min(sweeps) >= 1          # the parallel form reached its fixed point (no fall-back on these maps)
     el = oracle.wgt_median(oracle.u8_to_f32(l), lm, lv, D, right=False)
     er = oracle.wgt_median(oracle.u8_to_f32(r), rm, rv, D, right=True)
     print(f"[wmf] {W}x{H} D={D}: left mismatches {(gl != el).sum()}, right {(gr != er).sum()} "
@@ -53,12 +66,15 @@ def test_wgt_median_random_maps(psm, oracle, H, W, D, frac):
     assert np.array_equal(gl[lv != 0], lm[lv != 0])
 
 
+@pytest.mark.parametrize("form", ["sweeps", "dataflow"])
 @pytest.mark.parametrize("name", ["cones", "teddy"])
-def test_wgt_median_after_lr_check_middlebury(psm, oracle, golden, name):
+def test_wgt_median_after_lr_check_middlebury(psm, oracle, golden, name, form):
     """PP::processDM's sequence (src/PP.cpp:405-410): lrCheck -> fillInv -> wgtMedian on the real pair."""
+    from primestereomatch_amd import capi
     pair = golden(f"{name}_pair.npz")
     l, r = pair["l_bgr"], pair["r_bgr"]
     with psm.DispEst(l, r, 64) as de:
+        de.set_option(capi.PSM_OPT_FLAGS, WM_FORMS[form])
         de.CostConst_GPU(); de.CostFilter_GPU(); de.DispSelect_GPU()
         de.LRCheck_GPU()
         lv, rv = de.lValid.copy(), de.rValid.copy()
@@ -67,6 +83,8 @@ def test_wgt_median_after_lr_check_middlebury(psm, oracle, golden, name):
         de.WgtMedian_GPU()
         gl, gr = de.lDisMap.copy(), de.rDisMap.copy()
         us = de.stage_time_us(3)
+        sweeps, evals = de.wgt_median_stats()
+    print(f"[wmf] {name} ({form}): sweeps {sweeps}, evaluations {evals}")
     el = oracle.wgt_median(oracle.u8_to_f32(l), lf, lv, 64, right=False)
     er = oracle.wgt_median(oracle.u8_to_f32(r), rf, rv, 64, right=True)
     nl, nr = int((gl != el).sum()), int((gr != er).sum())
