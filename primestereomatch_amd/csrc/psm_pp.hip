@@ -231,39 +231,87 @@ __global__ __launch_bounds__(64) void k_wm_eval(const uint8_t *__restrict__ cur,
                                                const float4 *__restrict__ g1, const int *__restrict__ list, const int *n_act,
                                                uint8_t *__restrict__ newv, int *__restrict__ chg, int *n_chg, int W, int H, int maxDis)
 {
+    // NB == 1: taps in window raster order.  NB > 1: the voting taps stably partitioned by dep / 64 (bucket j holds, in raster
+    // order, the taps of the bins lane + 64 j, buckets back to back), so a lane walks every tap once instead of NB times;
+    // wsum[] keeps the raster order for the total.
     __shared__ float2 taps[WM_TAPS + 3];
+    __shared__ float wsum[NB == 1 ? 1 : WM_TAPS + 3];
     __shared__ float hist[64 * NB];
     const int lane = threadIdx.x;
     const int n = *n_act;
     constexpr int WM_ROUNDS = (WM_TAPS + 63) / 64;
+    const unsigned long long below = (1ull << lane) - 1ull;
     for (int i = blockIdx.x; i < n; i += gridDim.x) {
         const int pix = list[i];
         const int y = pix / W, x = pix - y * W;
         const float4 p = g1[pix];
+        int cntj[NB], basej[NB];
+#pragma unroll
+        for (int j = 0; j < NB; ++j) cntj[j] = 0;
+        int dep[WM_ROUNDS], off[WM_ROUNDS];
 #pragma unroll
         for (int k = 0; k < WM_ROUNDS; ++k) {
             const int t = min(lane + 64 * k, WM_TAPS - 1);
             const int wy = t / WM_K - WM_R, wx = t % WM_K - WM_R;
             const int qy = (y + wy + H) % H, qx = (x + wx + W) % W;
-            const int off = qy * W + qx;
+            off[k] = qy * W + qx;
             // raster order is index order: an earlier pixel shows its current iterate (= the input where it is valid),
             // a later one - and the pixel itself - the input (src/PP.cpp:164-166 reads the map in place)
-            const int dep = off < pix ? cur[off] : orig[off];
-            const float w = wm_weight<RIGHT>(p, g1[off], wx, wy);
-            if (lane + 64 * k < WM_TAPS) taps[t] = make_float2(__int_as_float(dep), dep != 0 ? w : 0.0f);
+            dep[k] = off[k] < pix ? cur[off[k]] : orig[off[k]];
+            if (NB > 1) {
+#pragma unroll
+                for (int j = 0; j < NB; ++j)
+                    cntj[j] += __builtin_popcountll(__builtin_amdgcn_ballot_w64(lane + 64 * k < WM_TAPS && dep[k] != 0 && (dep[k] >> 6) == j));
+            }
+        }
+        if (NB > 1) {
+            int b = 0;
+#pragma unroll
+            for (int j = 0; j < NB; ++j) { basej[j] = b; b += cntj[j]; }
+        }
+        int fill[NB];
+#pragma unroll
+        for (int j = 0; j < NB; ++j) fill[j] = 0;
+#pragma unroll
+        for (int k = 0; k < WM_ROUNDS; ++k) {
+            const int t = min(lane + 64 * k, WM_TAPS - 1);
+            const int wy = t / WM_K - WM_R, wx = t % WM_K - WM_R;
+            const float w = wm_weight<RIGHT>(p, g1[off[k]], wx, wy);
+            const bool live = lane + 64 * k < WM_TAPS;
+            if (NB == 1) {
+                if (live) taps[t] = make_float2(__int_as_float(dep[k]), dep[k] != 0 ? w : 0.0f);
+            } else {
+                if (live) wsum[t] = dep[k] != 0 ? w : 0.0f;
+#pragma unroll
+                for (int j = 0; j < NB; ++j) {
+                    const bool mine = live && dep[k] != 0 && (dep[k] >> 6) == j;
+                    const unsigned long long m = __builtin_amdgcn_ballot_w64(mine);
+                    if (mine) taps[basej[j] + fill[j] + __builtin_popcountll(m & below)] = make_float2(__int_as_float(dep[k] & 63), w);
+                    fill[j] += __builtin_popcountll(m);
+                }
+            }
         }
         __syncthreads();
         float acc[NB];
 #pragma unroll
         for (int j = 0; j < NB; ++j) acc[j] = 0.0f;
         float tot = 0.0f;
+        if (NB == 1) {
 #pragma unroll 19
-        for (int t = 0; t < WM_TAPS; ++t) {
-            const float2 tw = taps[t];
-            const int dep = __float_as_int(tw.x);
-            tot = __fadd_rn(tot, tw.y);
+            for (int t = 0; t < WM_TAPS; ++t) {
+                const float2 tw = taps[t];
+                tot = __fadd_rn(tot, tw.y);
+                acc[0] = __fadd_rn(acc[0], __float_as_int(tw.x) == lane ? tw.y : 0.0f);
+            }
+        } else {
+#pragma unroll 19
+            for (int t = 0; t < WM_TAPS; ++t) tot = __fadd_rn(tot, wsum[t]);     // adding 0.0f for "does not vote" is the identity
 #pragma unroll
-            for (int j = 0; j < NB; ++j) acc[j] = __fadd_rn(acc[j], dep == lane + 64 * j ? tw.y : 0.0f);
+            for (int j = 0; j < NB; ++j)
+                for (int t = 0; t < cntj[j]; ++t) {
+                    const float2 tw = taps[basej[j] + t];
+                    acc[j] = __fadd_rn(acc[j], __float_as_int(tw.x) == lane ? tw.y : 0.0f);
+                }
         }
 #pragma unroll
         for (int j = 0; j < NB; ++j) hist[lane + 64 * j] = acc[j];

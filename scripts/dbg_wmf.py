@@ -35,4 +35,9 @@ run("one full row", H, W, D, v)
 v = np.ones((H, W), np.uint8); v[:, 7] = 0
 run("one full column", H, W, D, v)
 run("all invalid", H, W, D, np.zeros((H, W), np.uint8))
-run("all invalid 1080p D=256", 1080, 1920, 256, np.zeros((1080, 1920), np.uint8)) if len(sys.argv) > 1 else None
+if len(sys.argv) > 1:
+    H, W, D = 1080, 1920, 256
+    run("1080p iid 20%", H, W, D, (rng.random((H, W)) > 0.2).astype(np.uint8))
+    run("1080p iid 43%", H, W, D, (rng.random((H, W)) > 0.43).astype(np.uint8))
+    v = np.ones((H, W), np.uint8); v[:, 300:420] = 0; v[:, 900:960] = 0; v[200:260, :] = 0
+    run("1080p bands", H, W, D, v)

@@ -23,12 +23,15 @@ $B --config c5 --steps 4 --warmup 1 --verify > $OUT/bench_c5_n1.json 2>> $OUT/be
 $B --config c1 --steps 30 --verify > $OUT/bench_c1_u8_n1.json 2>> $OUT/bench_var.err
 $B --config c1x --steps 30 --verify > $OUT/bench_c1x_u8_n1.json 2>> $OUT/bench_var.err
 $B --config c4 --dtype u8 --no-cpu-baseline --verify > $OUT/bench_c4_u8_n1.json 2>> $OUT/bench_var.err
+$B --flags 2097152 --no-cpu-baseline --verify > $OUT/bench_c4_single_phase_n1.json 2>> $OUT/bench_var.err
 $B --flags 8192 --no-cpu-baseline --verify > $OUT/bench_c4_store_mode_n1.json 2>> $OUT/bench_var.err
 $B --flags 65536 --no-cpu-baseline --verify > $OUT/bench_c4_one_side_per_launch_n1.json 2>> $OUT/bench_var.err
 $B --flags 16384 --no-cpu-baseline --verify > $OUT/bench_c4_q2_variant_n1.json 2>> $OUT/bench_var.err
 $B --flags 16 --no-cpu-baseline > $OUT/bench_c4_twostage_n1.json 2>> $OUT/bench_var.err
 for s in 2 4 8; do $B --fgf $s --no-cpu-baseline > $OUT/bench_c4_fgf_s${s}_n1.json 2>> $OUT/bench_var.err; done
 for g in 2 4 8; do $B --shard-sim $g --steps 40 --no-cpu-baseline > $OUT/bench_c4_shardsim_1of$g.json 2>> $OUT/bench_var.err; done
+echo "== weighted median timing (sweeps form / dataflow form)"
+timeout 300 python scripts/dbg_wmf.py big > $OUT/wmf_timing.txt 2>&1; WM_FLAGS=4194304 timeout 300 python scripts/dbg_wmf.py >> $OUT/wmf_timing.txt 2>&1; tail -22 $OUT/wmf_timing.txt
 echo "== torch.distributed path on 1 GPU (RCCL, world_size 1)"
 D="timeout 600 python bench.py --gpus 1 --force-dist --steps 10 --warmup 3 --no-cpu-baseline"
 $D > $OUT/bench_c4_dist_world1.json 2> $OUT/bench_dist1.err
@@ -61,8 +64,10 @@ for pass in "sq:SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_LD
   fdb=$(find $OUT/pmcq2_$n -name "*.db" | head -1); [ -n "$fdb" ] && python $GRAFT_REPO_ROOT/scripts/rocpd_summary.py $fdb > $OUT/pmcq2_$n.summary.txt 2>&1
 done
 cd $GRAFT_REPO_ROOT
-python scripts/make_traffic.py $OUT "k_cvf_pc<false, 3, 1" "profiles/$TAG/rocprofv3_pmc_{rd,wr}.summary.txt" > $OUT/traffic.log 2>&1; tail -8 $OUT/traffic.log
+python scripts/make_traffic.py $OUT "k_cvf_pc<false, 3, 1|k_cvf_pc<false, 3, 2" "profiles/$TAG/rocprofv3_pmc_{rd,wr}.summary.txt" > $OUT/traffic.log 2>&1; tail -8 $OUT/traffic.log
 cp profiles/traffic.json $OUT/traffic.json
+echo "== headline line again, carrying this session's traffic figure"
+timeout 900 python bench.py --box-bench --verify > $OUT/bench_c4_n1.json 2> $OUT/bench_c4.err; python -c "import json;j=json.load(open('$OUT/bench_c4_n1.json'));print(j['value'],j['ms_per_step'],j['roofline'])"
 echo "== per-role cycle counters (debug build, if present)"
 if [ -f primestereomatch_amd/lib/libprimesm_hip_dbg.so ]; then PRIMESM_HIP_LIB=$GRAFT_REPO_ROOT/primestereomatch_amd/lib/libprimesm_hip_dbg.so python scripts/dbg_pc_timing.py > $OUT/role_cycles.txt 2>&1; cat $OUT/role_cycles.txt; fi
 find $OUT -name "*.db" -delete; find $OUT -name "*kernel_trace.csv" -size +3M -delete
