@@ -78,6 +78,10 @@ def main():
     ap.add_argument("--exchange", default="allreduce", choices=["allreduce", "allgather", "none"],
                     help="N>1 exchange step: one all_reduce(MIN) of the packed keys (default; ~2x33 MB per rank "
                          "at 1080p whatever N) or one all_gather ((N-1)x33 MB per rank) + device-side minimum")
+    ap.add_argument("--shard", default="rows", choices=["rows", "disp"],
+                    help="N > 1: what a rank owns - 'rows': a stripe of H/N output rows of both volumes, all D slices (no minima "
+                         "exchanged, one all-gather of the finished map rows per frame); 'disp': D/N slices of both volumes, whole "
+                         "image (one collective on packed per-pixel minima per frame, --exchange)")
     ap.add_argument("--box-bench", action="store_true", help="also time the plain box-filter pass")
     ap.add_argument("--fgf", type=int, default=0, choices=[0, 2, 4, 8],
                     help="diagnostic: aggregate with the Fast Guided Filter variant (CostFilter_FGF) at this subsample "
@@ -98,8 +102,10 @@ def main():
     N = args.gpus
     if N < 1:
         raise SystemExit("bench.py: --gpus must be >= 1")
-    if N > CONFIGS[args.config][2]:
+    if args.shard == "disp" and N > CONFIGS[args.config][2]:
         raise SystemExit(f"bench.py: --gpus {N} exceeds the {CONFIGS[args.config][2]} disparity slices of config {args.config} (one shard per rank)")
+    if args.shard == "rows" and N > CONFIGS[args.config][1]:
+        raise SystemExit(f"bench.py: --gpus {N} exceeds the {CONFIGS[args.config][1]} rows of config {args.config} (one stripe per rank)")
     if N > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
         # bare `python bench.py --gpus N`: become the launcher - one rank per GPU under torch.distributed.run on
         # 127.0.0.1 - and pass rank 0's single JSON line through
@@ -138,7 +144,17 @@ def main():
         ALG_BYTES.update(ALG_BYTES_U8)
         if not args.config.startswith("c1"):
             desc = desc.replace("float32", "8-bit char mode")
-    if use_dist:
+    rows_mode = args.shard == "rows" and not args.fgf and (use_dist or args.shard_sim > 1)
+    from primestereomatch_amd import stripes
+    parts = world if use_dist else max(args.shard_sim, 1)
+    rows_max, y0, y1 = H, 0, H
+    if rows_mode:
+        # stripes aligned at multiples of ceil(H / parts): the gathered tensor is the image
+        rows_max, y0, y1 = stripes.stripe_bounds(H, parts, rank if use_dist else 0)
+        if y1 <= y0:
+            raise SystemExit(f"bench.py: rank {rank} of {world} has no rows of the {H}-row image")
+        d0, d1 = 0, D
+    elif use_dist:
         d0, d1 = D * rank // world, D * (rank + 1) // world
     elif args.shard_sim > 1:
         d0, d1 = 0, D // args.shard_sim
@@ -154,6 +170,8 @@ def main():
     if args.flags >= 0:
         de.set_option(capi.PSM_OPT_FLAGS, args.flags)
     de.set_option(capi.PSM_OPT_ASYNC, 1)
+    if rows_mode:
+        de.set_rows(y0, y1)
 
     keys_local = keys_all = None
     kbuf = []
@@ -164,6 +182,12 @@ def main():
         kbuf = [torch.empty(HW2, dtype=torch.int64, device="cuda") for _ in range(2)]
         keys_local = kbuf[0]
         keys_all = torch.empty(world * HW2 if args.exchange == "allgather" else 1, dtype=torch.int64, device="cuda")
+        if rows_mode:
+            # the maps of a frame are written by the library straight into one of two torch tensors (psm_set_map_buffer);
+            # the stripe rows go through one all_gather per frame: [world][2][rows_max][W] uint8 = the two whole maps
+            mbuf = [torch.zeros(HW2 + 4, dtype=torch.uint8, device="cuda") for _ in range(2)]
+            send = torch.zeros(2 * rows_max * W, dtype=torch.uint8, device="cuda")
+            recv = torch.zeros(world * 2 * rows_max * W, dtype=torch.uint8, device="cuda")
         # one non-default torch stream carries both our kernels and the RCCL collective, so the
         # exchange is ordered against the kernels without host synchronisation
         side_stream = torch.cuda.Stream()
@@ -173,7 +197,7 @@ def main():
     if args.fgf:
         de.setSubsampleRate(args.fgf)
 
-    pipelined = use_dist and args.exchange == "allreduce" and not args.no_frame_pipeline and not args.fgf
+    pipelined = use_dist and (args.exchange == "allreduce" or rows_mode) and not args.no_frame_pipeline and not args.fgf
 
     def finish_pending():
         # exchange of an earlier frame -> final maps (the collective ran on RCCL's stream meanwhile)
@@ -181,7 +205,15 @@ def main():
             works, kb = pending.pop(0)
             for w_ in works:
                 w_.wait()
-            de.DispSelect_merge(kb.data_ptr(), 1, download=False)
+            if rows_mode:
+                stripes.assemble(recv, world, H, W, rows_max, kb)    # [rank][side][row][x] -> [side][y][x]
+                de.set_map_buffer(kb.data_ptr(), whole=True)
+            else:
+                de.DispSelect_merge(kb.data_ptr(), 1, download=False)
+
+    def stripe_exchange(mb, async_op):
+        stripes.pack_stripe(mb, y0, y1, send, H, W, rows_max)
+        return dist.all_gather_into_tensor(recv, send, async_op=async_op)      # the one exchange step (RCCL)
 
     def step():
         de.CostConst_GPU()
@@ -195,6 +227,22 @@ def main():
                 de.DispSelect_partial()
             else:
                 de.DispSelect_device()
+            return
+        if rows_mode and use_dist:
+            # Row stripes: nothing of the cost volumes or their minima leaves the rank; the finished rows of both maps are
+            # gathered - asynchronously, behind the next frame's filter when pipelined (maps alternate between two tensors).
+            mb = mbuf[frame[0] & 1]
+            frame[0] += 1
+            de.set_map_buffer(mb.data_ptr())
+            de.CostFilter_GPU()
+            de.DispSelect_device()
+            finish_pending()
+            if pipelined:
+                pending.append(((stripe_exchange(mb, True),), mb))
+            else:
+                stripe_exchange(mb, False)
+                pending.append(((), mb))
+                finish_pending()
             return
         if pipelined:
             # Frame pipeline, ONE collective per frame: the fused kernel leaves the packed minima of both volumes directly
@@ -221,7 +269,7 @@ def main():
             else:
                 dist.all_gather_into_tensor(keys_all, keys_local)     # the one exchange step (RCCL)
                 de.DispSelect_merge(keys_all.data_ptr(), world, download=False)
-        elif args.shard_sim > 1:
+        elif args.shard_sim > 1 and not rows_mode:
             de.DispSelect_partial()
         else:
             de.DispSelect_device()
@@ -300,7 +348,7 @@ def main():
     # of both volumes through the minima planes, then the other slices of both volumes against the key plane; the two
     # are instantiations of the same kernel, so avg_launch_ms is their mean and alg bytes / launch the mean as well)
     lps = max(1, round(kern.get("cvf_fused", {}).get("launches_per_step", 2)))   # (other filter forms: one side per launch)
-    vox_per_launch = 2.0 * W * H * (d1 - d0) / lps
+    vox_per_launch = 2.0 * W * (y1 - y0) * (d1 - d0) / lps                        # (this rank's rows and slices)
     if args.fgf:   # per launch pair (setup + model + smooth + apply of one side): cost read at 1/s^2, model planes, q write
         ALG_BYTES["cvf_fgf"] = 4.0 + 68.0 / (args.fgf * args.fgf)
     # the default fused kernel also builds the costs and runs the WTA over its slices ("select" mode): it is credited
@@ -403,8 +451,10 @@ def main():
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": dtype,
             "data": "synthetic",
             "config": {"workload": desc, "W": W, "H": H, "D": D, "voxels_per_step": voxels_per_step,
-                       "parallelism": "1 GPU" if world == 1 else f"D sharded over {world} ranks + 1 RCCL {args.exchange} of packed minima",
-                       "kernel_variant": args.variant, "shard_sim": args.shard_sim},
+                       "parallelism": "1 GPU" if world == 1 and not use_dist else
+                                      (f"{world} row stripes of {rows_max} rows (all {D} slices each) + 1 RCCL all_gather of the map rows per frame"
+                                       if rows_mode else f"D sharded over {world} ranks + 1 RCCL {args.exchange} of packed minima"),
+                       "kernel_variant": args.variant, "shard_sim": args.shard_sim, "shard": (args.shard if (use_dist or args.shard_sim > 1) else None)},
             "roofline": roofline, "cpu_baseline": cpu, "kernels": kern,
             "median_ms_per_step": round(median_ms, 4), "pcie": pcie,
         }

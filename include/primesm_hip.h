@@ -203,6 +203,25 @@ int psm_wgt_median(psm_ctx *ctx, uint8_t *lmap, uint8_t *rmap, size_t stride);
  * evaluations in total.  Either pointer may be NULL. */
 int psm_wgt_median_stats(psm_ctx *ctx, int sweeps[2], long long evals[2]);
 
+/* ---- second sharding axis: row stripes (SURVEY.md 8e asks for shards of the path; the filter's vertical support is
+ * bounded - 8 rows of costs either side - so a stripe of output rows needs nothing from another stripe) ----
+ * psm_set_rows restricts psm_cost_filter (select form) and psm_disp_select* of this context to the output rows
+ * [y_begin, y_end) of the whole image - all D slices (or this context's slices) of both volumes, identical values to
+ * the unrestricted run; the image pair is uploaded whole (borders reflect at the true image border).  Rows outside the
+ * stripe of the maps / minima are undefined.  (0, 0) or (0, H): whole image again.  Takes effect with the next psm_cost_filter.
+ * With G contexts / ranks on stripes [H*g/G, H*(g+1)/G) no minima are exchanged at all: the only exchange is the
+ * gather of the finished map rows (2*W*H bytes in total) - psm_gather_rows_ctx in one process, an all-gather of the
+ * stripes between ranks (bench.py).  The post-processing entry points refuse stripe-only maps. */
+int psm_set_rows(psm_ctx *ctx, int y_begin, int y_end);
+/* The disparity maps [2][H][W] (uint8) of this context live in dev_maps (device memory of this context's GPU, at least
+ * 2*W*H + 4 bytes) from now on; NULL: the context's own buffer again.  whole != 0: the buffer already holds both
+ * complete maps of the current frame (the caller gathered the stripes into it). */
+int psm_set_map_buffer(psm_ctx *ctx, void *dev_maps, int whole);
+/* One process, several contexts (one per GPU or logical stripes on one GPU): copies the stripe rows of every context's
+ * maps into root's maps (root may be one of them); checks that the stripes tile [0, H) and that every context has run
+ * psm_disp_select for the frame.  lmap/rmap (optional) receive the whole maps. */
+int psm_gather_rows_ctx(psm_ctx *root, psm_ctx *const *stripes, int nstripes, uint8_t *lmap, uint8_t *rmap, size_t stride);
+
 /* ---- debug / bench entry points (no counterpart in the reference) ---- */
 
 /* Replace the device maps and validity masks (any may be NULL = keep) - lets the post-processing stages run on maps

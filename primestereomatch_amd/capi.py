@@ -50,6 +50,9 @@ SYMBOLS = [
     ("psm_fill_invalid", _i, [_vp, _vp, _vp, _sz]),
     ("psm_wgt_median", _i, [_vp, _vp, _vp, _sz]),
     ("psm_wgt_median_stats", _i, [_vp, _vp, _vp]),
+    ("psm_set_rows", _i, [_vp, _i, _i]),
+    ("psm_set_map_buffer", _i, [_vp, _vp, _i]),
+    ("psm_gather_rows_ctx", _i, [_vp, _vp, _i, _vp, _vp, _sz]),
     ("psm_upload_maps", _i, [_vp, _vp, _vp, _vp, _vp, _sz]),
     ("psm_download_volume", _i, [_vp, _i, _i, _i, _vp]),
     ("psm_upload_volume", _i, [_vp, _i, _i, _i, _vp]),

@@ -51,7 +51,9 @@ struct psm_ctx {
     long long *keys_cur = nullptr;      // where the packed minima go: `keys`, or the caller's buffer (psm_set_key_buffer)
     long long *gather = nullptr;        // [gather_ranks][2][H][W], psm_disp_merge_ctx
     int gather_ranks = 0;
-    uint8_t *maps = nullptr;            // [2][H][W]
+    uint8_t *maps = nullptr;            // [2][H][W]: maps_own, or the caller's buffer (psm_set_map_buffer)
+    uint8_t *maps_own = nullptr;
+    bool have_rows = false;             // the maps hold the rows of this context's stripe only (psm_set_rows) for this frame
     uint8_t *valid = nullptr;           // [2][H][W]
     uint8_t *pinned = nullptr;          // [2][H][W] page-locked bounce buffer for map / mask downloads (on first use)
     int *wm = nullptr;                  // psm_wgt_median scratch: nxt[H][W+1], prog[H], err[1]; allocated on first use
@@ -71,6 +73,8 @@ struct psm_ctx {
     // UNFILTERED volume); any reader of the filtered volume re-runs the filter in "store" mode first (materialize()).
     bool gf_virtual[2] = {false, false};
     bool have_guid[2] = {false, false};   // g2..g4 of a side are those of the current image pair
+    int guid_y0 = 0, guid_y1 = 0;         // ... or, while have_guid is false, only their rows [guid_y0, guid_y1) of both sides are (row stripes)
+    int g1_y0 = 0, g1_y1 = 0;             // likewise for g1 (and the 8-bit planes) while have_g1 is false
     void *gf_scratch = nullptr;         // chunk planes of the select-mode kernel (PcPlan::scratch_bytes)
     size_t gf_scratch_bytes = 0;
     int *gf_cnt = nullptr;              // slice counters of the dynamic select form (one per side and pair)
@@ -198,7 +202,7 @@ void free_all(psm_ctx *c)
     (void)hipFree(c->ab);
     (void)hipFree(c->keys);
     (void)hipFree(c->gather);
-    (void)hipFree(c->maps);
+    (void)hipFree(c->maps_own);
     (void)hipFree(c->valid);
     if (c->pinned) (void)hipHostFree(c->pinned);
     (void)hipFree(c->wm);
@@ -216,21 +220,32 @@ void free_all(psm_ctx *c)
 }
 
 // planarise + scale + gray + x-gradient of both staged images -> g1 (and the 8-bit planes)
-int run_prep(psm_ctx *c)
+// (rows [ya, yb) only - the kernels are row-independent - when a row stripe is all the following filter will read: have_g1
+// then stays false and g1_y0/1 say what is there; every other consumer finds have_g1 false and prepares the whole image)
+int run_prep(psm_ctx *c, int ya = 0, int yb = 0)
 {
+    const bool whole = yb <= ya || (ya <= 0 && yb >= c->H);
+    if (whole) { ya = 0; yb = c->H; }
+    ya = ya < 0 ? 0 : ya;
+    yb = yb > c->H ? c->H : yb;
     const size_t row = (size_t)c->W * 3 * (c->raw_depth == PSM_IMG_F32 ? 4 : 1);
+    const size_t o = (size_t)ya * c->W;
     {   // both images in one launch
         Prof p(c, PSM_K_PREP);
-        launch_prep(c->stream, c->raw[0], row, c->raw_depth == PSM_IMG_F32, c->W, c->H, c->g[0].g1, c->raw[1], c->g[1].g1);
+        launch_prep(c->stream, (const char *)c->raw[0] + ya * row, row, c->raw_depth == PSM_IMG_F32, c->W, yb - ya, c->g[0].g1 + o,
+                    (const char *)c->raw[1] + ya * row, c->g[1].g1 + o);
     }
     for (int s = 0; s < 2 && c->dtype == PSM_U8; ++s) {
         Prof p(c, PSM_K_PREP);
-        launch_prep_u8(c->stream, (const uint8_t *)c->raw[s], row, c->W, c->H, c->p4[s]);
+        launch_prep_u8(c->stream, (const uint8_t *)c->raw[s] + ya * row, row, c->W, yb - ya, c->p4[s] + 4 * o);
     }
     if (check_launch(c, "prep")) return 1;
     c->soa_state[0] = c->soa_state[1] = 0;
     c->have_guid[0] = c->have_guid[1] = false;
-    c->have_g1 = true;
+    c->guid_y0 = c->guid_y1 = 0;
+    c->have_g1 = whole;
+    c->g1_y0 = ya;
+    c->g1_y1 = yb;
     return 0;
 }
 
@@ -320,9 +335,27 @@ int fgf_flush(psm_ctx *c, int side)
 }
 
 // make sure the whole volume of `side` (unfiltered, or filtered by psm_cost_filter_fgf) is in memory
+// g1 (and the 8-bit planes) and the guidance of the whole image: a row-stripe filter leaves only its own rows behind
+static int ensure_whole_planes(psm_ctx *c)
+{
+    if (!c->have_g1 && run_prep(c)) return 1;
+    if (!(c->have_guid[0] && c->have_guid[1])) {
+        {
+            Prof p(c, PSM_K_GUIDE);
+            launch_guidance(c->stream, c->g[0], nullptr, c->W, c->H, 0, &c->g[1]);
+        }
+        c->have_guid[0] = c->have_guid[1] = true;
+        c->guid_y0 = 0;
+        c->guid_y1 = c->H;
+        return check_launch(c, "guidance");
+    }
+    return 0;
+}
+
 int materialize(psm_ctx *c, int side)
 {
     if (fgf_flush(c, side)) return 1;
+    if ((c->gf_virtual[side] || c->raw_rows[side] != psm_ctx::RAW_ALL) && ensure_whole_planes(c)) return 1;
     if (c->dtype == PSM_U8) {
         if (c->raw_rows[side] != psm_ctx::RAW_ALL) {      // the 8-bit costs exist only as a recipe: build them
             Prof p(c, PSM_K_CVC);
@@ -432,7 +465,8 @@ int psm_create_shard(psm_ctx **out, int width, int height, int max_disp, int d_b
     // (fvol, the float work copy of the 8-bit storing path, is allocated on first use)
     if (e == hipSuccess) e = hipMalloc((void **)&c->keys, 2 * HW * sizeof(long long));
     c->keys_cur = c->keys;
-    if (e == hipSuccess) e = hipMalloc((void **)&c->maps, 2 * HW + 4);   // +4: psm_wgt_median reads/updates whole aligned dwords
+    if (e == hipSuccess) e = hipMalloc((void **)&c->maps_own, 2 * HW + 4);   // +4: psm_wgt_median reads/updates whole aligned dwords
+    c->maps = c->maps_own;
     if (e == hipSuccess) e = hipMalloc((void **)&c->valid, 2 * HW);
     if (e != hipSuccess) {
         fail(nullptr, "psm_create: device setup failed: %s", hipGetErrorString(e));
@@ -528,6 +562,7 @@ int psm_upload_pair(psm_ctx *c, const void *l, const void *r, int channels, size
     c->raw_depth = depth;
     c->have_images = true;
     c->have_g1 = false;
+    c->g1_y0 = c->g1_y1 = 0;
     c->have_cost = false;
     c->have_maps = false;
     c->have_valid = false;
@@ -544,14 +579,17 @@ int psm_cost_construct(psm_ctx *c)
     if (!c->have_images) return fail(c, "psm_cost_construct: no image pair uploaded");
     if (bind(c)) return 1;
     const double t0 = now_us();
-    if (run_prep(c)) return 1;  // CVC::preprocess belongs to this stage (src/DispEst.cpp:232-233)
-    c->fgf_virtual[0] = c->fgf_virtual[1] = 0;   // a new cost volume replaces whatever was pending
-    c->gf_virtual[0] = c->gf_virtual[1] = false;
     // Lazy cost volume: when the fused filter will consume the costs (float mode, marching kernels,
     // fusion not disabled) they are built inside that kernel and never written to HBM.
     // (8-bit mode: lazy only when the select-mode kernel will consume the costs - its storing form reads a float copy)
     const bool lazy = c->opt_variant == 0 && !(c->march.flags & (16 | 128)) && c->H >= 8 &&
                       (c->dtype == PSM_F32 || !(c->march.flags & (512 | 8192)));
+    // CVC::preprocess belongs to this stage (src/DispEst.cpp:232-233).  A row stripe [y0, y1) with lazy costs reads the image
+    // planes of rows y0 - 8 .. y1 + 7 only (costs of the model rows y0 - 4 .. y1 + 2, +- 4 for their box sums, and the guidance)
+    const bool striped = c->march.yend > c->march.ybeg;
+    if (striped && lazy ? run_prep(c, c->march.ybeg - 8, c->march.yend + 8) : run_prep(c)) return 1;
+    c->fgf_virtual[0] = c->fgf_virtual[1] = 0;   // a new cost volume replaces whatever was pending
+    c->gf_virtual[0] = c->gf_virtual[1] = false;
     for (int s = 0; s < 2; ++s) {
         if (lazy) {
             c->raw_rows[s] = psm_ctx::RAW_NONE;
@@ -610,7 +648,7 @@ static int filter_side(psm_ctx *c, int side, bool stage_b)
             return check_launch(c, "cvf (fused, select mode, shared keys)");
         }
         const bool dynsel = !q2 && (c->march.flags & 524288);    // flag 524288: dynamic slice distribution (measured slower)
-        const PcPlan pl = q2 ? q2_plan(W, H, c->Dloc, c->march.seg_rows) : pc_plan(W, H, c->Dloc, c->march.seg_rows, dynsel ? 5 : 1);
+        const PcPlan pl = q2 ? q2_plan(W, H, c->Dloc, c->march.seg_rows) : pc_plan(W, c->march.rows(H), c->Dloc, c->march.seg_rows, dynsel ? 5 : 1);
         if (ensure_gf_scratch(c, pl.scratch_bytes())) return 1;
         if (dynsel && ensure_gf_cnt(c, 2 * (size_t)pl.ngroups * pl.nsegs)) return 1;
         const size_t HW = (size_t)W * H;
@@ -735,11 +773,25 @@ static bool can_filter_both(const psm_ctx *c)
 
 static int filter_both(psm_ctx *c)
 {
-    if (!c->have_g1 && run_prep(c)) return 1;
+    {   // g1 rows this launch reads: everything, or the stripe's rows - 8 .. + 8
+        const bool striped = c->march.yend > c->march.ybeg;
+        const int ya = striped ? (c->march.ybeg - 8 > 0 ? c->march.ybeg - 8 : 0) : 0;
+        const int yb = striped ? (c->march.yend + 8 < c->H ? c->march.yend + 8 : c->H) : c->H;
+        if (!c->have_g1 && !(c->g1_y1 > c->g1_y0 && c->g1_y0 <= ya && c->g1_y1 >= yb) && run_prep(c)) return 1;
+    }
     if (!(c->have_guid[0] && c->have_guid[1])) {
-        Prof p(c, PSM_K_GUIDE);
-        launch_guidance(c->stream, c->g[0], nullptr, c->W, c->H, 0, &c->g[1]);
-        c->have_guid[0] = c->have_guid[1] = true;
+        // a row stripe needs the guidance of its model rows only: y0 - 4 .. y1 + 2 (have_guid stays false: the planes are not
+        // whole, any other consumer recomputes them; guid_y0/1 remember what is there for the next frame's check)
+        const bool striped = c->march.yend > c->march.ybeg;
+        const int gy0 = striped ? (c->march.ybeg - 4 > 0 ? c->march.ybeg - 4 : 0) : 0;
+        const int gy1 = striped ? (c->march.yend + 4 < c->H ? c->march.yend + 4 : c->H) : c->H;
+        if (!(c->guid_y1 > c->guid_y0 && c->guid_y0 <= gy0 && c->guid_y1 >= gy1)) {
+            Prof p(c, PSM_K_GUIDE);
+            launch_guidance(c->stream, c->g[0], nullptr, c->W, c->H, 0, &c->g[1], gy0, gy1);
+            c->guid_y0 = gy0;
+            c->guid_y1 = gy1;
+            if (gy0 == 0 && gy1 == c->H) c->have_guid[0] = c->have_guid[1] = true;
+        }
     }
     if (c->march.flags & 262144) {
         Prof p(c, PSM_K_CVF_F);
@@ -758,7 +810,7 @@ static int filter_both(psm_ctx *c)
     const bool two_phase = !dynsel && !(c->march.flags & 2097152) && c->Dloc >= 2 && (c->Dloc >= 160 || (c->march.flags & 1048576));
     if (two_phase) {
         const int n1 = (c->Dloc + S - 1) / S, n2 = c->Dloc - n1;
-        const PcPlan pl1 = pc_plan(c->W, c->H, n1, c->march.seg_rows, 2);
+        const PcPlan pl1 = pc_plan(c->W, c->march.rows(c->H), n1, c->march.seg_rows, 2);
         if (ensure_gf_scratch(c, 2 * pl1.scratch_bytes())) return 1;
         {
             Prof p(c, PSM_K_CVF_F);
@@ -775,7 +827,7 @@ static int filter_both(psm_ctx *c)
         c->gf_virtual[0] = c->gf_virtual[1] = true;
         return check_launch(c, "cvf (fused, select mode, two phases, both volumes)");
     }
-    const PcPlan pl = pc_plan(c->W, c->H, c->Dloc, c->march.seg_rows, dynsel ? 6 : 2);
+    const PcPlan pl = pc_plan(c->W, c->march.rows(c->H), c->Dloc, c->march.seg_rows, dynsel ? 6 : 2);
     if (ensure_gf_scratch(c, 2 * pl.scratch_bytes())) return 1;
     if (dynsel && ensure_gf_cnt(c, 2 * (size_t)pl.ngroups * pl.nsegs)) return 1;
     {
@@ -799,13 +851,17 @@ int psm_cost_filter(psm_ctx *c)
     if (bind(c)) return 1;
     const double t0 = now_us();
     // preprocess L, filter L, preprocess R, filter R (src/DispEst.cpp:302-305)
+    const bool striped = c->march.yend > c->march.ybeg;
     if (can_filter_both(c)) {
         if (filter_both(c)) return 1;
     } else {
+        if (striped) return fail(c, "psm_cost_filter: a row stripe (psm_set_rows) needs the default select form of the filter "
+                                    "(no variant / storing / per-side flags, cost volumes not materialised)");
         for (int s = 0; s < 2; ++s)
             if (filter_side(c, s, true)) return 1;
     }
     c->have_maps = false;
+    c->have_rows = striped;
     return end_stage(c, PSM_STAGE_CVF, t0);
 }
 
@@ -1006,6 +1062,75 @@ int psm_disp_select_partial_side(psm_ctx *c, int side, void *dev_keys_side)
     return 0;
 }
 
+int psm_set_rows(psm_ctx *c, int y_begin, int y_end)
+{
+    if (!c) return 1;
+    // (takes effect with the next psm_cost_filter; minima / maps already computed keep describing the stripe they were made for)
+    if (y_begin == 0 && (y_end == 0 || y_end == c->H)) {   // whole image
+        c->march.ybeg = c->march.yend = 0;
+        return 0;
+    }
+    if (y_begin < 0 || y_end > c->H || y_begin >= y_end) return fail(c, "psm_set_rows: bad stripe [%d,%d) of %d rows", y_begin, y_end, c->H);
+    c->march.ybeg = y_begin;
+    c->march.yend = y_end;
+    return 0;
+}
+
+int psm_set_map_buffer(psm_ctx *c, void *dev_maps, int whole)
+{
+    if (!c) return 1;
+    uint8_t *m = dev_maps ? (uint8_t *)dev_maps : c->maps_own;
+    if (m != c->maps) { c->have_maps = false; c->have_valid = false; }
+    c->maps = m;
+    if (whole) {    // the caller filled the buffer with both complete maps of the current frame (e.g. gathered row stripes)
+        c->have_maps = true;
+        c->have_rows = false;
+        c->have_valid = false;
+    }
+    return 0;
+}
+
+int psm_gather_rows_ctx(psm_ctx *root, psm_ctx *const *stripes, int nstripes, uint8_t *lmap, uint8_t *rmap, size_t stride)
+{
+    if (!root) return 1;
+    if (!stripes || nstripes < 1) return fail(root, "psm_gather_rows_ctx: bad arguments");
+    std::vector<char> covered((size_t)root->H, 0);
+    for (int i = 0; i < nstripes; ++i) {
+        const psm_ctx *s = stripes[i];
+        if (!s || s->W != root->W || s->H != root->H || s->D != root->D || s->dtype != root->dtype)
+            return fail(root, "psm_gather_rows_ctx: stripe %d does not belong to this job", i);
+        if (!s->have_maps) return fail(root, "psm_gather_rows_ctx: stripe %d has no maps for this frame (call psm_disp_select first)", i);
+        for (int y = s->march.y0(s->H); y < s->march.y1(s->H); ++y) {
+            if (covered[y]) return fail(root, "psm_gather_rows_ctx: row %d is held by more than one stripe", y);
+            covered[y] = 1;
+        }
+    }
+    for (int y = 0; y < root->H; ++y)
+        if (!covered[y]) return fail(root, "psm_gather_rows_ctx: no stripe holds row %d", y);
+    if (bind(root)) return 1;
+    const size_t HW = (size_t)root->W * root->H;
+    for (int i = 0; i < nstripes; ++i) {
+        psm_ctx *s = stripes[i];
+        if (s == root) continue;
+        (void)hipSetDevice(s->device);
+        PSM_HIP(root, hipStreamSynchronize(s->stream));     // the stripe's maps must be complete before they are read
+        (void)hipSetDevice(root->device);
+        const size_t o = (size_t)s->march.y0(s->H) * root->W, n = (size_t)s->march.rows(s->H) * root->W;
+        for (int side = 0; side < 2; ++side) {
+            if (s->device == root->device)
+                PSM_HIP(root, hipMemcpyAsync(root->maps + side * HW + o, s->maps + side * HW + o, n, hipMemcpyDeviceToDevice, root->stream));
+            else
+                PSM_HIP(root, hipMemcpyPeerAsync(root->maps + side * HW + o, root->device, s->maps + side * HW + o, s->device, n, root->stream));
+        }
+    }
+    root->have_maps = true;
+    root->have_rows = false;      // the root's maps are whole now
+    root->have_valid = false;
+    if (copy_maps_out(root, root->maps, lmap, rmap, stride)) return 1;
+    if (!root->opt_async) PSM_HIP(root, hipStreamSynchronize(root->stream));
+    return 0;
+}
+
 int psm_set_key_buffer(psm_ctx *c, void *dev_keys)
 {
     if (!c) return 1;
@@ -1098,6 +1223,7 @@ int psm_lr_check(psm_ctx *c, uint8_t *lvalid, uint8_t *rvalid, size_t stride)
 {
     if (!c) return 1;
     if (!c->have_maps) return fail(c, "psm_lr_check: no disparity maps computed");
+    if (c->have_rows) return fail(c, "psm_lr_check: the maps hold this context's row stripe only (gather the stripes first)");
     if (bind(c)) return 1;
     const double t0 = now_us();
     const size_t HW = (size_t)c->W * c->H;

@@ -23,13 +23,19 @@ struct March {       // geometry of the marching kernels
     int waves;       // waves (= disparity slices) per workgroup: 1,2,4,8
     int flags;       // PSM_OPT_FLAGS (include/primesm_hip.h): bit 0 nontemporal stores of 4-byte outputs, bits 1-2
                      // block traversal order of stage A, bit 6 plain CVC kernel, ...
+    int ybeg = 0, yend = 0;   // row stripe of the select-form filter (psm_set_rows): output rows [ybeg, yend) of the whole
+                              // image; yend <= ybeg: all rows
+    int y0(int H) const { (void)H; return yend > ybeg ? ybeg : 0; }
+    int y1(int H) const { return yend > ybeg ? yend : H; }
+    int rows(int H) const { return y1(H) - y0(H); }
 };
 
 // image -> g1 (planarise, scale, gray, x-gradient).  src: device copy of the interleaved image.
 void launch_prep(hipStream_t s, const void *src, size_t pitch, int depth_f32, int W, int H, float4 *g1, const void *src1 = nullptr,
                  float4 *g11 = nullptr);
 // g1 -> g2,g3,g4.  hs9: scratch, 9*H*W doubles.
-void launch_guidance(hipStream_t s, Guidance g, double *hs9, int W, int H, int two_pass, const Guidance *second = nullptr);
+void launch_guidance(hipStream_t s, Guidance g, double *hs9, int W, int H, int two_pass, const Guidance *second = nullptr,
+                     int ybeg = 0, int yend = 0);   // [ybeg, yend): rows of g2..g4 to produce (single-pass form; default all)
 // cost volume slices [d_begin, d_begin+Dloc) of one side.  base: g1 of the side's own image.
 void launch_cvc(hipStream_t s, const float4 *g1_base, const float4 *g1_other, float *vol, int W, int H,
                 int d_begin, int Dloc, int right, int flags, int ybeg, int yend);

@@ -176,7 +176,7 @@ __device__ __forceinline__ void guide_finish(const float *m, float4 &g2, float4 
 }
 
 __global__ __launch_bounds__(64) void k_guide_march(const float4 *g1, int W, int H, int nstrips, int seg_rows,
-                                                   float4 *g2, float4 *g3, float2 *g4, Guidance second)
+                                                   float4 *g2, float4 *g3, float2 *g4, Guidance second, int ybeg, int yend)
 {
     if (blockIdx.y == 1) { g1 = second.g1; g2 = second.g2; g3 = second.g3; g4 = second.g4; }   // second image of a two-image launch
     const int strip = blockIdx.x % nstrips, seg = blockIdx.x / nstrips;
@@ -184,7 +184,7 @@ __global__ __launch_bounds__(64) void k_guide_march(const float4 *g1, int W, int
     const int x0 = strip * 56;
     const int cs = r101c(x0 - 4 + lane, W), xo = x0 + lane;
     const bool ovalid = lane < 56 && xo < W;
-    const int y0 = seg * seg_rows, y1 = min(H, y0 + seg_rows);
+    const int y0 = ybeg + seg * seg_rows, y1 = min(yend, y0 + seg_rows);   // output rows [y0, y1) of the rows [ybeg, yend) asked for
     const int n = (y1 - y0) + 7, ybase = y0 - 4;
     const int i1 = ((lane + 1) & 63) << 2, i2 = ((lane + 2) & 63) << 2, i4 = ((lane + 4) & 63) << 2;
     (void)i1;
@@ -220,17 +220,20 @@ __global__ __launch_bounds__(64) void k_guide_march(const float4 *g1, int W, int
     }
 }
 
-void launch_guidance(hipStream_t s, Guidance g, double *hs9, int W, int H, int two_pass, const Guidance *second)
-{   // second != NULL (single-pass form only): the guidance of both images in one launch
+void launch_guidance(hipStream_t s, Guidance g, double *hs9, int W, int H, int two_pass, const Guidance *second, int ybeg, int yend)
+{   // second != NULL (single-pass form only): the guidance of both images in one launch; [ybeg, yend) (single-pass form only,
+    // yend <= ybeg: all rows): the rows of g2..g4 to produce - a row stripe of the filter needs its own rows + 4 either side
     if (!two_pass) {
+        if (yend <= ybeg) { ybeg = 0; yend = H; }
+        const int rows = yend - ybeg;
         // one wave per (strip, segment): ~2048 waves over both images = one resident round (two per SIMD at 199 VGPRs), 8..64 rows each
         const int nstrips = (W + 55) / 56;
         const int waves = second ? 1024 : 2048;                  // per image
         int seg_rows = 8;                                        // shortest segment whose waves fit one round
-        while (seg_rows < 64 && nstrips * ((H + seg_rows - 1) / seg_rows) > waves) ++seg_rows;
-        const int nsegs = (H + seg_rows - 1) / seg_rows;
+        while (seg_rows < 64 && nstrips * ((rows + seg_rows - 1) / seg_rows) > waves) ++seg_rows;
+        const int nsegs = (rows + seg_rows - 1) / seg_rows;
         hipLaunchKernelGGL(k_guide_march, dim3(nstrips * nsegs, second ? 2 : 1), dim3(64), 0, s, (const float4 *)g.g1, W, H, nstrips, seg_rows, g.g2, g.g3, g.g4,
-                           second ? *second : Guidance{});
+                           second ? *second : Guidance{}, ybeg, yend);
         return;
     }
     dim3 grid((W + 255) / 256, H);

@@ -528,7 +528,8 @@ __global__ __launch_bounds__(64 * (PcLayout<MODE>::NA + PcLayout<MODE>::NB)) PSM
 // One thread per record (pair, batch, column) = four rows of one column, as the select kernel wrote them.
 __global__ __launch_bounds__(256) void k_chunk_min(const float4 *kcost, const unsigned *kdisp, int nchunks, int npairs,
                                                   int nbmax, int ngroups, int seg_rows, int W, int H, long long *keys,
-                                                  uint8_t *map, const float4 *__restrict__ kcost1, const unsigned *__restrict__ kdisp1)
+                                                  uint8_t *map, const float4 *__restrict__ kcost1, const unsigned *__restrict__ kdisp1,
+                                                  int ybeg, int yend)
 {
     using L = PcLayout<1>;
     if (blockIdx.y == 1) {   // second volume of a two-side launch: its own planes, keys / map one image further
@@ -547,7 +548,7 @@ __global__ __launch_bounds__(256) void k_chunk_min(const float4 *kcost, const un
     const int g = pair % ngroups, seg = pair / ngroups;
     const int x = g * L::COLS + col;
     if (x >= W) return;
-    const int y0 = seg * seg_rows, y1 = min(H, y0 + seg_rows);
+    const int y0 = ybeg + seg * seg_rows, y1 = min(yend, y0 + seg_rows);
     const int ya = y0 + 4 * c - 7;                                  // output row of the record's first entry
     if (ya + 3 < y0 || ya >= y1) return;
     float4 kc = kcost[idx];
@@ -702,7 +703,7 @@ void launch_cvf_select(hipStream_t s, March m, const float *vin, Guidance gd, in
                        int d_begin, int cvc_mode, void *scratch, int *cnt, const uint8_t *p4_own, const uint8_t *p4_other, int sel, int step)
 {   // p4_own != NULL (cvc_mode 1 / 2 only): 8-bit char mode; cnt != NULL: dynamic slice distribution (npairs ints, zeroed here)
     // Dloc = number of slices of this launch, (sel, step) = which ones (PcDyn)
-    const PcPlan pl = pc_plan(W, H, Dloc, m.seg_rows, cnt ? 5 : 1);
+    const PcPlan pl = pc_plan(W, m.rows(H), Dloc, m.seg_rows, cnt ? 5 : 1);
     const PcDyn dyn = {cnt, pl.NW, sel, step};
     if (cnt) (void)hipMemsetAsync(cnt, 0, sizeof(int) * pl.ngroups * pl.nsegs, s);
     float *kcost = (float *)scratch;                                           // nchunks * rec_per_chunk float4
@@ -712,12 +713,12 @@ void launch_cvf_select(hipStream_t s, March m, const float *vin, Guidance gd, in
 #define PSM_LAUNCH_PC(CV)                                                                                                   \
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_cvf_pc<false, CV, 1>), dim3(nblocks), blk, 0, s, vin, (float *)nullptr, (const float4 *)gd.g1, \
                        (const float4 *)gd.g2, (const float4 *)gd.g3, (const float2 *)gd.g4, W, H, Dloc, pl.ngroups, pl.nsegs, \
-                       pl.seg_rows, 0, H, g1_other, d_begin, pl.DC, kcost, kdisp, pl.nbmax, PcSide{}, dyn)
+                       pl.seg_rows, m.y0(H), m.y1(H), g1_other, d_begin, pl.DC, kcost, kdisp, pl.nbmax, PcSide{}, dyn)
     if (p4_own && cvc_mode != 0) {
 #define PSM_LAUNCH_PC8(CV)                                                                                                  \
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_cvf_pc<false, CV, 1, true>), dim3(nblocks), blk, 0, s, (const float *)p4_own, (float *)const_cast<uint8_t *>(p4_other), \
                        (const float4 *)gd.g1, (const float4 *)gd.g2, (const float4 *)gd.g3, (const float2 *)gd.g4, W, H, Dloc, pl.ngroups, pl.nsegs, \
-                       pl.seg_rows, 0, H, g1_other, d_begin, pl.DC, kcost, kdisp, pl.nbmax, PcSide{}, dyn)
+                       pl.seg_rows, m.y0(H), m.y1(H), g1_other, d_begin, pl.DC, kcost, kdisp, pl.nbmax, PcSide{}, dyn)
         if (cvc_mode == 1) PSM_LAUNCH_PC8(1); else PSM_LAUNCH_PC8(2);
 #undef PSM_LAUNCH_PC8
     } else if (cvc_mode == 1) PSM_LAUNCH_PC(1); else if (cvc_mode == 2) PSM_LAUNCH_PC(2); else PSM_LAUNCH_PC(0);
@@ -728,7 +729,7 @@ void launch_cvf_select(hipStream_t s, March m, const float *vin, Guidance gd, in
 void launch_cvf_select_keys(hipStream_t s, March m, const float *vin, Guidance gd, int W, int H, int Dloc, const float4 *g1_other,
                             int d_begin, int cvc_mode, long long *keys, const uint8_t *p4_own, const uint8_t *p4_other, int init, int sel, int step)
 {   // init: start from key(+inf, 0); otherwise continue from what `keys` holds (second phase of the two-phase selection)
-    const PcPlan pl = pc_plan(W, H, Dloc, m.seg_rows, 3);
+    const PcPlan pl = pc_plan(W, m.rows(H), Dloc, m.seg_rows, 3);
     const size_t HW = (size_t)W * H;
     if (init) hipLaunchKernelGGL(k_fill_keys, dim3((unsigned)((HW + 255) / 256)), dim3(256), 0, s, keys, HW);
     const int nblocks = 8 * ((pl.ngroups * pl.nsegs * Dloc + 7) / 8);
@@ -736,7 +737,7 @@ void launch_cvf_select_keys(hipStream_t s, March m, const float *vin, Guidance g
 #define PSM_LAUNCH_K(CV, U8V, A0, A1)                                                                                       \
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_cvf_pc<false, CV, 2, U8V>), dim3(nblocks), blk, 0, s, A0, A1, (const float4 *)gd.g1, \
                        (const float4 *)gd.g2, (const float4 *)gd.g3, (const float2 *)gd.g4, W, H, Dloc, pl.ngroups, pl.nsegs, \
-                       pl.seg_rows, 0, H, g1_other, d_begin, 1, (float *)keys, (unsigned *)nullptr, 0, PcSide{}, PcDyn{nullptr, 0, sel, step})
+                       pl.seg_rows, m.y0(H), m.y1(H), g1_other, d_begin, 1, (float *)keys, (unsigned *)nullptr, 0, PcSide{}, PcDyn{nullptr, 0, sel, step})
     if (p4_own && cvc_mode != 0) {
         if (cvc_mode == 1) PSM_LAUNCH_K(1, true, (const float *)p4_own, (float *)const_cast<uint8_t *>(p4_other));
         else PSM_LAUNCH_K(2, true, (const float *)p4_own, (float *)const_cast<uint8_t *>(p4_other));
@@ -750,7 +751,7 @@ void launch_cvf_select_keys(hipStream_t s, March m, const float *vin, Guidance g
 void launch_cvf_select_keys2(hipStream_t s, March m, const Guidance *g, int W, int H, int Dloc, int d_begin, long long *keys,
                              const uint8_t *const *p4, int init, int sel, int step)
 {
-    const PcPlan pl = pc_plan(W, H, Dloc, m.seg_rows, 4);
+    const PcPlan pl = pc_plan(W, m.rows(H), Dloc, m.seg_rows, 4);
     const size_t HW = (size_t)W * H;
     if (init) hipLaunchKernelGGL(k_fill_keys, dim3((unsigned)((2 * HW + 255) / 256)), dim3(256), 0, s, keys, 2 * HW);
     const int nblocks = 8 * ((pl.ngroups * pl.nsegs * Dloc + 7) / 8);
@@ -760,21 +761,21 @@ void launch_cvf_select_keys2(hipStream_t s, March m, const Guidance *g, int W, i
     if (p4)
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_cvf_pc<false, 3, 2, true>), dim3(nblocks, 2), blk, 0, s, (const float *)p4[0], (float *)const_cast<uint8_t *>(p4[1]),
                            (const float4 *)g[0].g1, (const float4 *)g[0].g2, (const float4 *)g[0].g3, (const float2 *)g[0].g4, W, H, Dloc, pl.ngroups,
-                           pl.nsegs, pl.seg_rows, 0, H, (const float4 *)g[1].g1, d_begin, 1, (float *)keys, (unsigned *)nullptr, 0, s1, PcDyn{nullptr, 0, sel, step});
+                           pl.nsegs, pl.seg_rows, m.y0(H), m.y1(H), (const float4 *)g[1].g1, d_begin, 1, (float *)keys, (unsigned *)nullptr, 0, s1, PcDyn{nullptr, 0, sel, step});
     else
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_cvf_pc<false, 3, 2, false>), dim3(nblocks, 2), blk, 0, s, (const float *)nullptr, (float *)nullptr,
                            (const float4 *)g[0].g1, (const float4 *)g[0].g2, (const float4 *)g[0].g3, (const float2 *)g[0].g4, W, H, Dloc, pl.ngroups,
-                           pl.nsegs, pl.seg_rows, 0, H, (const float4 *)g[1].g1, d_begin, 1, (float *)keys, (unsigned *)nullptr, 0, s1, PcDyn{nullptr, 0, sel, step});
+                           pl.nsegs, pl.seg_rows, m.y0(H), m.y1(H), (const float4 *)g[1].g1, d_begin, 1, (float *)keys, (unsigned *)nullptr, 0, s1, PcDyn{nullptr, 0, sel, step});
 }
 
 void launch_chunk_min(hipStream_t s, March m, int W, int H, int Dloc, void *scratch, long long *keys, uint8_t *map, int dynamic)
 {
-    const PcPlan pl = pc_plan(W, H, Dloc, m.seg_rows, dynamic ? 5 : 1);
+    const PcPlan pl = pc_plan(W, m.rows(H), Dloc, m.seg_rows, dynamic ? 5 : 1);
     const float *kcost = (const float *)scratch;
     const unsigned *kdisp = (const unsigned *)(kcost + 4 * pl.rec_per_chunk * pl.nchunks);
     hipLaunchKernelGGL(k_chunk_min, dim3((unsigned)((pl.rec_per_chunk + 255) / 256)), dim3(256), 0, s, (const float4 *)kcost, (const unsigned *)kdisp,
                        pl.nchunks, pl.ngroups * pl.nsegs, pl.nbmax, pl.ngroups, pl.seg_rows, W, H, keys, map, (const float4 *)nullptr,
-                       (const unsigned *)nullptr);
+                       (const unsigned *)nullptr, m.y0(H), m.y1(H));
 }
 
 // Both volumes in one launch each (costs built on the fly): left volume = (g[0], other g[1].g1), right = (g[1], other g[0].g1);
@@ -783,7 +784,7 @@ void launch_cvf_select2(hipStream_t s, March m, const Guidance *g, int W, int H,
                         const uint8_t *const *p4, int sel, int step)
 {   // p4 != NULL: 8-bit char mode, p4[0] / p4[1] = byte planes {c0,c1,c2,grad} of the left / right image
     // cnt != NULL: dynamic slice distribution (2 * npairs ints, zeroed here)
-    const PcPlan pl = pc_plan(W, H, Dloc, m.seg_rows, cnt ? 6 : 2);
+    const PcPlan pl = pc_plan(W, m.rows(H), Dloc, m.seg_rows, cnt ? 6 : 2);
     const PcDyn dyn = {cnt, pl.NW, sel, step};
     if (cnt) (void)hipMemsetAsync(cnt, 0, sizeof(int) * 2 * pl.ngroups * pl.nsegs, s);
     float *kcost0 = (float *)scratch;
@@ -796,22 +797,22 @@ void launch_cvf_select2(hipStream_t s, March m, const Guidance *g, int W, int H,
     if (p4)
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_cvf_pc<false, 3, 1, true>), dim3(nblocks, 2), blk, 0, s, (const float *)p4[0], (float *)const_cast<uint8_t *>(p4[1]),
                            (const float4 *)g[0].g1, (const float4 *)g[0].g2, (const float4 *)g[0].g3, (const float2 *)g[0].g4, W, H, Dloc, pl.ngroups,
-                           pl.nsegs, pl.seg_rows, 0, H, (const float4 *)g[1].g1, d_begin, pl.DC, kcost0, kdisp0, pl.nbmax, s1, dyn);
+                           pl.nsegs, pl.seg_rows, m.y0(H), m.y1(H), (const float4 *)g[1].g1, d_begin, pl.DC, kcost0, kdisp0, pl.nbmax, s1, dyn);
     else
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_cvf_pc<false, 3, 1>), dim3(nblocks, 2), blk, 0, s, (const float *)nullptr, (float *)nullptr, (const float4 *)g[0].g1,
-                           (const float4 *)g[0].g2, (const float4 *)g[0].g3, (const float2 *)g[0].g4, W, H, Dloc, pl.ngroups, pl.nsegs, pl.seg_rows, 0, H,
+                           (const float4 *)g[0].g2, (const float4 *)g[0].g3, (const float2 *)g[0].g4, W, H, Dloc, pl.ngroups, pl.nsegs, pl.seg_rows, m.y0(H), m.y1(H),
                            (const float4 *)g[1].g1, d_begin, pl.DC, kcost0, kdisp0, pl.nbmax, s1, dyn);
 }
 
 void launch_chunk_min2sides(hipStream_t s, March m, int W, int H, int Dloc, void *scratch, long long *keys, uint8_t *map, int dynamic)
 {
-    const PcPlan pl = pc_plan(W, H, Dloc, m.seg_rows, dynamic ? 6 : 2);
+    const PcPlan pl = pc_plan(W, m.rows(H), Dloc, m.seg_rows, dynamic ? 6 : 2);
     const float *kcost0 = (const float *)scratch;
     const unsigned *kdisp0 = (const unsigned *)(kcost0 + 4 * pl.rec_per_chunk * pl.nchunks);
     const float *kcost1 = (const float *)((const char *)scratch + pl.scratch_bytes());
     const unsigned *kdisp1 = (const unsigned *)(kcost1 + 4 * pl.rec_per_chunk * pl.nchunks);
     hipLaunchKernelGGL(k_chunk_min, dim3((unsigned)((pl.rec_per_chunk + 255) / 256), 2), dim3(256), 0, s, (const float4 *)kcost0, kdisp0,
-                       pl.nchunks, pl.ngroups * pl.nsegs, pl.nbmax, pl.ngroups, pl.seg_rows, W, H, keys, map, (const float4 *)kcost1, kdisp1);
+                       pl.nchunks, pl.ngroups * pl.nsegs, pl.nbmax, pl.ngroups, pl.seg_rows, W, H, keys, map, (const float4 *)kcost1, kdisp1, m.y0(H), m.y1(H));
 }
 
 }  // namespace psm

@@ -204,6 +204,24 @@ class DispEst:
                                               _ptr(self.rDisMap) if download else None, self.wid),
                  "DispSelect_merge_ctx")
 
+    def set_rows(self, y_begin: int = 0, y_end: int = 0):
+        """Row stripe: CostFilter_GPU / DispSelect* compute output rows [y_begin, y_end) of the whole image only (all
+        slices, both volumes, identical values); (0, 0): whole image.  Call before CostFilter_GPU."""
+        self._ck(self._lib.psm_set_rows(self._h, int(y_begin), int(y_end)), "set_rows")
+
+    def set_map_buffer(self, dev_maps_ptr: int | None, whole: bool = False):
+        """The device maps [2][H][W] uint8 live in this device buffer (>= 2*H*W + 4 bytes) from now on; None: own buffer.
+        whole: the buffer already holds both complete maps of the current frame."""
+        self._ck(self._lib.psm_set_map_buffer(self._h, C.c_void_p(dev_maps_ptr or 0), int(whole)), "set_map_buffer")
+
+    def gather_rows_ctx(self, stripes, download: bool = True):
+        """Single-process exchange of the row-stripe sharding: the stripe rows of every context's maps -> this context."""
+        arr = (C.c_void_p * len(stripes))(*[s._h for s in stripes])
+        self._ck(self._lib.psm_gather_rows_ctx(self._h, arr, len(stripes),
+                                               _ptr(self.lDisMap) if download else None,
+                                               _ptr(self.rDisMap) if download else None, self.wid),
+                 "gather_rows_ctx")
+
     def DispSelect_device(self):
         """WTA with the maps left on the device (bench: D2H excluded from the timed region)."""
         self._ck(self._lib.psm_disp_select(self._h, None, None, 0), "DispSelect_device")

@@ -1,4 +1,3 @@
 #!/bin/bash
 cd $GRAFT_REPO_ROOT
-timeout 600 python -m pytest tests/test_gpu_pp_ocv.py -m gpu -q -x -p no:cacheprovider --timeout=300 2>&1 | tail -2
-timeout 300 python scripts/dbg_wmf.py big 2>&1 | tail -5
+timeout 1200 python -m pytest tests -m gpu -q -x -p no:cacheprovider --timeout=600 2>&1 | tail -5

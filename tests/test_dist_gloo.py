@@ -73,3 +73,54 @@ def test_pack_keys_order():
     order = np.argsort(k, kind="stable")
     assert list(order) == [3, 5, 4, 6, 2, 1, 0]     # -2 < (+-0: d=6 < d=7) < denormal < (1.0: d=4 < d=5) < inf
     assert np.array_equal(unpack_disp(k), d.astype(np.uint8))
+
+
+def _stripe_worker(rank, world, port, H, W, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from primestereomatch_amd import stripes
+        rng = np.random.default_rng(7)                          # the same "whole-image" maps on every rank
+        full = rng.integers(0, 256, size=(2, H, W), dtype=np.uint8)
+        R, y0, y1 = stripes.stripe_bounds(H, world, rank)
+        mine = torch.full((2 * H * W + 4,), 255, dtype=torch.uint8)       # rows outside the stripe: garbage, never sent
+        mine[:2 * H * W].view(2, H, W)[:, y0:y1] = torch.from_numpy(full[:, y0:y1].copy())
+        send = torch.zeros(2 * R * W, dtype=torch.uint8)
+        recv = torch.zeros(world * 2 * R * W, dtype=torch.uint8)
+        stripes.pack_stripe(mine, y0, y1, send, H, W, R)
+        dist.all_gather_into_tensor(recv, send)                 # the one exchange step of bench.py --shard rows
+        out = torch.zeros(2 * H * W + 4, dtype=torch.uint8)
+        stripes.assemble(recv, world, H, W, R, out)
+        q.put((rank, bool(np.array_equal(out[:2 * H * W].view(2, H, W).numpy(), full))))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,H", [(2, 12), (3, 10), (2, 7), (4, 9)])
+def test_row_stripe_gather_rebuilds_the_maps(world, H):
+    """bench.py --shard rows: aligned stripes of ceil(H / N) rows, one all_gather, a transpose - also when H % N != 0, when
+    the last rank's stripe is shorter, and when it is empty (N = 4, H = 9: 3-row stripes; bench.py itself refuses that)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29700 + world * 20 + H
+    procs = [ctx.Process(target=_stripe_worker, args=(r, world, port, H, 11, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+    assert all(res[r] for r in range(world)), res
+
+
+def test_stripe_bounds_tile_the_image():
+    from primestereomatch_amd import stripes
+    for H in (1, 7, 288, 375, 1080, 2160):
+        for G in (1, 2, 3, 4, 8):
+            rows = []
+            for g in range(G):
+                R, y0, y1 = stripes.stripe_bounds(H, G, g)
+                assert 0 <= y0 <= y1 <= H and y1 - y0 <= R and (y0 == g * R or y0 == H)
+                rows += list(range(y0, y1))
+            assert rows == list(range(H))

@@ -34,18 +34,28 @@ def test_bench_line_live_small_config():
     assert j["median_ms_per_step"] > 0 and j["pcie"]["h2d_ms"] > 0 and j["pcie"]["d2h_ms"] > 0
 
 
-@pytest.mark.parametrize("exchange", ["allreduce", "allgather"])
-def test_distributed_path_world1_verified(exchange):
-    """The RCCL call sequence of the N > 1 bench (packed-key local WTA, collective, merge) with one rank, maps checked
-    against the plain single-context run."""
-    j = _bench("--gpus", "1", "--force-dist", "--exchange", exchange, "--config", "c3", "--steps", "3", "--warmup", "1",
-               "--no-cpu-baseline")
-    assert j["verified_vs_single_gpu"] is True and j["scaling"] == "strong"
+@pytest.mark.parametrize("shard,exchange,extra", [("rows", "allreduce", ()), ("rows", "allreduce", ("--no-frame-pipeline",)),
+                                                  ("disp", "allreduce", ()), ("disp", "allgather", ())])
+def test_distributed_path_world1_verified(shard, exchange, extra):
+    """The RCCL call sequence of the N > 1 bench with one rank, maps checked against the plain single-context run:
+    row stripes (all_gather of the finished map rows into torch-owned map tensors) and disparity shards (packed-key local
+    WTA, collective, merge)."""
+    j = _bench("--gpus", "1", "--force-dist", "--shard", shard, "--exchange", exchange, "--config", "c3", "--steps", "3", "--warmup", "1",
+               "--no-cpu-baseline", *extra)
+    assert j["verified_vs_single_gpu"] is True and j["scaling"] == "strong" and j["config"]["shard"] == shard
 
 
-def test_distributed_path_world2_rccl_when_two_gpus():
+@pytest.mark.parametrize("shard", ["rows", "disp"])
+def test_distributed_path_world2_rccl_when_two_gpus(shard):
     from primestereomatch_amd import capi
     if capi.device_count() < 2:
         pytest.skip("needs 2 GPUs (the driver's multi-GPU bench covers N > 1 on an 8-GPU node)")
-    j = _bench("--gpus", "2", "--config", "c3", "--steps", "3", "--warmup", "1", "--no-cpu-baseline")   # bare command: self-launch
+    j = _bench("--gpus", "2", "--shard", shard, "--config", "c3", "--steps", "3", "--warmup", "1", "--no-cpu-baseline")   # bare command: self-launch
     assert j["n_gpus"] == 2 and j["verified_vs_single_gpu"] is True
+
+
+@pytest.mark.parametrize("parts", [2, 8])
+def test_one_stripe_of_n_live(parts):
+    """--shard-sim N --shard rows: the rank-local work of an N-way row-stripe run (stripe 0) on this GPU."""
+    j = _bench("--shard-sim", str(parts), "--shard", "rows", "--config", "c3", "--steps", "3", "--warmup", "1", "--no-cpu-baseline")
+    assert j["config"]["shard"] == "rows" and j["ms_per_step"] > 0
