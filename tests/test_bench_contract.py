@@ -105,7 +105,10 @@ def test_bare_multi_gpu_command_becomes_its_own_launcher(monkeypatch):
     assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
     assert cmd[-6:] == ["--gpus", "4", "--steps", "3", "--warmup", "1"] and cmd[-7].endswith("bench.py")
     assert env["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
-    # more ranks than disparity slices is refused up front (one shard per rank)
-    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "100", "--config", "c2"])
+    # more ranks than disparity slices (--shard disp) / than image rows (--shard rows, the default) is refused up front
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "100", "--config", "c2", "--shard", "disp"])
+    with pytest.raises(SystemExit):
+        bench.main()
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "400", "--config", "c2"])
     with pytest.raises(SystemExit):
         bench.main()
