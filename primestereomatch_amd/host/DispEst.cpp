@@ -27,19 +27,25 @@ DispEst::DispEst(Mat l, Mat r, const int d, int t, bool ocl, int ndev, int dtype
     const HipApi &api = hipUtil::api();
     int have = api.device_count();
     if (ndev < 1) ndev = 1;
-    if (ndev > have) ndev = have;
-    if (ndev > maxDis) ndev = maxDis;
+    // PSM_HOST_LOGICAL_STRIPES=1: more stripes than devices are allowed, the contexts then share devices (tests on one GPU)
+    const char *logical = std::getenv("PSM_HOST_LOGICAL_STRIPES");
+    const bool share = logical && *logical && *logical != '0' && have > 0;
+    if (ndev > have && !share) ndev = have;
+    if (ndev > hei) ndev = hei;
+    // several devices: one context per device on a stripe of the image rows - all disparities of both volumes, so the WTA
+    // finishes on the device and only finished map rows are gathered (psm_gather_rows_ctx)
     for (int g = 0; g < ndev; ++g) {
         psm_ctx *c = nullptr;
-        int d0 = (int)((long)maxDis * g / ndev), d1 = (int)((long)maxDis * (g + 1) / ndev);
-        if (api.create_shard(&c, wid, hei, maxDis, d0, d1, dtype, g) != 0) {
-            fprintf(stderr, "DispEst: %s\n", api.last_error(nullptr));
+        if (api.create_shard(&c, wid, hei, maxDis, 0, maxDis, dtype, g % have) != 0 ||
+            (ndev > 1 && api.set_rows(c, (int)((long)hei * g / ndev), (int)((long)hei * (g + 1) / ndev)) != 0)) {
+            fprintf(stderr, "DispEst: %s\n", api.last_error(c));
+            if (c) api.destroy(c);
             for (psm_ctx *p : ctx) api.destroy(p);
             ctx.clear();
             useOCL = false;
             return;
         }
-        if (ndev > 1) api.set_option(c, PSM_OPT_ASYNC, 1);  // shards run concurrently
+        if (ndev > 1) api.set_option(c, PSM_OPT_ASYNC, 1);  // the stripes run concurrently
         ctx.push_back(c);
     }
     setInputImages(lImg, rImg);
@@ -100,8 +106,8 @@ int DispEst::DispSelect_GPU()
     const HipApi &api = hipUtil::api();
     if (ctx.size() == 1) return api.disp_select(ctx[0], lDisMap.data, rDisMap.data, lDisMap.step);
     int rc = 0;
-    for (psm_ctx *c : ctx) rc |= api.disp_select_partial(c, nullptr);
-    rc |= api.disp_merge_ctx(ctx[0], ctx.data(), (int)ctx.size(), lDisMap.data, rDisMap.data, lDisMap.step);
+    for (psm_ctx *c : ctx) rc |= api.disp_select(c, nullptr, nullptr, 0);
+    rc |= api.gather_rows_ctx(ctx[0], ctx.data(), (int)ctx.size(), lDisMap.data, rDisMap.data, lDisMap.step);
     return rc;
 }
 

@@ -43,7 +43,8 @@ bool hipUtil::load(const char *path)
               bind(g_api.cost_construct, "psm_cost_construct") && bind(g_api.cost_filter, "psm_cost_filter") &&
               bind(g_api.cost_filter_fgf, "psm_cost_filter_fgf") &&
               bind(g_api.disp_select, "psm_disp_select") && bind(g_api.disp_select_partial, "psm_disp_select_partial") &&
-              bind(g_api.disp_merge_ctx, "psm_disp_merge_ctx") && bind(g_api.lr_check, "psm_lr_check") && bind(g_api.fill_invalid, "psm_fill_invalid") &&
+              bind(g_api.disp_merge_ctx, "psm_disp_merge_ctx") && bind(g_api.set_rows, "psm_set_rows") && bind(g_api.gather_rows_ctx, "psm_gather_rows_ctx") &&
+              bind(g_api.lr_check, "psm_lr_check") && bind(g_api.fill_invalid, "psm_fill_invalid") &&
               bind(g_api.wgt_median, "psm_wgt_median") &&
               bind(g_api.stage_time_us, "psm_stage_time_us");
     if (!ok) {

@@ -25,6 +25,8 @@ struct HipApi {
     int (*disp_select)(psm_ctx *, uint8_t *, uint8_t *, size_t) = nullptr;
     int (*disp_select_partial)(psm_ctx *, void *) = nullptr;
     int (*disp_merge_ctx)(psm_ctx *, psm_ctx *const *, int, uint8_t *, uint8_t *, size_t) = nullptr;
+    int (*set_rows)(psm_ctx *, int, int) = nullptr;
+    int (*gather_rows_ctx)(psm_ctx *, psm_ctx *const *, int, uint8_t *, uint8_t *, size_t) = nullptr;
     int (*lr_check)(psm_ctx *, uint8_t *, uint8_t *, size_t) = nullptr;
     int (*fill_invalid)(psm_ctx *, uint8_t *, uint8_t *, size_t) = nullptr;
     int (*wgt_median)(psm_ctx *, uint8_t *, uint8_t *, size_t) = nullptr;

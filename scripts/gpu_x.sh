@@ -1,3 +1,3 @@
 #!/bin/bash
 cd $GRAFT_REPO_ROOT
-timeout 1200 python -m pytest tests -m gpu -q -x -p no:cacheprovider --timeout=600 2>&1 | tail -5
+timeout 900 python -m pytest tests/test_gpu_stripes.py -m gpu -q -x -p no:cacheprovider --timeout=600 2>&1 | tail -15

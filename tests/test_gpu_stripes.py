@@ -176,3 +176,31 @@ def test_map_buffer_in_caller_memory():
     from conftest import ROOT
     p = subprocess.run([sys.executable, "-c", _MAP_BUFFER_SCRIPT, ROOT], capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert p.returncode == 0 and "map-buffer-ok" in p.stdout, (p.stdout[-1500:], p.stderr[-3000:])
+
+
+@pytest.mark.parametrize("ndev,mode", [(3, "f32"), (2, "u8")])
+def test_cpp_host_mirror_row_stripes(psm, oracle, golden, tmp_path, ndev, mode):
+    """The C++ DispEst mirror with several contexts: one row stripe each (logical stripes on this GPU via
+    PSM_HOST_LOGICAL_STRIPES; on a multi-GPU host one per device), psm_gather_rows_ctx, then the post-processing on the
+    gathered maps - same files as the one-context run."""
+    import os
+    import subprocess
+    from conftest import ROOT
+    demo = os.path.join(ROOT, "primestereomatch_amd", "lib", "psm_demo")
+    subprocess.run(["make", "-C", os.path.join(ROOT, "primestereomatch_amd", "host")], check=True, capture_output=True)
+    pair, gold = golden("teddy_pair.npz"), golden("teddy_oracle_d64.npz")
+    H, W, _ = pair["l_bgr"].shape
+    pair["l_bgr"].tofile(tmp_path / "l.raw")
+    pair["r_bgr"].tofile(tmp_path / "r.raw")
+    env = dict(os.environ, PRIMESM_HIP_LIB=psm.capi.LIB_PATH, PSM_HOST_LOGICAL_STRIPES="1")
+    p = subprocess.run([demo, str(tmp_path / "l.raw"), str(tmp_path / "r.raw"), str(W), str(H), "64",
+                        str(tmp_path / "o"), str(ndev), mode, "0", "0", "1"], env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr
+    ld = np.fromfile(tmp_path / "o_ldisp.raw", np.uint8).reshape(H, W)
+    rd = np.fromfile(tmp_path / "o_rdisp.raw", np.uint8).reshape(H, W)
+    key = ("ldisp", "rdisp") if mode == "f32" else ("ldisp_u8mode", "rdisp_u8mode")
+    assert np.array_equal(ld, gold[key[0]]) and np.array_equal(rd, gold[key[1]])
+    lv = np.fromfile(tmp_path / "o_lvalid.raw", np.uint8).reshape(H, W)
+    assert np.array_equal(lv, oracle.lr_check(ld, rd)[0])
+    lpp = np.fromfile(tmp_path / "o_ldisp_pp.raw", np.uint8).reshape(H, W)
+    assert np.array_equal(lpp, oracle.wgt_median(oracle.u8_to_f32(pair["l_bgr"]), oracle.fill_inv(ld, lv), lv, 64, right=False))
