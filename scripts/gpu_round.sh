@@ -30,12 +30,15 @@ $B --flags 16384 --no-cpu-baseline --verify > $OUT/bench_c4_q2_variant_n1.json 2
 $B --flags 16 --no-cpu-baseline > $OUT/bench_c4_twostage_n1.json 2>> $OUT/bench_var.err
 for s in 2 4 8; do $B --fgf $s --no-cpu-baseline > $OUT/bench_c4_fgf_s${s}_n1.json 2>> $OUT/bench_var.err; done
 for g in 2 4 8; do $B --shard-sim $g --steps 40 --no-cpu-baseline > $OUT/bench_c4_shardsim_1of$g.json 2>> $OUT/bench_var.err; done
+for g in 2 4 8; do $B --shard-sim $g --shard disp --steps 40 --no-cpu-baseline > $OUT/bench_c4_shardsim_disp_1of$g.json 2>> $OUT/bench_var.err; done
+$B --config c5 --shard-sim 8 --steps 6 --warmup 2 --no-cpu-baseline > $OUT/bench_c5_shardsim_1of8.json 2>> $OUT/bench_var.err
 echo "== weighted median timing (sweeps form / dataflow form)"
 timeout 300 python scripts/dbg_wmf.py big > $OUT/wmf_timing.txt 2>&1; WM_FLAGS=4194304 timeout 300 python scripts/dbg_wmf.py >> $OUT/wmf_timing.txt 2>&1; tail -22 $OUT/wmf_timing.txt
 echo "== torch.distributed path on 1 GPU (RCCL, world_size 1)"
 D="timeout 600 python bench.py --gpus 1 --force-dist --steps 10 --warmup 3 --no-cpu-baseline"
 $D > $OUT/bench_c4_dist_world1.json 2> $OUT/bench_dist1.err
-$D --exchange allgather > $OUT/bench_c4_dist_world1_allgather.json 2>> $OUT/bench_dist1.err
+$D --shard disp > $OUT/bench_c4_dist_world1_disp.json 2>> $OUT/bench_dist1.err
+$D --shard disp --exchange allgather > $OUT/bench_c4_dist_world1_allgather.json 2>> $OUT/bench_dist1.err
 $D --no-frame-pipeline > $OUT/bench_c4_dist_world1_nopipeline.json 2>> $OUT/bench_dist1.err
 python - <<PY
 import json,glob
