@@ -379,6 +379,12 @@ def main():
                 roofline["traffic"] = tr[key]    # HBM bytes per launch from rocprofv3 PMC passes (not measured in this run)
                 roofline["traffic_source"] = tr.get("_source", "profiles/traffic.json (rocprofv3 --pmc passes of scripts/gpu_run.sh)")
                 roofline["traffic_GBs"] = round(tr[key] / (dom_ms * 1e-3) / 1e9, 1)   # physical HBM rate of the kernel
+                vi = tr.get(key + "_valu_insts")
+                if vi:
+                    # what bounds it: VALU issue.  256 CUs x 4 SIMDs, one wave-instruction per 4 cycles and SIMD, 2.4 GHz peak
+                    # engine clock (MI355X_MICROARCH.md) -> fraction of the issue slots the launch filled
+                    roofline["valu"] = {"wave_insts_per_launch": vi, "issue_slot_frac_at_2.4GHz": round(vi * 4.0 / (1024 * 2.4e9 * dom_ms * 1e-3), 4),
+                                        "source": "SQ_INSTS_VALU, " + roofline["traffic_source"].replace("{rd,wr}", "sq")}
         except Exception:
             pass
     for nm, v in kern.items():

@@ -61,6 +61,12 @@ def main():
     }
     for k, v in parts.items():
         out["c4:" + k] = {"read": round(v[0]), "write": round(v[1])}
+    # VALU wave-instructions per launch (SQ_INSTS_VALU of the sq pass), same mean: what actually bounds the kernel
+    try:
+        insts = [counters(os.path.join(d, "pmc_sq.summary.txt"), k)["SQ_INSTS_VALU"] for k in parts]
+        out["c4:k_cvf_fused_valu_insts"] = round(sum(insts) / n)
+    except Exception:
+        pass
     try:
         r2, w2 = fabric_bytes(d, "k_chunk_min")
         out["c4:k_chunk_min"] = round(r2 + w2)
