@@ -192,7 +192,7 @@ __global__ __launch_bounds__(64 * (PcLayout<MODE>::NA + PcLayout<MODE>::NB)) PSM
     const int xm0 = xg - 4;                           // first model column of the workgroup
     const int y0 = ybeg + seg * seg_rows, y1 = min(yend, y0 + seg_rows);   // output rows [y0, y1)
     const int mstart = max(0, y0 - 4);                // model rows produced: mstart .. mend
-    const int mend = min(H - 1, y1 + 2);
+    const int mend = min(H - 1, max(y1 + 2, 4 - y0));   // (a one-row segment at the top still needs model row 4: REFLECT_101 of row -4)
     const int nbA = (mend - mstart + 1 + 3) >> 2;     // producer batches
     const int nf = (y1 - y0) + 7;                     // consumer feeds (model rows y0-4 .. y1+2, reflected)
     const int nbB = (nf + 3) >> 2;                    // consumer batches

@@ -102,3 +102,37 @@ def test_random_geometry_u8_mode(psm, oracle, W, H, D, seed):
         de.DispSelect_GPU()
         assert np.array_equal(de.download_volume(0), ref["lvol"]) and np.array_equal(de.download_volume(1), ref["rvol"])
         assert np.array_equal(de.lDisMap, ref["ldisp"]) and np.array_equal(de.rDisMap, ref["rdisp"])
+
+
+@pytest.mark.parametrize("W,H,D,seed", _geometries(24, 424242))
+def test_random_geometry_two_phase_and_stripes(psm, oracle, W, H, D, seed):
+    """Forced two-phase selection (planes for every 6th slice, keys for the rest) on random geometries, whole image and as
+    row stripes cut at random rows (psm_set_rows / psm_gather_rows_ctx); float and 8-bit mode.  Maps bit-identical."""
+    from primestereomatch_amd import capi, synth
+    rng = np.random.default_rng(seed)
+    D = max(D, 2)
+    dtype = "u8" if rng.random() < 0.3 else "f32"
+    l, r, _ = synth.make_pair(W, H, D, seed=seed & 0xffff)
+    if rng.random() < 0.3:
+        l[H // 3:, W // 3:] = 200
+        r[H // 3:, W // 3:] = 200
+    ref = (oracle.pipeline_u8 if dtype == "u8" else oracle.pipeline_f32)(l, r, D, threads=4)
+    flags = 1048576 | int(rng.choice([0, 0, 65536 * 0, 128 if dtype == "f32" else 0]))
+    with psm.DispEst(l, r, D, dtype=dtype) as de:
+        de.set_option(capi.PSM_OPT_FLAGS, flags)
+        if rng.random() < 0.5:
+            de.set_option(capi.PSM_OPT_SEG_ROWS, int(rng.integers(8, 40)))
+        de.CostConst_GPU(); de.CostFilter_GPU(); de.DispSelect_GPU()
+        assert np.array_equal(de.lDisMap, ref["ldisp"]) and np.array_equal(de.rDisMap, ref["rdisp"]), (W, H, D, dtype, flags)
+    cuts = sorted(set([0, H] + [int(c) for c in rng.integers(1, H, size=int(rng.integers(1, 4)))]))
+    ctxs = [psm.DispEst(l, r, D, dtype=dtype) for _ in range(len(cuts) - 1)]
+    try:
+        for c, y0, y1 in zip(ctxs, cuts[:-1], cuts[1:]):
+            c.set_option(capi.PSM_OPT_FLAGS, 1048576 if rng.random() < 0.5 else 0)
+            c.set_rows(y0, y1)
+            c.CostConst_GPU(); c.CostFilter_GPU(); c.DispSelect_GPU()
+        ctxs[0].gather_rows_ctx(ctxs)
+        assert np.array_equal(ctxs[0].lDisMap, ref["ldisp"]) and np.array_equal(ctxs[0].rDisMap, ref["rdisp"]), (W, H, D, dtype, cuts)
+    finally:
+        for c in ctxs:
+            c.close()

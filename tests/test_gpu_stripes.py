@@ -28,7 +28,8 @@ def _full(psm, oracle, l, r, D, dtype):
 
 @pytest.mark.parametrize("W,H,D,dtype,flags,G", [(260, 150, 12, "f32", 0, 3), (200, 97, 20, "f32", 1048576, 4), (107, 20, 9, "f32", 0, 7),
                                                  (230, 64, 33, "u8", 0, 2), (214, 40, 19, "u8", 1048576, 5), (260, 40, 200, "f32", 0, 2),
-                                                 (330, 135, 16, "f32", 524288, 3), (120, 33, 8, "f32", 262144, 2)])
+                                                 (330, 135, 16, "f32", 524288, 3), (120, 33, 8, "f32", 262144, 2),
+                                                 (100, 12, 42, "u8", 0, 12), (100, 12, 42, "f32", 1048576, 12)])   # one row per stripe
 def test_row_stripes_equal_the_whole_image(psm, oracle, W, H, D, dtype, flags, G):
     from primestereomatch_amd import capi, synth
     l, r, _ = synth.make_pair(W, H, D, seed=W + H + D)
