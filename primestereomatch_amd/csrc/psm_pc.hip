@@ -63,6 +63,18 @@ typedef float f4v __attribute__((ext_vector_type(4)));
 #ifndef PSM_PC_ATTR
 #define PSM_PC_ATTR
 #endif
+// Occupancy of the key form (MODE 2, 5/6 of the slices of a 256-slice volume): four workgroups per CU instead of three.
+// The kernel is latency-sensitive at 3 waves per SIMD (barrier waits, LDS round trips); 128 VGPRs need a shorter load
+// look-ahead (PSM_PC_LEAN bit 0: consumer G1 / keys two rows ahead instead of a batch; bit 1: producer guidance planes issued
+// at the start of their own step, partner pixels right after the cost is formed) and cost 4 spilled registers per producer batch.
+// Measured at 1080p x 256: key phase 6.36 -> 5.86 ms (PSM_PC_LEAN 1 or 3; 0 with the cap: 65 spills, 12.7 ms per frame).
+// PSM_PC_OCC4 == 2 caps the plane form (MODE 1) as well (31+ spills: slower), bits 2-5 of PSM_PC_LEAN are further experiments.
+#ifndef PSM_PC_OCC4
+#define PSM_PC_OCC4 1
+#endif
+#ifndef PSM_PC_LEAN
+#define PSM_PC_LEAN 3
+#endif
 constexpr int PC_RING = 4;   // batches of four model rows kept in LDS
 #ifndef PSM_PC_NT
 #define PSM_PC_NT 1          // MODE 0: nontemporal stores of the output rows (the volume is next read long after it left the L2)
@@ -108,6 +120,13 @@ __device__ __forceinline__ float4 pc_load4(__amdgpu_buffer_rsrc_t r, int voff, i
     return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
 }
 
+typedef unsigned pc_u3 __attribute__((ext_vector_type(3)));
+__device__ __forceinline__ float3 pc_load3(__amdgpu_buffer_rsrc_t r, int voff, int soff)
+{   // the first three floats of a float4 element (the consumer waves never use g1.w)
+    const pc_u3 v = __builtin_amdgcn_raw_buffer_load_b96(r, voff, soff, 0);
+    return make_float3(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z));
+}
+
 // Second set of plane pointers for CVC == 3: one launch filters BOTH volumes (blockIdx.y = side; side 0 = left volume with
 // the kernel's own arguments, side 1 = right volume with these) - twice the workgroups per launch, half the launches.
 struct PcSide {
@@ -145,7 +164,11 @@ __device__ __forceinline__ int pc_slice(const PcDyn &o, int i)
 // strict-'<' selection (assets/dispsel.cl:41-62 with the initial minimum above 255) - the build-defined 8-bit contract
 // of oracle/psm_oracle.h, in one pass and without an 8-bit volume in memory.
 template <bool VEC4, int CVC, int MODE, bool U8 = false>
-__global__ __launch_bounds__(64 * (PcLayout<MODE>::NA + PcLayout<MODE>::NB)) PSM_PC_ATTR void k_cvf_pc(
+__global__ __launch_bounds__(64 * (PcLayout<MODE>::NA + PcLayout<MODE>::NB)) PSM_PC_ATTR
+#if PSM_PC_OCC4   // the key form (MODE 2) capped at 128 VGPRs = four workgroups per CU
+__attribute__((amdgpu_waves_per_eu((MODE == 2 || (MODE == 1 && PSM_PC_OCC4 == 2)) ? 4 : 1, (MODE == 2 || (MODE == 1 && PSM_PC_OCC4 == 2)) ? 4 : 8)))
+#endif
+void k_cvf_pc(
     const float *__restrict__ vin, float *__restrict__ vout, const float4 *__restrict__ G1a, const float4 *__restrict__ G2a,
     const float4 *__restrict__ G3a, const float2 *__restrict__ G4a, int W, int H, int Dloc, int ngroups, int nsegs, int seg_rows,
     int ybeg, int yend, const float4 *__restrict__ Gothera, int d_begin, int DC, float *__restrict__ kcosta, unsigned *__restrict__ kdispa, int nbmax,
@@ -236,6 +259,7 @@ __global__ __launch_bounds__(64 * (PcLayout<MODE>::NA + PcLayout<MODE>::NB)) PSM
         float pin[2];
         float4 oth[2], gin[2], o2[2], o3[2];
         float2 o4[2];
+        constexpr bool LEANA = (PSM_PC_LEAN & 2) != 0 && (MODE == 2 || (MODE == 1 && (PSM_PC_LEAN & 32)));
         // raw buffer loads: descriptors and row offsets in scalar registers, one constant 32-bit byte offset per lane
         // (psm_create keeps W*H < 2^27, so every byte offset into a 16-byte plane fits 31 bits)
         const __amdgpu_buffer_rsrc_t rG1 = pc_rsrc(G1, (unsigned)HW * 16u), rG2 = pc_rsrc(G2, (unsigned)HW * 16u);
@@ -257,16 +281,28 @@ __global__ __launch_bounds__(64 * (PcLayout<MODE>::NA + PcLayout<MODE>::NB)) PSM
         else if (U8) {                                                                  \
             pu[SLOT] = __builtin_amdgcn_raw_buffer_load_b32(rP, vci >> 2, row_ * 4, 0); \
             po[SLOT] = __builtin_amdgcn_raw_buffer_load_b32(rPo, vcp >> 2, row_ * 4, 0); \
-        } else oth[SLOT] = pc_load4(rGo, vcp, row_ * 16);                               \
+        } else if (!LEANA) oth[SLOT] = pc_load4(rGo, vcp, row_ * 16);                   \
         gin[SLOT] = pc_load4(rG1, vci, row_ * 16);                                      \
-        o2[SLOT] = pc_load4(rG2, vxa, oa_ * 16);                                        \
-        o3[SLOT] = pc_load4(rG3, vxa, oa_ * 16);                                        \
-        o4[SLOT] = pc_load2(rG4, vxa >> 1, oa_ * 8);                                    \
+        if (!LEANA) {                                                                   \
+            o2[SLOT] = pc_load4(rG2, vxa, oa_ * 16);                                    \
+            o3[SLOT] = pc_load4(rG3, vxa, oa_ * 16);                                    \
+            o4[SLOT] = pc_load2(rG4, vxa >> 1, oa_ * 8);                                \
+        }                                                                               \
+    }
+#define PSM_ISSUE_PA2(STEP)   /* PSM_PC_LEAN: the guidance planes of step STEP, issued when the step starts */ \
+    {                                                                                   \
+        int ya_ = mstart - 8 + (STEP);                                                  \
+        ya_ = ya_ < 0 ? 0 : (ya_ > H - 1 ? H - 1 : ya_);                                \
+        const int oa_ = ya_ * W;                                                        \
+        o2[0] = pc_load4(rG2, vxa, oa_ * 16);                                           \
+        o3[0] = pc_load4(rG3, vxa, oa_ * 16);                                           \
+        o4[0] = pc_load2(rG4, vxa >> 1, oa_ * 8);                                       \
     }
         // one step: consume the loads of step S (slot K&1), issue those of step S+1
 #define PSM_STEP_PA(K, S, DST)                                                                      \
     {                                                                                               \
         PSM_ISSUE_PA((K + 1) & 1, (S) + 1)                                                          \
+        if (LEANA && !(PSM_PC_LEAN & 4)) PSM_ISSUE_PA2(S)                                           \
         float p;                                                                                    \
         if (CVC == 0) p = pin[K & 1];                                                               \
         else if (U8) {                                                                              \
@@ -276,23 +312,38 @@ __global__ __launch_bounds__(64 * (PcLayout<MODE>::NA + PcLayout<MODE>::NB)) PSM
             const float f_ = __fadd_rn(__fmul_rn(0.9f, (float)(clr_ / 3u)), __fmul_rn(__fsub_rn(1.0f, 0.9f), (float)(gd_ < 0 ? -gd_ : gd_))); \
             p = __fmul_rn((float)(unsigned)(unsigned char)f_, 1 / 255.0f);                          \
         } else {                                                                                    \
-            p = cost_pair(gin[K & 1], oth[K & 1]);                                                  \
+            p = cost_pair(gin[K & 1], oth[LEANA ? 0 : (K & 1)]);                                    \
+            if (LEANA) oth[0] = pc_load4(rGo, vcp, r101c(mstart - 5 + (S) + 1, H) * W * 16);   /* partner pixels of the next step: the current ones are dead now */ \
             if (any_border) {   /* only where x < d (left) / x >= W-d (right) occurs in this wave */   \
                 asm volatile("; border cost");   /* keeps this a real branch */                     \
                 const float cb_ = cost_border(gin[K & 1]);                                          \
                 p = inb ? p : cb_;                                                                  \
             }                                                                                       \
         }                                                                                           \
+        double n0, n1, n2, n3;                                                                      \
+        if (LEANA && (PSM_PC_LEAN & 8)) {   /* two channels at a time: fewer doubles alive */        \
+            double h0 = hsum8(p, i1, i2, i4);                                                       \
+            double h1 = hsum8(__fmul_rn(gin[K & 1].x, p), i1, i2, i4);                              \
+            n0 = vstep<K>(t0, h0); n1 = vstep<K>(t1, h1);                                           \
+            __builtin_amdgcn_sched_barrier(0);                                                      \
+            double h2 = hsum8(__fmul_rn(gin[K & 1].y, p), i1, i2, i4);                              \
+            double h3 = hsum8(__fmul_rn(gin[K & 1].z, p), i1, i2, i4);                              \
+            n2 = vstep<K>(t2, h2); n3 = vstep<K>(t3, h3);                                           \
+        } else {                                                                                    \
         double h0 = hsum8(p, i1, i2, i4);                                                           \
         double h1 = hsum8(__fmul_rn(gin[K & 1].x, p), i1, i2, i4);                                  \
         double h2 = hsum8(__fmul_rn(gin[K & 1].y, p), i1, i2, i4);                                  \
         double h3 = hsum8(__fmul_rn(gin[K & 1].z, p), i1, i2, i4);                                  \
-        double n0 = vstep<K>(t0, h0), n1 = vstep<K>(t1, h1), n2 = vstep<K>(t2, h2), n3 = vstep<K>(t3, h3); \
-        float4 r = solve_ab(box_out(n0), box_out(n1), box_out(n2), box_out(n3), o2[K & 1], o3[K & 1], o4[K & 1]); \
+        if (LEANA && (PSM_PC_LEAN & 4)) { __builtin_amdgcn_sched_barrier(0); PSM_ISSUE_PA2(S) }     \
+        n0 = vstep<K>(t0, h0); n1 = vstep<K>(t1, h1); n2 = vstep<K>(t2, h2); n3 = vstep<K>(t3, h3); \
+        }                                                                                           \
+        float4 r = solve_ab(box_out(n0), box_out(n1), box_out(n2), box_out(n3), o2[LEANA ? 0 : (K & 1)], o3[LEANA ? 0 : (K & 1)], o4[LEANA ? 0 : (K & 1)]); \
         if ((DST) != nullptr && mvalid) (DST)[K * PC_MCOLS] = r;                                    \
         __builtin_amdgcn_sched_barrier(0);                                                          \
     }
-        PSM_ISSUE_PA(0, 0) __builtin_amdgcn_sched_barrier(0);
+        PSM_ISSUE_PA(0, 0)
+        if (LEANA && CVC != 0 && !U8) oth[0] = pc_load4(rGo, vcp, r101c(mstart - 5, H) * W * 16);
+        __builtin_amdgcn_sched_barrier(0);
         {   // warm-up: 8 rows fill the tree (loop bodies stay free of conditionals around the tree updates:
             // a conditional turns the trees into loop-carried phis and doubles their registers)
             float4 *const none = nullptr;
@@ -308,6 +359,7 @@ __global__ __launch_bounds__(64 * (PcLayout<MODE>::NA + PcLayout<MODE>::NB)) PSM
         for (int b = nbA; b < iters; ++b) PC_SYNC();
 #undef PSM_STEP_PA
 #undef PSM_ISSUE_PA
+#undef PSM_ISSUE_PA2
     } else {
         // ---------------- consumer: stage B ----------------
         // feed j (j = 0 .. nf-1) is model row r101(y0-4+j); from feed 7 on the tree yields output row y0+j-7
@@ -343,6 +395,13 @@ __global__ __launch_bounds__(64 * (PcLayout<MODE>::NA + PcLayout<MODE>::NB)) PSM
         const __amdgpu_buffer_rsrc_t rKy = pc_rsrc(MODE == 2 ? (const void *)keyp : (const void *)G1, (unsigned)HW * 8u);
         long long kcur[4] = {0, 0, 0, 0};
         float acc_dbg = 0.f; (void)acc_dbg;
+#define PSM_KEY_LOAD1(SLOT, J)   /* PSM_PC_LEAN: the key of feed row J alone */                     \
+    {                                                                                              \
+        int yk_ = y0 + (J) - 7;                                                                    \
+        yk_ = yk_ < 0 ? 0 : (yk_ > H - 1 ? H - 1 : yk_);                                           \
+        const pc_u2 v_ = __builtin_amdgcn_raw_buffer_load_b64(rKy, xbc * 8, yk_ * W * 8, PSM_KEY_LD_AUX); \
+        kcur[SLOT] = (long long)(((unsigned long long)v_.y << 32) | v_.x);                         \
+    }
 #define PSM_KEY_LOAD(C)                                                                            \
     {                                                                                              \
         _Pragma("unroll") for (int k_ = 0; k_ < 4; ++k_) {                                         \
@@ -360,7 +419,7 @@ __global__ __launch_bounds__(64 * (PcLayout<MODE>::NA + PcLayout<MODE>::NB)) PSM
     {                                                                                   \
         int yb_ = y0 + (J) - 7;                                                         \
         yb_ = yb_ < 0 ? 0 : (yb_ > H - 1 ? H - 1 : yb_);                                \
-        const float4 g_ = pc_load4(rG1, vxb, yb_ * W * 16);                             \
+        const float3 g_ = pc_load3(rG1, vxb, yb_ * W * 16);                             \
         o1x[SLOT] = g_.x; o1y[SLOT] = g_.y; o1z[SLOT] = g_.z;                           \
     }
         // ring address of the model row that feed J consumes (wave-uniform arithmetic)
@@ -397,13 +456,19 @@ __global__ __launch_bounds__(64 * (PcLayout<MODE>::NA + PcLayout<MODE>::NB)) PSM
             }
             }
         };
-        PSM_ISSUE_PB(0, 0) PSM_ISSUE_PB(1, 1) PSM_ISSUE_PB(2, 2) PSM_ISSUE_PB(3, 3)
+        constexpr bool LEANB = (PSM_PC_LEAN & 1) != 0 && MODE == 2;
+        constexpr bool LEANG = LEANB || ((PSM_PC_LEAN & 16) != 0 && MODE == 1);   // G1 of the output rows two rows ahead instead of a batch
+        PSM_ISSUE_PB(0, 0) PSM_ISSUE_PB(1, 1)
+        if (!LEANG) { PSM_ISSUE_PB(2, 2) PSM_ISSUE_PB(3, 3) }
         if constexpr (MODE == 1) {
             if (!first) {                              // records of batch 0, written by this wave one slice earlier (L1 bypassed)
                 PSM_K_LOAD(0)
             }
         }
-        if constexpr (MODE == 2) PSM_KEY_LOAD(0)
+        if constexpr (MODE == 2) {
+            if (LEANB) { PSM_KEY_LOAD1(0, 0) PSM_KEY_LOAD1(1, 1) }
+            else PSM_KEY_LOAD(0)
+        }
         PC_SYNC();                               // iteration 0
         PC_SYNC();                               // iteration 1
         for (int b = 2; b <= nbB + 1; ++b) {           // iteration b: consume feed batch c = b-2
@@ -421,9 +486,21 @@ __global__ __launch_bounds__(64 * (PcLayout<MODE>::NA + PcLayout<MODE>::NB)) PSM
         double h2 = hsum8(a_cur.z, i1, i2, i4);                                                     \
         double h3 = hsum8(a_cur.w, i1, i2, i4);                                                     \
         double n0 = vstep<K>(t0, h0), n1 = vstep<K>(t1, h1), n2 = vstep<K>(t2, h2), n3 = vstep<K>(t3, h3); \
-        qv[K] = __fadd_rn(__fadd_rn(__fadd_rn(box_out(n3), __fmul_rn(box_out(n0), o1x[K])),        \
-                                    __fmul_rn(box_out(n1), o1y[K])), __fmul_rn(box_out(n2), o1z[K])); \
-        PSM_ISSUE_PB(K, j0 + K + 4)                                                                 \
+        qv[K] = __fadd_rn(__fadd_rn(__fadd_rn(box_out(n3), __fmul_rn(box_out(n0), o1x[LEANG ? (K & 1) : K])),        \
+                                    __fmul_rn(box_out(n1), o1y[LEANG ? (K & 1) : K])), __fmul_rn(box_out(n2), o1z[LEANG ? (K & 1) : K])); \
+        if (LEANG && !LEANB) PSM_ISSUE_PB(K & 1, j0 + K + 2)                                        \
+        else if (LEANB) {                                                                           \
+            PSM_ISSUE_PB(K & 1, j0 + K + 2)                                                         \
+            if (U8) {                                                                               \
+                const float r_ = rintf(__fmul_rn(qv[K], 255.0f));                                   \
+                qv[K] = !(r_ > 0.0f) ? 0.0f : (r_ > 255.0f ? 255.0f : r_);                          \
+            }                                                                                       \
+            const int j_ = j0 + K, yo_ = y0 + j_ - 7;                                               \
+            const long long key_ = pack_key_f32(qv[K], dg);                                         \
+            if (j_ >= 7 && yo_ < y1 && lane_out && dg != 0 && qv[K] == qv[K] && key_ < kcur[K & 1]) \
+                (void)__hip_atomic_fetch_min(keyp + (size_t)yo_ * W + xb, key_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); \
+            PSM_KEY_LOAD1(K & 1, j0 + K + 2)                                                        \
+        } else PSM_ISSUE_PB(K, j0 + K + 4)                                                          \
         a_cur = a_nxt;                                                                              \
         __builtin_amdgcn_sched_barrier(0);                                                          \
     }
@@ -433,6 +510,8 @@ __global__ __launch_bounds__(64 * (PcLayout<MODE>::NA + PcLayout<MODE>::NB)) PSM
 #pragma unroll
                     for (int k = 0; k < 4; ++k)
                         if (lane < bwidth) qbuf[c & 1][k][wb * PC_OUT_B + lane] = qv[k];
+                } else if constexpr (LEANB) {
+                    // (selection done row by row inside the steps)
                 } else if constexpr (MODE == 2) {
                     // DispSel::CVSelect (src/DispSel.cpp:96-104) against the volume's shared key plane: strict '<' / lowest d on
                     // ties = signed minimum of pack_key_f32; d = 0 never a candidate; NaN never wins
@@ -495,6 +574,7 @@ __global__ __launch_bounds__(64 * (PcLayout<MODE>::NA + PcLayout<MODE>::NB)) PSM
         PC_SYNC();
 #undef PSM_ISSUE_PB
 #undef PSM_KEY_LOAD
+#undef PSM_KEY_LOAD1
 #undef PSM_K_LOAD
     }
     if (MODE == 1) __builtin_amdgcn_s_waitcnt(0);      // the chunk planes of this slice are in the L2 before the next slice reads them
