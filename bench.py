@@ -344,7 +344,7 @@ def main():
             kern[nm] = {"avg_ms": tot / n, "launches_per_step": n / prof_steps}
     de.set_option(capi.PSM_OPT_PROFILE, 0)
     # voxels per launch of the filter kernel = the step's 2*W*H*Dloc over its launches per step: 1 (both volumes in one
-    # launch), 2 (one launch per volume - or, from 160 local slices up, the two phases of the select form: every 6th slice
+    # launch), 2 (one launch per volume - or, from 112 local slices up, the two phases of the select form: every 6th slice
     # of both volumes through the minima planes, then the other slices of both volumes against the key plane; the two
     # are instantiations of the same kernel, so avg_launch_ms is their mean and alg bytes / launch the mean as well)
     lps = max(1, round(kern.get("cvf_fused", {}).get("launches_per_step", 2)))   # (other filter forms: one side per launch)
@@ -357,7 +357,7 @@ def main():
     if select_mode:
         ALG_BYTES["cvf_fused"] = ALG_BYTES["pipeline"]
     fl = max(args.flags, 0)
-    two_phase = select_mode and not (fl & (2097152 | 524288 | 262144 | 65536 | 16384)) and ((d1 - d0) >= 160 or (fl & 1048576))
+    two_phase = select_mode and not (fl & (2097152 | 524288 | 262144 | 65536 | 16384)) and ((d1 - d0) >= 112 or (fl & 1048576))
     dom = max(("cvf_fgf",) if args.fgf else ("cvf_fused", "cvf_a", "cvf_b"), key=lambda k: kern.get(k, {"avg_ms": 0})["avg_ms"])
     dom_ms = kern[dom]["avg_ms"]
     achieved = ALG_BYTES[dom] * vox_per_launch / (dom_ms * 1e-3) / 1e9

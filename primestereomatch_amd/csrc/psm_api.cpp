@@ -800,14 +800,14 @@ static int filter_both(psm_ctx *c)
         return check_launch(c, "cvf (fused, select mode, shared keys, both volumes)");
     }
     const bool dynsel = (c->march.flags & 524288) != 0;
-    // Two-phase selection (default from 160 local slices up - measured: -5 % at 1080p x 256, -11 % at 4K x 256, neutral or
-    // worse below; flag 1048576 forces it for any Dloc >= 2, flag 2097152 turns it off): every S-th slice goes through the
+    // Two-phase selection (default from 112 local slices up - measured: -10 % at 1080p x 256, -13 % at 4K x 256, -4 % at
+    // 720p x 128, worse at 64 slices and below; flag 1048576 forces it for any Dloc >= 2, flag 2097152 turns it off): every S-th slice goes through the
     // minima planes -> k_chunk_min -> keys; the other slices then run against that seeded key plane (MODE 2: one key load
     // per voxel, an atomic only where a slice beats the current minimum - rare after the seeding), so they write no
     // planes and need no reduction.  PSM_PC_S overrides S (default 6).
     static const int S_env = getenv("PSM_PC_S") ? atoi(getenv("PSM_PC_S")) : 0;
     const int S = S_env > 1 ? S_env : 6;
-    const bool two_phase = !dynsel && !(c->march.flags & 2097152) && c->Dloc >= 2 && (c->Dloc >= 160 || (c->march.flags & 1048576));
+    const bool two_phase = !dynsel && !(c->march.flags & 2097152) && c->Dloc >= 2 && (c->Dloc >= 112 || (c->march.flags & 1048576));
     if (two_phase) {
         const int n1 = (c->Dloc + S - 1) / S, n2 = c->Dloc - n1;
         const PcPlan pl1 = pc_plan(c->W, c->march.rows(c->H), n1, c->march.seg_rows, 2);

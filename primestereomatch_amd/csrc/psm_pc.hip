@@ -194,7 +194,10 @@ void k_cvf_pc(
     // (block b -> XCD b%8): every XCD owns a contiguous range of (group, segment) pairs and walks the
     // chunks of one pair back to back, so the guidance rows its resident workgroups are reading (few
     // pairs, neighbouring rows, many slices) fit its 4 MB L2 instead of coming from the MALL.  Speed only.
-    const bool dynamic = MODE == 1 && dyn.cnt != nullptr;
+#ifndef PSM_PC_NODYN
+#define PSM_PC_NODYN 0
+#endif
+    const bool dynamic = !PSM_PC_NODYN && MODE == 1 && dyn.cnt != nullptr;
     const int nchunks = dynamic ? dyn.NW : (Dloc + DC - 1) / DC;
     int id = blockIdx.x;
     const int npairs = ngroups * nsegs;               // (column group, segment) pairs

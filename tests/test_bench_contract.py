@@ -55,7 +55,7 @@ def test_round2_lines():
     r = j["roofline"]
     assert r["bound"] == "hbm" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
     assert abs(r["achieved"] - r["alg_bytes_per_launch"] / (r["avg_launch_ms"] * 1e-3) / 1e9) / r["achieved"] < 1e-3
-    # select form: CVC + CVF + WTA of both volumes in one launch, or (from 160 local slices up) in the two launches of the
+    # select form: CVC + CVF + WTA of both volumes in one launch, or (from 112 local slices up) in the two launches of the
     # two-phase selection - "per launch" is then the mean over the two
     lps = round(j["kernels"]["cvf_fused"]["launches_per_step"])
     assert lps in (1, 2) and r["alg_bytes_per_launch"] * lps == 48.0 * 2 * W * H * D
