@@ -68,7 +68,11 @@ typedef float f4v __attribute__((ext_vector_type(4)));
 // look-ahead (PSM_PC_LEAN bit 0: consumer G1 / keys two rows ahead instead of a batch; bit 1: producer guidance planes issued
 // at the start of their own step, partner pixels right after the cost is formed) and cost 4 spilled registers per producer batch.
 // Measured at 1080p x 256: key phase 6.36 -> 5.86 ms (PSM_PC_LEAN 1 or 3; 0 with the cap: 65 spills, 12.7 ms per frame).
-// PSM_PC_OCC4 == 2 caps the plane form (MODE 1) as well (31+ spills: slower), bits 2-5 of PSM_PC_LEAN are further experiments.
+// PSM_PC_OCC4 == 2 caps the plane form (MODE 1) as well; its own register diet (PSM_PC_LEAN bits 4-7: G1 two rows ahead, the
+// producer changes, selection row by row inside the steps, role constants recomputed per slice from an opaque lane index so
+// that they do not stay alive through the other role's code) gets it from 159 to 139 registers / 9 spills under the cap, but
+// there the shorter look-ahead costs what the fourth workgroup gains (720p x 128 1.91 vs 1.92 ms, 450 x 375 x 64 0.32 vs 0.31,
+// 8-bit 450 x 375 0.45 vs 0.32): off by default.
 #ifndef PSM_PC_OCC4
 #define PSM_PC_OCC4 1
 #endif
@@ -248,8 +252,12 @@ void k_cvf_pc(
         // ---------------- producer: stage A ----------------
         // step s reads input row mstart-5+s; from step 8 on it yields model row mstart+(s-8)
         const int xa0 = xm0 + wave * PC_OUT_A;        // first model column of this wave
-        const int ci = r101c(xa0 - 4 + lane, W);      // input column of this lane
-        const int xa = xa0 + lane;                    // model column of this lane
+        // (plane form, several slices per workgroup: the per-lane constants of a role are recomputed per slice from an opaque
+        // copy of the lane index - hoisted out of the slice loop they would stay alive through the other role's code)
+        int lane_r = lane;
+        if (MODE == 1 && (PSM_PC_LEAN & 128)) asm volatile("" : "+v"(lane_r));
+        const int ci = r101c(xa0 - 4 + lane_r, W);    // input column of this lane
+        const int xa = xa0 + lane_r;                  // model column of this lane
         const int xac = xa < 0 ? 0 : (xa > W - 1 ? W - 1 : xa);
         const bool mvalid = lane < PC_OUT_A;
         const float *vd = vin + (size_t)pc_slice(dyn, d) * HW;
@@ -305,7 +313,7 @@ void k_cvf_pc(
 #define PSM_STEP_PA(K, S, DST)                                                                      \
     {                                                                                               \
         PSM_ISSUE_PA((K + 1) & 1, (S) + 1)                                                          \
-        if (LEANA && !(PSM_PC_LEAN & 4)) PSM_ISSUE_PA2(S)                                           \
+        if (LEANA) PSM_ISSUE_PA2(S)                                                                 \
         float p;                                                                                    \
         if (CVC == 0) p = pin[K & 1];                                                               \
         else if (U8) {                                                                              \
@@ -323,23 +331,11 @@ void k_cvf_pc(
                 p = inb ? p : cb_;                                                                  \
             }                                                                                       \
         }                                                                                           \
-        double n0, n1, n2, n3;                                                                      \
-        if (LEANA && (PSM_PC_LEAN & 8)) {   /* two channels at a time: fewer doubles alive */        \
-            double h0 = hsum8(p, i1, i2, i4);                                                       \
-            double h1 = hsum8(__fmul_rn(gin[K & 1].x, p), i1, i2, i4);                              \
-            n0 = vstep<K>(t0, h0); n1 = vstep<K>(t1, h1);                                           \
-            __builtin_amdgcn_sched_barrier(0);                                                      \
-            double h2 = hsum8(__fmul_rn(gin[K & 1].y, p), i1, i2, i4);                              \
-            double h3 = hsum8(__fmul_rn(gin[K & 1].z, p), i1, i2, i4);                              \
-            n2 = vstep<K>(t2, h2); n3 = vstep<K>(t3, h3);                                           \
-        } else {                                                                                    \
         double h0 = hsum8(p, i1, i2, i4);                                                           \
         double h1 = hsum8(__fmul_rn(gin[K & 1].x, p), i1, i2, i4);                                  \
         double h2 = hsum8(__fmul_rn(gin[K & 1].y, p), i1, i2, i4);                                  \
         double h3 = hsum8(__fmul_rn(gin[K & 1].z, p), i1, i2, i4);                                  \
-        if (LEANA && (PSM_PC_LEAN & 4)) { __builtin_amdgcn_sched_barrier(0); PSM_ISSUE_PA2(S) }     \
-        n0 = vstep<K>(t0, h0); n1 = vstep<K>(t1, h1); n2 = vstep<K>(t2, h2); n3 = vstep<K>(t3, h3); \
-        }                                                                                           \
+        double n0 = vstep<K>(t0, h0), n1 = vstep<K>(t1, h1), n2 = vstep<K>(t2, h2), n3 = vstep<K>(t3, h3); \
         float4 r = solve_ab(box_out(n0), box_out(n1), box_out(n2), box_out(n3), o2[LEANA ? 0 : (K & 1)], o3[LEANA ? 0 : (K & 1)], o4[LEANA ? 0 : (K & 1)]); \
         if ((DST) != nullptr && mvalid) (DST)[K * PC_MCOLS] = r;                                    \
         __builtin_amdgcn_sched_barrier(0);                                                          \
@@ -369,10 +365,12 @@ void k_cvf_pc(
         const int wb = wave - PC_NA;
         const int bwidth = wb < PC_NB - 1 ? PC_OUT_B : PC_COLS - (PC_NB - 1) * PC_OUT_B;
         const int xb0 = xg + wb * PC_OUT_B;           // first output column of this wave
-        const int xmod = xb0 - 4 + lane;              // model column this lane consumes
+        int lane_r = lane;                            // (see the producer branch)
+        if (MODE == 1 && (PSM_PC_LEAN & 128)) asm volatile("" : "+v"(lane_r));
+        const int xmod = xb0 - 4 + lane_r;            // model column this lane consumes
         int mc = r101(xmod, W) - xm0;                 // REFLECT_101 of the model planes, as ring column
         mc = mc < 0 ? 0 : (mc > PC_MCOLS - 1 ? PC_MCOLS - 1 : mc);
-        const int xb = xb0 + lane;                    // output column of this lane
+        const int xb = xb0 + lane_r;                  // output column of this lane
         const int xbc = min(xb, W - 1);
         float *od = vout + (MODE == 0 ? (size_t)pc_slice(dyn, d) * HW : 0);
         const int amax = 4 * nbA - 1;
@@ -461,6 +459,7 @@ void k_cvf_pc(
         };
         constexpr bool LEANB = (PSM_PC_LEAN & 1) != 0 && MODE == 2;
         constexpr bool LEANG = LEANB || ((PSM_PC_LEAN & 16) != 0 && MODE == 1);   // G1 of the output rows two rows ahead instead of a batch
+        constexpr bool LEANS = (PSM_PC_LEAN & 64) != 0 && MODE == 1;              // plane form: selection row by row inside the steps
         PSM_ISSUE_PB(0, 0) PSM_ISSUE_PB(1, 1)
         if (!LEANG) { PSM_ISSUE_PB(2, 2) PSM_ISSUE_PB(3, 3) }
         if constexpr (MODE == 1) {
@@ -481,6 +480,7 @@ void k_cvf_pc(
                 const int j0 = 4 * c;
                 float4 a_cur = *model_of(j0), a_nxt;
                 float qv[4];
+                bool anyb = false; (void)anyb;
 #define PSM_STEP_PB(K)                                                                              \
     {                                                                                               \
         if (K < 3) a_nxt = *model_of(j0 + K + 1);     /* model row of the next feed, one step ahead */ \
@@ -491,6 +491,18 @@ void k_cvf_pc(
         double n0 = vstep<K>(t0, h0), n1 = vstep<K>(t1, h1), n2 = vstep<K>(t2, h2), n3 = vstep<K>(t3, h3); \
         qv[K] = __fadd_rn(__fadd_rn(__fadd_rn(box_out(n3), __fmul_rn(box_out(n0), o1x[LEANG ? (K & 1) : K])),        \
                                     __fmul_rn(box_out(n1), o1y[LEANG ? (K & 1) : K])), __fmul_rn(box_out(n2), o1z[LEANG ? (K & 1) : K])); \
+        if (LEANS) {                                                                                \
+            if (U8) {                                                                               \
+                const float r_ = rintf(__fmul_rn(qv[K], 255.0f));                                   \
+                qv[K] = !(r_ > 0.0f) ? 0.0f : (r_ > 255.0f ? 255.0f : r_);                          \
+            }                                                                                       \
+            const int j_ = j0 + K, yo_ = y0 + j_ - 7;                                               \
+            float &kqK_ = K == 0 ? kq.x : (K == 1 ? kq.y : (K == 2 ? kq.z : kq.w));                 \
+            const bool better_ = j_ >= 7 && yo_ < y1 && lane_out && dg != 0 && qv[K] < kqK_;        \
+            kqK_ = better_ ? qv[K] : kqK_;                                                          \
+            kd4 = better_ ? ((kd4 & ~(0xffu << (8 * K))) | ((unsigned)dg << (8 * K))) : kd4;        \
+            anyb |= better_;                                                                        \
+        }                                                                                           \
         if (LEANG && !LEANB) PSM_ISSUE_PB(K & 1, j0 + K + 2)                                        \
         else if (LEANB) {                                                                           \
             PSM_ISSUE_PB(K & 1, j0 + K + 2)                                                         \
@@ -538,6 +550,15 @@ void k_cvf_pc(
                     }
                     if (c + 1 < nbB) PSM_KEY_LOAD(c + 1)               // keys of the next batch's rows
 #endif
+                } else if constexpr (LEANS) {
+                    // (selection done row by row inside the steps; kq / kd4 hold the updated records of this batch)
+                    if (lane < bwidth && (first || anyb)) {
+                        const pc_u4 kv = {__float_as_uint(kq.x), __float_as_uint(kq.y), __float_as_uint(kq.z), __float_as_uint(kq.w)};
+                        __builtin_amdgcn_raw_buffer_store_b128(kv, rKc, lane * 16, c * (PC_COLS * 16), 0);
+                        __builtin_amdgcn_raw_buffer_store_b32(kd4, rKd, lane * 4, c * (PC_COLS * 4), 0);
+                    }
+                    if (first) { kq = make_float4(__builtin_inff(), __builtin_inff(), __builtin_inff(), __builtin_inff()); kd4 = 0; }
+                    else if (c + 1 < nbB) PSM_K_LOAD(c + 1)            // records of the next batch
                 } else {
                     // DispSel::CVSelect (src/DispSel.cpp:96-104) over the slices of this chunk: strict '<', d = 0 never a
                     // candidate, NaN never wins.  Rows outside [y0, y1) and halo lanes keep (+inf, 0).
