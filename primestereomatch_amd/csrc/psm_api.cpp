@@ -808,6 +808,37 @@ static int filter_both(psm_ctx *c)
     static const int S_env = getenv("PSM_PC_S") ? atoi(getenv("PSM_PC_S")) : 0;
     const int S = S_env > 1 ? S_env : 6;
     const bool two_phase = !dynsel && !(c->march.flags & 2097152) && c->Dloc >= 2 && (c->Dloc >= 112 || (c->march.flags & 1048576));
+    // Three phases (PSM_PC_S0 = r > 1, experiment): the seeding itself in two steps - every (S*r)-th slice through the planes,
+    // then the other multiples of S against those few seeds (key form), then the rest.
+    static const int R_env = getenv("PSM_PC_S0") ? atoi(getenv("PSM_PC_S0")) : 0;
+    if (two_phase && R_env > 1 && c->Dloc > S * R_env) {
+        const int R = R_env, D = c->Dloc;
+        const int n0 = (D + S * R - 1) / (S * R);                  // multiples of S*R below D
+        const int m1 = (D + S - 1) / S - 1;                        // k = 1..m1: S*k < D
+        const int n1 = m1 - m1 / R;                                // ... that are not multiples of R
+        const int n2 = D - (m1 + 1);                               // slices that are not multiples of S
+        const PcPlan pl0 = pc_plan(c->W, c->march.rows(c->H), n0, c->march.seg_rows, 2);
+        if (ensure_gf_scratch(c, 2 * pl0.scratch_bytes())) return 1;
+        const uint8_t *const *p4 = c->dtype == PSM_U8 ? c->p4 : nullptr;
+        {
+            Prof p(c, PSM_K_CVF_F);
+            launch_cvf_select2(c->stream, c->march, c->g, c->W, c->H, n0, c->d0, c->gf_scratch, nullptr, p4, 1, S * R);
+        }
+        {
+            Prof p(c, PSM_K_WTA);
+            launch_chunk_min2sides(c->stream, c->march, c->W, c->H, n0, c->gf_scratch, c->keys_cur, nullptr, 0);
+        }
+        if (n1 > 0) {
+            Prof p(c, PSM_K_CVF_F);
+            launch_cvf_select_keys2(c->stream, c->march, c->g, c->W, c->H, n1, c->d0, c->keys_cur, p4, 0, 2, R, S);
+        }
+        if (n2 > 0) {
+            Prof p(c, PSM_K_CVF_F);
+            launch_cvf_select_keys2(c->stream, c->march, c->g, c->W, c->H, n2, c->d0, c->keys_cur, p4, 0, 2, S, 1);
+        }
+        c->gf_virtual[0] = c->gf_virtual[1] = true;
+        return check_launch(c, "cvf (fused, select mode, three phases, both volumes)");
+    }
     if (two_phase) {
         const int n1 = (c->Dloc + S - 1) / S, n2 = c->Dloc - n1;
         const PcPlan pl1 = pc_plan(c->W, c->march.rows(c->H), n1, c->march.seg_rows, 2);

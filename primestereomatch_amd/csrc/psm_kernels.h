@@ -71,7 +71,7 @@ void launch_cvf_select_keys(hipStream_t s, March m, const float *vin, Guidance g
                             int d_begin, int cvc_mode, long long *keys, const uint8_t *p4_own = nullptr, const uint8_t *p4_other = nullptr,
                             int init = 1, int sel = 0, int step = 1);
 void launch_cvf_select_keys2(hipStream_t s, March m, const Guidance *g, int W, int H, int Dloc, int d_begin, long long *keys,
-                             const uint8_t *const *p4 = nullptr, int init = 1, int sel = 0, int step = 1);
+                             const uint8_t *const *p4 = nullptr, int init = 1, int sel = 0, int step = 1, int unit = 1);
 // both volumes per launch (costs on the fly): g[0] / g[1] = guidance of the left / right image; scratch: 2 x scratch_bytes();
 // keys / map: [2][H][W]
 void launch_cvf_select2(hipStream_t s, March m, const Guidance *g, int W, int H, int Dloc, int d_begin, void *scratch, int *cnt = nullptr,

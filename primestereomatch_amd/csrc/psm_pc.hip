@@ -152,11 +152,13 @@ struct PcDyn {
     // step-th slice (i -> i * step); sel 2 the others (i -> (i / (step-1)) * step + i % (step-1) + 1).  Two-phase
     // selection: a first launch reduces every step-th slice to the key plane, a MODE 2 launch then runs the rest
     // against that plane - its consumer lanes find a tight bound there and issue an atomic only a few times per pixel.
-    int sel, step;
+    // unit > 1 (sel 2 only): the same pattern in units of `unit` slices - the multiples of unit that are not multiples of
+    // unit * step (a middle phase of a three-phase selection).
+    int sel, step, unit;
 };
 __device__ __forceinline__ int pc_slice(const PcDyn &o, int i)
 {
-    return o.sel == 1 ? i * o.step : (o.sel == 2 ? (i / (o.step - 1)) * o.step + i % (o.step - 1) + 1 : i);
+    return o.sel == 1 ? i * o.step : (o.sel == 2 ? ((i / (o.step - 1)) * o.step + i % (o.step - 1) + 1) * o.unit : i);
 }
 
 // CVC = 0: the cost slice is read from `vin`.  CVC = 1 (left volume) / 2 (right volume): the cost volume is never
@@ -797,7 +799,7 @@ void launch_cvf_fused(hipStream_t s, March m, const float *vin, float *vout, Gui
 #define PSM_LAUNCH_PC(V4, CV)                                                                                              \
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_cvf_pc<V4, CV, 0>), dim3(nblocks), blk, 0, s, vin, vout, (const float4 *)gd.g1,   \
                        (const float4 *)gd.g2, (const float4 *)gd.g3, (const float2 *)gd.g4, W, H, Dloc, pl.ngroups, pl.nsegs, \
-                       pl.seg_rows, ybeg, yend, g1_other, d_begin, 1, (float *)nullptr, (unsigned *)nullptr, 0, PcSide{}, PcDyn{nullptr, 0, 0, 1})
+                       pl.seg_rows, ybeg, yend, g1_other, d_begin, 1, (float *)nullptr, (unsigned *)nullptr, 0, PcSide{}, PcDyn{nullptr, 0, 0, 1, 1})
     const bool v4 = (W & 3) == 0;
     if (cvc_mode == 1) { if (v4) PSM_LAUNCH_PC(true, 1); else PSM_LAUNCH_PC(false, 1); }
     else if (cvc_mode == 2) { if (v4) PSM_LAUNCH_PC(true, 2); else PSM_LAUNCH_PC(false, 2); }
@@ -810,7 +812,7 @@ void launch_cvf_select(hipStream_t s, March m, const float *vin, Guidance gd, in
 {   // p4_own != NULL (cvc_mode 1 / 2 only): 8-bit char mode; cnt != NULL: dynamic slice distribution (npairs ints, zeroed here)
     // Dloc = number of slices of this launch, (sel, step) = which ones (PcDyn)
     const PcPlan pl = pc_plan(W, m.rows(H), Dloc, m.seg_rows, cnt ? 5 : 1);
-    const PcDyn dyn = {cnt, pl.NW, sel, step};
+    const PcDyn dyn = {cnt, pl.NW, sel, step, 1};
     if (cnt) (void)hipMemsetAsync(cnt, 0, sizeof(int) * pl.ngroups * pl.nsegs, s);
     float *kcost = (float *)scratch;                                           // nchunks * rec_per_chunk float4
     unsigned *kdisp = (unsigned *)(kcost + 4 * pl.rec_per_chunk * pl.nchunks);  // nchunks * rec_per_chunk uchar4
@@ -843,7 +845,7 @@ void launch_cvf_select_keys(hipStream_t s, March m, const float *vin, Guidance g
 #define PSM_LAUNCH_K(CV, U8V, A0, A1)                                                                                       \
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_cvf_pc<false, CV, 2, U8V>), dim3(nblocks), blk, 0, s, A0, A1, (const float4 *)gd.g1, \
                        (const float4 *)gd.g2, (const float4 *)gd.g3, (const float2 *)gd.g4, W, H, Dloc, pl.ngroups, pl.nsegs, \
-                       pl.seg_rows, m.y0(H), m.y1(H), g1_other, d_begin, 1, (float *)keys, (unsigned *)nullptr, 0, PcSide{}, PcDyn{nullptr, 0, sel, step})
+                       pl.seg_rows, m.y0(H), m.y1(H), g1_other, d_begin, 1, (float *)keys, (unsigned *)nullptr, 0, PcSide{}, PcDyn{nullptr, 0, sel, step, 1})
     if (p4_own && cvc_mode != 0) {
         if (cvc_mode == 1) PSM_LAUNCH_K(1, true, (const float *)p4_own, (float *)const_cast<uint8_t *>(p4_other));
         else PSM_LAUNCH_K(2, true, (const float *)p4_own, (float *)const_cast<uint8_t *>(p4_other));
@@ -855,7 +857,7 @@ void launch_cvf_select_keys(hipStream_t s, March m, const float *vin, Guidance g
 
 // ... both volumes in one launch: keys[2][H][W]
 void launch_cvf_select_keys2(hipStream_t s, March m, const Guidance *g, int W, int H, int Dloc, int d_begin, long long *keys,
-                             const uint8_t *const *p4, int init, int sel, int step)
+                             const uint8_t *const *p4, int init, int sel, int step, int unit)
 {
     const PcPlan pl = pc_plan(W, m.rows(H), Dloc, m.seg_rows, 4);
     const size_t HW = (size_t)W * H;
@@ -867,11 +869,11 @@ void launch_cvf_select_keys2(hipStream_t s, March m, const Guidance *g, int W, i
     if (p4)
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_cvf_pc<false, 3, 2, true>), dim3(nblocks, 2), blk, 0, s, (const float *)p4[0], (float *)const_cast<uint8_t *>(p4[1]),
                            (const float4 *)g[0].g1, (const float4 *)g[0].g2, (const float4 *)g[0].g3, (const float2 *)g[0].g4, W, H, Dloc, pl.ngroups,
-                           pl.nsegs, pl.seg_rows, m.y0(H), m.y1(H), (const float4 *)g[1].g1, d_begin, 1, (float *)keys, (unsigned *)nullptr, 0, s1, PcDyn{nullptr, 0, sel, step});
+                           pl.nsegs, pl.seg_rows, m.y0(H), m.y1(H), (const float4 *)g[1].g1, d_begin, 1, (float *)keys, (unsigned *)nullptr, 0, s1, PcDyn{nullptr, 0, sel, step, unit});
     else
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_cvf_pc<false, 3, 2, false>), dim3(nblocks, 2), blk, 0, s, (const float *)nullptr, (float *)nullptr,
                            (const float4 *)g[0].g1, (const float4 *)g[0].g2, (const float4 *)g[0].g3, (const float2 *)g[0].g4, W, H, Dloc, pl.ngroups,
-                           pl.nsegs, pl.seg_rows, m.y0(H), m.y1(H), (const float4 *)g[1].g1, d_begin, 1, (float *)keys, (unsigned *)nullptr, 0, s1, PcDyn{nullptr, 0, sel, step});
+                           pl.nsegs, pl.seg_rows, m.y0(H), m.y1(H), (const float4 *)g[1].g1, d_begin, 1, (float *)keys, (unsigned *)nullptr, 0, s1, PcDyn{nullptr, 0, sel, step, unit});
 }
 
 void launch_chunk_min(hipStream_t s, March m, int W, int H, int Dloc, void *scratch, long long *keys, uint8_t *map, int dynamic)
@@ -891,7 +893,7 @@ void launch_cvf_select2(hipStream_t s, March m, const Guidance *g, int W, int H,
 {   // p4 != NULL: 8-bit char mode, p4[0] / p4[1] = byte planes {c0,c1,c2,grad} of the left / right image
     // cnt != NULL: dynamic slice distribution (2 * npairs ints, zeroed here)
     const PcPlan pl = pc_plan(W, m.rows(H), Dloc, m.seg_rows, cnt ? 6 : 2);
-    const PcDyn dyn = {cnt, pl.NW, sel, step};
+    const PcDyn dyn = {cnt, pl.NW, sel, step, 1};
     if (cnt) (void)hipMemsetAsync(cnt, 0, sizeof(int) * 2 * pl.ngroups * pl.nsegs, s);
     float *kcost0 = (float *)scratch;
     unsigned *kdisp0 = (unsigned *)(kcost0 + 4 * pl.rec_per_chunk * pl.nchunks);
