@@ -344,7 +344,7 @@ def main():
             kern[nm] = {"avg_ms": tot / n, "launches_per_step": n / prof_steps}
     de.set_option(capi.PSM_OPT_PROFILE, 0)
     # voxels per launch of the filter kernel = the step's 2*W*H*Dloc over its launches per step: 1 (both volumes in one
-    # launch), 2 (one launch per volume - or, from 112 local slices up, the two phases of the select form: every 6th slice
+    # launch), 2 (one launch per volume - or, from 112 local slices up, the two phases of the select form: every 5th slice
     # of both volumes through the minima planes, then the other slices of both volumes against the key plane; the two
     # are instantiations of the same kernel, so avg_launch_ms is their mean and alg bytes / launch the mean as well)
     lps = max(1, round(kern.get("cvf_fused", {}).get("launches_per_step", 2)))   # (other filter forms: one side per launch)

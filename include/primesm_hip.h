@@ -71,7 +71,7 @@ enum {
                                    workgroups take the slices of their (column group, segment) pair dynamically from a
                                    device counter (default: static chunks of slices per workgroup); 1048576 / 2097152 =
                                    force / disable the two-phase selection of psm_cost_filter (default: on from 112
-                                   local slices - every 6th slice through the minima planes, the rest against the
+                                   local slices - every 5th slice through the minima planes, the rest against the
                                    seeded key plane); 4194304 = psm_wgt_median runs its row-dataflow form only;
                                    8388608 = at most 2 sweeps of its parallel form (test hook for the fall-back).
                                    No flag changes any result. */

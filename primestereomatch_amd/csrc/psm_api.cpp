@@ -804,9 +804,12 @@ static int filter_both(psm_ctx *c)
     // 720p x 128, worse at 64 slices and below; flag 1048576 forces it for any Dloc >= 2, flag 2097152 turns it off): every S-th slice goes through the
     // minima planes -> k_chunk_min -> keys; the other slices then run against that seeded key plane (MODE 2: one key load
     // per voxel, an atomic only where a slice beats the current minimum - rare after the seeding), so they write no
-    // planes and need no reduction.  PSM_PC_S overrides S (default 6).
+    // planes and need no reduction.  PSM_PC_S overrides S (default 5; 4 from 4 Mpixel up).
     static const int S_env = getenv("PSM_PC_S") ? atoi(getenv("PSM_PC_S")) : 0;
-    const int S = S_env > 1 ? S_env : 6;
+    // (measured, S = 4 / 5 / 6: 1080p x 256 7.60 / 7.20-7.36 / 7.43-7.60 ms, 4K x 256 28.6-29.4 / 30.0-30.8 / 29.6-30.4,
+    // 720p x 128 1.97 / 1.90 / 1.90, 1/8 stripe of 1080p 1.08 / 1.10 / 1.10: the optimum moves with how the two launches fill
+    // their rounds of resident workgroups)
+    const int S = S_env > 1 ? S_env : ((size_t)c->W * c->H >= ((size_t)1 << 22) ? 4 : 5);
     const bool two_phase = !dynsel && !(c->march.flags & 2097152) && c->Dloc >= 2 && (c->Dloc >= 112 || (c->march.flags & 1048576));
     // Three phases (PSM_PC_S0 = r > 1, experiment): the seeding itself in two steps - every (S*r)-th slice through the planes,
     // then the other multiples of S against those few seeds (key form), then the rest.

@@ -764,7 +764,9 @@ PcPlan pc_plan_cols(int W, int H, int Dloc, int seg_rows_opt, int mode_in, int c
         const long per_xcd = ((long)sides * pl.ngroups * kk * nch + 7) / 8;
         static const int slots_env = getenv("PSM_PC_SLOTS") ? atoi(getenv("PSM_PC_SLOTS")) : 0;
         const long slots = slots_env > 0 ? slots_env : ((mode_in == 3 || mode_in == 4) && PSM_PC_OCC4 ? 128 : 96);   // resident workgroups per XCD: 32 CUs x 3 (key form: x 4)
-        const long rounds2 = 2 * ((per_xcd + slots - 1) / slots) + 1;                // 2 x (rounds + 1/2)
+        static const int tail_env = getenv("PSM_PC_TAIL") ? atoi(getenv("PSM_PC_TAIL")) : -1;
+        const long tail2 = tail_env >= 0 ? tail_env : 1;                             // 2 x the tail allowance in rounds
+        const long rounds2 = 2 * ((per_xcd + slots - 1) / slots) + ((mode_in == 3 || mode_in == 4) ? tail2 : 1);   // 2 x (rounds + 1/2)
         return rounds2 * dc * ((rows + kk - 1) / kk + 14) / 2 + (mode == 1 ? 2L * sides * nch : 0);
     };
     auto allowed = [&](int dc, int kk) { return (dc == dcs[0] || dc <= Dloc) && (seg_rows_opt <= 0 || kk == (rows + seg_rows_opt - 1) / seg_rows_opt); };
