@@ -449,6 +449,7 @@ def main():
             sw = (resw["cvc_ms"] + resw["cvf_ms"] + resw["dispsel_ms"]) * 1e-3
             cpu["wide"] = {"value": round(2.0 * W * H * sd / sw, 1), "cores": wide}
 
+    seed_stride = de.seed_stride()        # what the library's in-place tuner chose for this geometry (0: not in use)
     if rank == 0:
         out = {
             "metric": "cost-volume voxels/s (CVC+CVF+WTA)" if not args.fgf else f"cost-volume voxels/s (CVC+CVF_FGF s={args.fgf}+WTA)",
@@ -460,7 +461,7 @@ def main():
                        "parallelism": "1 GPU" if world == 1 and not use_dist else
                                       (f"{world} row stripes of {rows_max} rows (all {D} slices each) + 1 RCCL all_gather of the map rows per frame"
                                        if rows_mode else f"D sharded over {world} ranks + 1 RCCL {args.exchange} of packed minima"),
-                       "kernel_variant": args.variant, "shard_sim": args.shard_sim, "shard": (args.shard if (use_dist or args.shard_sim > 1) else None)},
+                       "kernel_variant": args.variant, "shard_sim": args.shard_sim, "seed_stride": seed_stride, "shard": (args.shard if (use_dist or args.shard_sim > 1) else None)},
             "roofline": roofline, "cpu_baseline": cpu, "kernels": kern,
             "median_ms_per_step": round(median_ms, 4), "pcie": pcie,
         }

@@ -73,7 +73,10 @@ enum {
                                    force / disable the two-phase selection of psm_cost_filter (default: on from 112
                                    local slices - every 5th slice through the minima planes, the rest against the
                                    seeded key plane); 4194304 = psm_wgt_median runs its row-dataflow form only;
-                                   8388608 = at most 2 sweeps of its parallel form (test hook for the fall-back).
+                                   8388608 = at most 2 sweeps of its parallel form (test hook for the fall-back);
+                                   16777216 = in-place tuning of the seeding stride of the two-phase selection
+                                   (the strides 5, 4, 6 are timed twice each on frames 4-9 of a geometry and the
+                                   fastest kept; default: 5, and 4 from 4 Mpixel up).
                                    No flag changes any result. */
 };
 
@@ -223,6 +226,9 @@ int psm_set_map_buffer(psm_ctx *ctx, void *dev_maps, int whole);
 int psm_gather_rows_ctx(psm_ctx *root, psm_ctx *const *stripes, int nstripes, uint8_t *lmap, uint8_t *rmap, size_t stride);
 
 /* ---- debug / bench entry points (no counterpart in the reference) ---- */
+/* Stride of the seeding phase of the two-phase selection the in-place tuner settled on for the current geometry
+ * (0: still measuring, or the two-phase selection is not in use). */
+int psm_debug_seed_stride(psm_ctx *ctx);
 
 /* Replace the device maps and validity masks (any may be NULL = keep) - lets the post-processing stages run on maps
  * that did not come from this context's WTA.  H rows of W bytes, pitch `stride`; map values must be < max_disp. */

@@ -50,6 +50,7 @@ SYMBOLS = [
     ("psm_fill_invalid", _i, [_vp, _vp, _vp, _sz]),
     ("psm_wgt_median", _i, [_vp, _vp, _vp, _sz]),
     ("psm_wgt_median_stats", _i, [_vp, _vp, _vp]),
+    ("psm_debug_seed_stride", _i, [_vp]),
     ("psm_set_rows", _i, [_vp, _i, _i]),
     ("psm_set_map_buffer", _i, [_vp, _vp, _i]),
     ("psm_gather_rows_ctx", _i, [_vp, _vp, _i, _vp, _vp, _sz]),

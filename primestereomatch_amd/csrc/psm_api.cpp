@@ -77,6 +77,16 @@ struct psm_ctx {
     int g1_y0 = 0, g1_y1 = 0;             // likewise for g1 (and the 8-bit planes) while have_g1 is false
     void *gf_scratch = nullptr;         // chunk planes of the select-mode kernel (PcPlan::scratch_bytes)
     size_t gf_scratch_bytes = 0;
+    // Stride of the seeding phase, tuned in place: the first frames of a geometry run the candidates once each (same
+    // results whatever the stride), timed with events on the launch stream; the fastest is kept.
+    struct Tune {
+        int W = 0, H = 0, D = 0, y0 = 0, y1 = 0, dtype = -1;
+        int calls = 0, best = 0;
+        int n[3] = {0, 0, 0};                     // measurements taken per candidate
+        float ms[3] = {-1.f, -1.f, -1.f};         // fastest of them
+        hipEvent_t e0[3] = {nullptr, nullptr, nullptr}, e1[3] = {nullptr, nullptr, nullptr};
+        bool pend[3] = {false, false, false};
+    } tune;
     int *gf_cnt = nullptr;              // slice counters of the dynamic select form (one per side and pair)
     size_t gf_cnt_n = 0;
     float4 *fgf_mab[2] = {nullptr, nullptr};
@@ -216,6 +226,10 @@ void free_all(psm_ctx *c)
             (void)hipEventDestroy(p.second);
         }
     for (auto e : c->event_pool) (void)hipEventDestroy(e);
+    for (int i = 0; i < 3; ++i) {
+        if (c->tune.e0[i]) (void)hipEventDestroy(c->tune.e0[i]);
+        if (c->tune.e1[i]) (void)hipEventDestroy(c->tune.e1[i]);
+    }
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
 }
 
@@ -771,6 +785,12 @@ static bool can_filter_both(const psm_ctx *c)
            !c->fgf_virtual[0] && !c->fgf_virtual[1];
 }
 
+static int R_env_on()
+{
+    static const int r = getenv("PSM_PC_S0") ? atoi(getenv("PSM_PC_S0")) : 0;
+    return r > 1 ? r : 0;
+}
+
 static int filter_both(psm_ctx *c)
 {
     {   // g1 rows this launch reads: everything, or the stripe's rows - 8 .. + 8
@@ -809,7 +829,62 @@ static int filter_both(psm_ctx *c)
     // (measured, S = 4 / 5 / 6: 1080p x 256 7.60 / 7.20-7.36 / 7.43-7.60 ms, 4K x 256 28.6-29.4 / 30.0-30.8 / 29.6-30.4,
     // 720p x 128 1.97 / 1.90 / 1.90, 1/8 stripe of 1080p 1.08 / 1.10 / 1.10: the optimum moves with how the two launches fill
     // their rounds of resident workgroups)
-    const int S = S_env > 1 ? S_env : ((size_t)c->W * c->H >= ((size_t)1 << 22) ? 4 : 5);
+    int S = S_env > 1 ? S_env : ((size_t)c->W * c->H >= ((size_t)1 << 22) ? 4 : 5);
+    // ... so PSM_OPT_FLAGS 16777216 (for hosts that run many frames of one geometry) tunes it in place: the candidates 5, 4, 6
+    // are timed twice each, round robin, on the frames 4-9 of a geometry (the first frames carry allocations and ramping
+    // clocks) and the one with the fastest frame is kept - psm_debug_seed_stride reports it.  On the measured
+    // configurations it settles on the static defaults above (1080p: 5, 4K: 4; 720p x 128 and stripes: 6, within 0.5 %).
+    static const int TUNE_S[3] = {5, 4, 6};
+    int tune_i = -1;
+    psm_ctx::Tune &tn = c->tune;
+    if (S_env <= 1 && (c->march.flags & 16777216) && R_env_on() == 0 && !dynsel && !(c->march.flags & 2097152) &&
+        (c->Dloc >= 112 || (c->march.flags & 1048576)) && c->Dloc >= 2) {
+        if (tn.W != c->W || tn.H != c->H || tn.D != c->Dloc || tn.y0 != c->march.ybeg || tn.y1 != c->march.yend || tn.dtype != c->dtype) {
+            for (int i = 0; i < 3; ++i) {      // new geometry: start over (events still in flight are simply ignored)
+                tn.ms[i] = -1.f;
+                tn.n[i] = 0;
+                tn.pend[i] = false;
+            }
+            tn.W = c->W; tn.H = c->H; tn.D = c->Dloc; tn.y0 = c->march.ybeg; tn.y1 = c->march.yend; tn.dtype = c->dtype;
+            tn.calls = 0;
+            tn.best = 0;
+        }
+        for (int i = 0; i < 3; ++i)
+            if (tn.pend[i] && hipEventQuery(tn.e1[i]) == hipSuccess) {
+                float ms = -1.f;
+                if (hipEventElapsedTime(&ms, tn.e0[i], tn.e1[i]) != hipSuccess) ms = 1e30f;
+                tn.ms[i] = (tn.n[i] == 0 || ms < tn.ms[i]) ? ms : tn.ms[i];
+                tn.n[i] += 1;
+                tn.pend[i] = false;
+            }
+        (void)hipGetLastError();               // (hipEventQuery reports "not ready" through the error state)
+        const int TUNE_ROUNDS = 2, TUNE_SKIP = 3;   // frames before the first measurement: allocations, clocks still ramping up
+        if (!tn.best && tn.n[0] >= TUNE_ROUNDS && tn.n[1] >= TUNE_ROUNDS && tn.n[2] >= TUNE_ROUNDS) {
+            int b = 0;
+            for (int i = 1; i < 3; ++i)
+                if (tn.ms[i] < tn.ms[b]) b = i;
+            tn.best = TUNE_S[b];
+        }
+        if (tn.best) S = tn.best;
+        else if (++tn.calls > TUNE_SKIP) {
+            // round robin 5, 4, 6, 5, 4, 6: the candidate with the fewest measurements (taken + in flight) next
+            int fewest = 1 << 30;
+            for (int i = 0; i < 3; ++i) {
+                const int k = tn.n[i] + (tn.pend[i] ? 1 : 0);
+                if (k < TUNE_ROUNDS && !tn.pend[i] && k < fewest) { fewest = k; tune_i = i; }
+            }
+            if (tune_i >= 0) {
+                if (!tn.e0[tune_i] && (hipEventCreate(&tn.e0[tune_i]) != hipSuccess || hipEventCreate(&tn.e1[tune_i]) != hipSuccess)) {
+                    (void)hipGetLastError();
+                    tune_i = -1;               // no events: no tuning, the default stride stays
+                    tn.best = S;
+                } else {
+                    S = TUNE_S[tune_i];
+                    (void)hipEventRecord(tn.e0[tune_i], c->stream);
+                }
+            }
+        }
+    }
     const bool two_phase = !dynsel && !(c->march.flags & 2097152) && c->Dloc >= 2 && (c->Dloc >= 112 || (c->march.flags & 1048576));
     // Three phases (PSM_PC_S0 = r > 1, experiment): the seeding itself in two steps - every (S*r)-th slice through the planes,
     // then the other multiples of S against those few seeds (key form), then the rest.
@@ -845,7 +920,14 @@ static int filter_both(psm_ctx *c)
     if (two_phase) {
         const int n1 = (c->Dloc + S - 1) / S, n2 = c->Dloc - n1;
         const PcPlan pl1 = pc_plan(c->W, c->march.rows(c->H), n1, c->march.seg_rows, 2);
-        if (ensure_gf_scratch(c, 2 * pl1.scratch_bytes())) return 1;
+        {   // (sized for the smallest candidate stride as well: no reallocation - a pipeline stall - while tuning)
+            size_t need = 2 * pl1.scratch_bytes();
+            if (S_env <= 1 && c->Dloc >= 8) {
+                const size_t n4 = 2 * pc_plan(c->W, c->march.rows(c->H), (c->Dloc + 3) / 4, c->march.seg_rows, 2).scratch_bytes();
+                need = n4 > need ? n4 : need;
+            }
+            if (ensure_gf_scratch(c, need)) return 1;
+        }
         {
             Prof p(c, PSM_K_CVF_F);
             launch_cvf_select2(c->stream, c->march, c->g, c->W, c->H, n1, c->d0, c->gf_scratch, nullptr, c->dtype == PSM_U8 ? c->p4 : nullptr, 1, S);
@@ -857,6 +939,10 @@ static int filter_both(psm_ctx *c)
         {
             Prof p(c, PSM_K_CVF_F);
             launch_cvf_select_keys2(c->stream, c->march, c->g, c->W, c->H, n2, c->d0, c->keys_cur, c->dtype == PSM_U8 ? c->p4 : nullptr, 0, 2, S);
+        }
+        if (tune_i >= 0) {
+            (void)hipEventRecord(tn.e1[tune_i], c->stream);
+            tn.pend[tune_i] = true;
         }
         c->gf_virtual[0] = c->gf_virtual[1] = true;
         return check_launch(c, "cvf (fused, select mode, two phases, both volumes)");
@@ -1094,6 +1180,11 @@ int psm_disp_select_partial_side(psm_ctx *c, int side, void *dev_keys_side)
     if (!c->opt_async) PSM_HIP(c, hipStreamSynchronize(c->stream));
     c->stage_us[PSM_STAGE_DISPSEL] = (side == PSM_LEFT ? 0.0 : c->stage_us[PSM_STAGE_DISPSEL]) + (now_us() - t0);
     return 0;
+}
+
+int psm_debug_seed_stride(psm_ctx *c)
+{   // stride of the seeding phase the tuner settled on for the current geometry; 0 while it is still measuring / not in use
+    return c ? c->tune.best : 0;
 }
 
 int psm_set_rows(psm_ctx *c, int y_begin, int y_end)

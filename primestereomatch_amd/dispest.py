@@ -204,6 +204,10 @@ class DispEst:
                                               _ptr(self.rDisMap) if download else None, self.wid),
                  "DispSelect_merge_ctx")
 
+    def seed_stride(self) -> int:
+        """Stride of the seeding phase the in-place tuner settled on (0: still measuring / two-phase selection not in use)."""
+        return int(self._lib.psm_debug_seed_stride(self._h))
+
     def set_rows(self, y_begin: int = 0, y_end: int = 0):
         """Row stripe: CostFilter_GPU / DispSelect* compute output rows [y_begin, y_end) of the whole image only (all
         slices, both volumes, identical values); (0, 0): whole image.  Call before CostFilter_GPU."""

@@ -606,3 +606,29 @@ def test_two_phase_selection_on_shards(psm, oracle):
     finally:
         for s in shards:
             s.close()
+
+
+def test_seed_stride_tuner(psm, oracle):
+    """PSM_OPT_FLAGS 16777216: the stride of the seeding phase is tuned in place over the first frames of a geometry
+    (candidates 5, 4, 6, two frames each after three untimed ones): every frame gives the same maps, the tuner settles, a new
+    geometry (row stripe) starts it over; without the flag nothing is tuned."""
+    from primestereomatch_amd import capi, synth
+    W, H, D = 160, 40, 120
+    l, r, _ = synth.make_pair(W, H, D, seed=3)
+    ref = oracle.pipeline_f32(l, r, D, threads=8)
+    with psm.DispEst(l, r, D) as de:
+        de.set_option(capi.PSM_OPT_FLAGS, 16777216)
+        seen = []
+        for f in range(12):
+            de.CostConst_GPU(); de.CostFilter_GPU(); de.DispSelect_GPU()
+            assert np.array_equal(de.lDisMap, ref["ldisp"]) and np.array_equal(de.rDisMap, ref["rdisp"]), f
+            seen.append(de.seed_stride())
+        assert seen[0] == 0 and seen[-1] in (4, 5, 6), seen
+        de.set_rows(8, 30)                      # another geometry: measured again
+        de.CostConst_GPU(); de.CostFilter_GPU(); de.DispSelect_GPU()
+        assert de.seed_stride() == 0
+        assert np.array_equal(de.lDisMap[8:30], ref["ldisp"][8:30])
+    with psm.DispEst(l, r, D) as de:
+        for f in range(6):
+            de.CostConst_GPU(); de.CostFilter_GPU(); de.DispSelect_GPU()
+        assert de.seed_stride() == 0 and np.array_equal(de.lDisMap, ref["ldisp"])
