@@ -104,8 +104,10 @@ def main():
         raise SystemExit("bench.py: --gpus must be >= 1")
     if args.shard == "disp" and N > CONFIGS[args.config][2]:
         raise SystemExit(f"bench.py: --gpus {N} exceeds the {CONFIGS[args.config][2]} disparity slices of config {args.config} (one shard per rank)")
-    if args.shard == "rows" and N > CONFIGS[args.config][1]:
-        raise SystemExit(f"bench.py: --gpus {N} exceeds the {CONFIGS[args.config][1]} rows of config {args.config} (one stripe per rank)")
+    if args.shard == "rows" and (N > CONFIGS[args.config][1] or (N - 1) * -(-CONFIGS[args.config][1] // N) >= CONFIGS[args.config][1]):
+        # (every rank decides this the same way, before any rendezvous: stripes of ceil(H / N) rows must leave the last rank some)
+        raise SystemExit(f"bench.py: --gpus {N}: stripes of {-(-CONFIGS[args.config][1] // N)} rows leave a rank without rows of the "
+                         f"{CONFIGS[args.config][1]}-row image of config {args.config} (one stripe per rank)")
     if N > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
         # bare `python bench.py --gpus N`: become the launcher - one rank per GPU under torch.distributed.run on
         # 127.0.0.1 - and pass rank 0's single JSON line through
