@@ -210,3 +210,36 @@ def test_wgt_median_is_sequential_in_place(oracle):
         one[y, x] = 0
         jac[y, x] = oracle.wgt_median(img, dis, one, D)[y, x]
     assert not np.array_equal(seq, jac)
+
+
+@pytest.mark.parametrize("seed,frac,two_camps", [(21, 0.5, False), (22, 0.7, True), (23, 1.0, True)])
+def test_wgt_median_is_the_fixed_point_of_parallel_sweeps(oracle, seed, frac, two_camps):
+    """What the device's product form relies on (psm_wgt_median): the in-place raster-order map s is the unique
+    solution of s[p] = f(s[q] for invalid q earlier than p, input[q] otherwise).  Sweeping new[p] = f(cur[earlier], input[later])
+    over all invalid pixels at once (Jacobi, from cur = input) reaches a map that no sweep changes, and that map is s - also
+    when every pixel is invalid and on a two-camp map built to make changes propagate.  f is evaluated with the oracle itself
+    (one invalid pixel per call)."""
+    H, W = 14, 16
+    img, dis, valid, D = _wm_case(seed, H=H, W=W, D=12, frac_invalid=frac)
+    if two_camps:
+        img[:] = np.float32(0.5)
+        dis = np.where(np.random.default_rng(seed).random(dis.shape) < 0.5, 2, 9).astype(np.uint8)
+    seq = oracle.wgt_median(img, dis, valid, D)
+    idx = np.arange(H * W).reshape(H, W)
+    cur = dis.copy()
+    inv = list(zip(*np.nonzero(valid == 0)))
+    for sweep in range(1, 200):
+        new = cur.copy()
+        for (y, x) in inv:
+            seen = np.where(idx < idx[y, x], cur, dis)        # earlier pixels: current iterate, later ones (and p): the input
+            one = np.ones_like(valid)
+            one[y, x] = 0
+            new[y, x] = oracle.wgt_median(img, seen, one, D)[y, x]
+        if np.array_equal(new, cur):
+            break
+        cur = new
+    else:
+        pytest.fail("no fixed point within 200 sweeps")
+    assert np.array_equal(cur, seq)
+    assert sweep <= len(inv) + 1                               # (worst case: one pixel of the dependency chain per sweep)
+    print(f"[wmf-fixed-point] {len(inv)} invalid pixels, {sweep} sweeps")
