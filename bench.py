@@ -82,6 +82,8 @@ def main():
                     help="N > 1: what a rank owns - 'rows': a stripe of H/N output rows of both volumes, all D slices (no minima "
                          "exchanged, one all-gather of the finished map rows per frame); 'disp': D/N slices of both volumes, whole "
                          "image (one collective on packed per-pixel minima per frame, --exchange)")
+    ap.add_argument("--lr-check", type=int, default=-1, choices=[-1, 0, 1],
+                    help="PP left-right check on the GPU inside the step (BASELINE configs[4]); -1: on for config c5 only")
     ap.add_argument("--box-bench", action="store_true", help="also time the plain box-filter pass")
     ap.add_argument("--fgf", type=int, default=0, choices=[0, 2, 4, 8],
                     help="diagnostic: aggregate with the Fast Guided Filter variant (CostFilter_FGF) at this subsample "
@@ -200,6 +202,8 @@ def main():
         de.setSubsampleRate(args.fgf)
 
     pipelined = use_dist and (args.exchange == "allreduce" or rows_mode) and not args.no_frame_pipeline and not args.fgf
+    # BASELINE configs[4]: "+ PP left-right check on-GPU" - lrCheck (src/PP.cpp:17-50) on the finished maps, part of the step
+    lrc = (args.lr_check == 1 or (args.lr_check < 0 and args.config == "c5")) and not (args.shard_sim > 1)
 
     def finish_pending():
         # exchange of an earlier frame -> final maps (the collective ran on RCCL's stream meanwhile)
@@ -212,6 +216,8 @@ def main():
                 de.set_map_buffer(kb.data_ptr(), whole=True)
             else:
                 de.DispSelect_merge(kb.data_ptr(), 1, download=False)
+            if lrc:
+                de.LRCheck_device()
 
     def stripe_exchange(mb, async_op):
         stripes.pack_stripe(mb, y0, y1, send, H, W, rows_max)
@@ -275,6 +281,8 @@ def main():
             de.DispSelect_partial()
         else:
             de.DispSelect_device()
+        if lrc and not (use_dist and args.exchange == "none"):
+            de.LRCheck_device()
 
     def sync():
         finish_pending()
@@ -338,7 +346,7 @@ def main():
     sync()
     names = {capi.PSM_K_PREP: "prep", capi.PSM_K_CVC: "cvc", capi.PSM_K_GUIDE: "guidance", capi.PSM_K_CVF_F: "cvf_fused",
              capi.PSM_K_CVF_A: "cvf_a", capi.PSM_K_CVF_B: "cvf_b", capi.PSM_K_WTA: "wta",
-             capi.PSM_K_MERGE: "merge", capi.PSM_K_FGF: "cvf_fgf"}
+             capi.PSM_K_MERGE: "merge", capi.PSM_K_FGF: "cvf_fgf", capi.PSM_K_LRC: "lr_check"}
     kern = {}
     for k, nm in names.items():
         tot, n = de.kernel_time_ms(k)
@@ -408,6 +416,10 @@ def main():
             ref.CostFilter_FGF_GPU() if args.fgf else ref.CostFilter_GPU()
             ref.DispSelect_GPU()
             verified = bool(np.array_equal(ref.lDisMap, got_l) and np.array_equal(ref.rDisMap, got_r))
+            if lrc:      # the validity masks of the timed path against those of the one-GPU run
+                got_lv, got_rv = (m.copy() for m in de.download_valid())
+                ref.LRCheck_GPU()
+                verified = verified and bool(np.array_equal(ref.lValid, got_lv) and np.array_equal(ref.rValid, got_rv))
         if not verified:
             print("bench.py: MAPS OF THE TIMED PATH DIFFER FROM THE ONE-GPU RUN", file=sys.stderr)
 
@@ -463,7 +475,7 @@ def main():
                        "parallelism": "1 GPU" if world == 1 and not use_dist else
                                       (f"{world} row stripes of {rows_max} rows (all {D} slices each) + 1 RCCL all_gather of the map rows per frame"
                                        if rows_mode else f"D sharded over {world} ranks + 1 RCCL {args.exchange} of packed minima"),
-                       "kernel_variant": args.variant, "shard_sim": args.shard_sim, "seed_stride": seed_stride, "shard": (args.shard if (use_dist or args.shard_sim > 1) else None)},
+                       "kernel_variant": args.variant, "shard_sim": args.shard_sim, "seed_stride": seed_stride, "lr_check_on_gpu": bool(lrc), "shard": (args.shard if (use_dist or args.shard_sim > 1) else None)},
             "roofline": roofline, "cpu_baseline": cpu, "kernels": kern,
             "median_ms_per_step": round(median_ms, 4), "pcie": pcie,
         }

@@ -136,6 +136,15 @@ class DispEst:
                  "LRCheck_GPU")
         return 0
 
+    def LRCheck_device(self):
+        """PP lrCheck with the validity masks left on the device (bench: D2H excluded from the timed region)."""
+        self._ck(self._lib.psm_lr_check(self._h, None, None, 0), "LRCheck_device")
+
+    def download_valid(self):
+        """The validity masks of the last LRCheck (psm_lr_check is idempotent on unchanged maps: run again, with download)."""
+        self.LRCheck_GPU()
+        return self.lValid, self.rValid
+
     def FillInv_GPU(self) -> int:
         """PP fillInv (src/PP.cpp:52-143) on the device; updates lDisMap / rDisMap."""
         self._ck(self._lib.psm_fill_invalid(self._h, _ptr(self.lDisMap), _ptr(self.rDisMap), self.wid),

@@ -59,3 +59,11 @@ def test_one_stripe_of_n_live(parts):
     """--shard-sim N --shard rows: the rank-local work of an N-way row-stripe run (stripe 0) on this GPU."""
     j = _bench("--shard-sim", str(parts), "--shard", "rows", "--config", "c3", "--steps", "3", "--warmup", "1", "--no-cpu-baseline")
     assert j["config"]["shard"] == "rows" and j["ms_per_step"] > 0
+
+
+@pytest.mark.parametrize("extra", [(), ("--gpus", "1", "--force-dist", "--shard", "rows"), ("--gpus", "1", "--force-dist", "--shard", "disp")])
+def test_lr_check_inside_the_step(extra):
+    """BASELINE configs[4]: the PP left-right check runs on the GPU as part of the step (default for c5, --lr-check 1 elsewhere);
+    the validity masks of the timed path equal those of the plain one-GPU run."""
+    j = _bench("--config", "c3", "--lr-check", "1", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--verify", *extra)
+    assert j["config"]["lr_check_on_gpu"] is True and j["verified_vs_single_gpu"] is True
