@@ -106,3 +106,42 @@ def test_march_model_matches_oracle(oracle, shape, seg_rows, waves, order):
     assert np.all(written == 1)                     # every voxel produced exactly once
     for d in range(shape[0]):
         assert np.array_equal(out[d], oracle.box8(vol[d]))   # bit-exact: same tree order
+
+
+# ------------------------------------------------------------------------------------------
+# Row bookkeeping of the fused producer/consumer kernel (psm_pc.hip: y0/y1, mstart/mend, nbA, consumer feeds):
+# which model rows a segment [y0, y1) of an H-row image produces, against which ones its consumer taps read.
+# (A one-row segment at the top of the image needed model row 4 - REFLECT_101 of row -4 - which the first version
+# of the formula left out; the randomised stripe test on the GPU found it, this model pins it on the CPU.)
+# ------------------------------------------------------------------------------------------
+def r101(k, n):
+    k = -k if k < 0 else k
+    return 2 * (n - 1) - k if k >= n else k
+
+
+def pc_segment_rows(H, y0, y1):
+    mstart = max(0, y0 - 4)
+    mend = min(H - 1, max(y1 + 2, 4 - y0))
+    nbA = (mend - mstart + 1 + 3) >> 2                 # producer batches of four rows
+    produced = set(range(mstart, min(H, mstart + 4 * nbA)))   # rows the producer waves write into the ring (clamped to the image)
+    nf = (y1 - y0) + 7                                 # consumer feeds j = 0 .. nf-1: model row r101(y0 - 4 + j)
+    needed = {r101(y0 - 4 + j, H) for j in range(nf)}
+    return mstart, mend, produced, needed
+
+
+@pytest.mark.parametrize("H", [8, 9, 12, 13, 33, 64, 135, 375])
+def test_fused_kernel_segments_produce_every_model_row_they_consume(H):
+    rng = np.random.default_rng(H)
+    cases = [(0, 1), (0, 2), (1, 2), (H - 1, H), (H - 2, H), (0, H), (3, 4), (4, 5)]
+    cases += [tuple(sorted(rng.choice(H + 1, size=2, replace=False))) for _ in range(200)]
+    for y0, y1 in cases:
+        y0, y1 = int(y0), int(y1)
+        if not (0 <= y0 < y1 <= H):
+            continue
+        mstart, mend, produced, needed = pc_segment_rows(H, y0, y1)
+        assert needed <= produced, (H, y0, y1, sorted(needed - produced))
+        assert min(needed) >= mstart and max(needed) <= mend, (H, y0, y1)
+        # the old formula (mend = min(H-1, y1+2)) fails exactly for the one-row segment at the top
+        old_mend = min(H - 1, y1 + 2)
+        if max(needed) > old_mend:
+            assert (y0, y1) == (0, 1), (H, y0, y1)
