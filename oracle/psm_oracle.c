@@ -53,9 +53,28 @@ void psmo_u8_to_f32(const uint8_t *src, size_t n, float *dst)
 #define BC_32F 1.0     /* include/CVC.h:12  (a double literal) */
 #define ALPHA_32F 0.9f /* include/CVC.h:23 */
 
+/* Alternative READINGS of two reference lines whose meaning depends on the toolchain that compiles the reference
+ * (psmo_set_variant; never the canon - tests/test_oracle.py uses them to put a number on how far "the reference binary"
+ * can be from the canonical arithmetic):
+ *   PSMO_VAR_FABS_DOUBLE  src/CVC.cpp:21-23 calls unqualified fabs() on float differences with only <math.h> in scope
+ *                         (include/ComFunc.h:18): with libstdc++ >= 6 that resolves to the float overload (canon); with the
+ *                         2016-era toolchains the project targeted it is ::fabs(double) - the three terms are doubles, their
+ *                         sum is formed in double and rounded once when assigned to `float clrDiff`.
+ *   PSMO_VAR_FMA_SOLVE    the scalar solve loop src/CVF.cpp:129-147 compiled with -ffp-contract=fast on an FMA target (GCC's
+ *                         default outside ISO mode; ARM VFPv4 / NEON boards are what the project ran on): every a*b-c*d /
+ *                         a*b+c*d there becomes a fused multiply-add. */
+static int g_variant = 0;
+void psmo_set_variant(int bits) { g_variant = bits; }
+int psmo_get_variant(void) { return g_variant; }
+
 /* src/CVC.cpp:18-27 */
 static inline float myCostGrd2(const float *lC, const float *rC, const float *lG, const float *rG)
 {
+    if (g_variant & PSMO_VAR_FABS_DOUBLE) {
+        float cd = (float)(fabs((double)(lC[0] - rC[0])) + fabs((double)(lC[1] - rC[1])) + fabs((double)(lC[2] - rC[2])));
+        float gd = (float)fabs((double)(*lG - *rG));
+        return ALPHA_32F * cd + (1 - ALPHA_32F) * gd;
+    }
     float clrDiff = fabsf(lC[0] - rC[0]) + fabsf(lC[1] - rC[1]) + fabsf(lC[2] - rC[2]);
     float grdDiff = fabsf(*lG - *rG);
     return ALPHA_32F * clrDiff + (1 - ALPHA_32F) * grdDiff;
@@ -288,6 +307,18 @@ static void guided_filter_ws(const float *rgb, const float *mean_I, const float 
         float a31 = var_I[2 * N + i];
         float a32 = var_I[4 * N + i];
         float a33 = var_I[5 * N + i] + PSMO_GIF_EPS;
+        if (g_variant & PSMO_VAR_FMA_SOLVE) {
+            /* x*y - z*w -> fma(x, y, -(z*w)); s + x*y -> fma(x, y, s): the contraction GCC applies left to right */
+#define M2(x, y, z, w) fmaf((x), (y), -((z) * (w)))
+            float m00 = M2(a33, a22, a32, a23), m01 = M2(a33, a12, a32, a13), m02 = M2(a23, a12, a22, a13);
+            float DETf = fmaf(a31, m02, fmaf(-a21, m01, a11 * m00));
+            DETf = 1 / DETf;
+            a[0 * N + i] = DETf * fmaf(c2, M2(a32, a21, a31, a22), fmaf(c1, M2(a31, a23, a33, a21), c0 * m00));
+            a[1 * N + i] = DETf * fmaf(c2, M2(a31, a12, a32, a11), fmaf(c1, M2(a33, a11, a31, a13), c0 * M2(a32, a13, a33, a12)));
+            a[2 * N + i] = DETf * fmaf(c2, M2(a22, a11, a21, a12), fmaf(c1, M2(a21, a13, a23, a11), c0 * m02));
+#undef M2
+            continue;
+        }
         float DET = a11 * (a33 * a22 - a32 * a23) - a21 * (a33 * a12 - a32 * a13) +
                     a31 * (a23 * a12 - a22 * a13);
         DET = 1 / DET;

@@ -74,6 +74,12 @@ enum { PSMO_BOX_TREE = 0, PSMO_BOX_OCV = 1 };
 void psmo_set_box_order(int order);
 int psmo_get_box_order(void);
 
+/* Toolchain-dependent readings of two reference lines (see psm_oracle.c: myCostGrd2, guided_filter_ws).  0 = canon.
+ * Used by tests only, to bound how far the reference binary can be from the canonical arithmetic. */
+enum { PSMO_VAR_FABS_DOUBLE = 1, PSMO_VAR_FMA_SOLVE = 2 };
+void psmo_set_variant(int bits);
+int psmo_get_variant(void);
+
 /* src/CVF.cpp:44-70 CVF::preprocess.  rgb: 3 planes, mean: 3 planes, var: 6 planes
  * (order 00,01,02,11,12,22), each H*W floats, stored back to back. */
 void psmo_cvf_preprocess(const float *img, int H, int W, float *rgb, float *mean, float *var);

@@ -241,6 +241,27 @@ def pipeline_fgf(l_bgr, r_bgr, D, s=4, threads=8, want_volumes=False):
 
 
 BOX_TREE, BOX_OCV = 0, 1
+VAR_FABS_DOUBLE, VAR_FMA_SOLVE = 1, 2
+
+
+class variant:
+    """Context manager: evaluate the oracle under an alternative, toolchain-dependent READING of the reference
+    (VAR_FABS_DOUBLE: colour sum of myCostGrd in double; VAR_FMA_SOLVE: FMA-contracted 3x3 solve).  Never the canon."""
+
+    def __init__(self, bits):
+        self.bits = bits
+
+    def __enter__(self):
+        lib().psmo_get_variant.restype = C.c_int
+        self.prev = lib().psmo_get_variant()
+        lib().psmo_set_variant(self.bits)
+        return self
+
+    def __exit__(self, *a):
+        lib().psmo_set_variant(self.prev)
+        return False
+
+
 
 
 class box_order:

@@ -190,6 +190,18 @@ void k_cvf_pc(
     using L = PcLayout<MODE>;
     constexpr int PC_NA = L::NA, PC_NB = L::NB, PC_OUT_A = L::OUT_A, PC_OUT_B = L::OUT_B, PC_COLS = L::COLS;
     constexpr int PC_MCOLS = PC_NA * PC_OUT_A;   // model columns per workgroup (>= PC_COLS + 7)
+    // Select forms: the x 1/64 of the two box filters is not applied per window sum (a v_ldexp_f64 per channel and step).  The
+    // guided filter is homogeneous of degree one in (box(p), box(I p)) and in (box(a), box(b)), and a power-of-two scale commutes
+    // with every fp32 rounding as long as nothing under- or overflows: the producers hand over 64 x (a0, a1, a2, b), the consumers
+    // form 4096 x q and one fp32 multiply by 2^-12 (exact) restores q - bit-identical to the per-sum scaling while no intermediate
+    // of a voxel is subnormal or beyond 2^115 (costs are O(1); tests/test_gpu_parity.py::test_scaled_sums_domain).  The storing
+    // form (MODE 0) keeps the per-sum scaling, i.e. the oracle's arithmetic op for op.
+#ifndef PSM_PC_SCALED
+#define PSM_PC_SCALED 1
+#endif
+    constexpr bool SCALED = PSM_PC_SCALED && MODE != 0;
+    constexpr float QSCALE = SCALED ? 0x1p-12f : 1.0f;
+#define PSM_BOX(N) (SCALED ? (float)(N) : box_out(N))
     static_assert(PC_MCOLS >= PC_COLS + 7 && PC_OUT_A <= 57 && PC_OUT_B <= 57 && (MODE != 0 || (PC_COLS % 4) == 0), "bad producer/consumer layout");
     // Model rows live in a ring of PC_RING batches of four rows; consumers run two batches behind the
     // producers, so every model row the second box filter can ask for - including the REFLECT_101 rows at
@@ -338,7 +350,7 @@ void k_cvf_pc(
         double h2 = hsum8(__fmul_rn(gin[K & 1].y, p), i1, i2, i4);                                  \
         double h3 = hsum8(__fmul_rn(gin[K & 1].z, p), i1, i2, i4);                                  \
         double n0 = vstep<K>(t0, h0), n1 = vstep<K>(t1, h1), n2 = vstep<K>(t2, h2), n3 = vstep<K>(t3, h3); \
-        float4 r = solve_ab(box_out(n0), box_out(n1), box_out(n2), box_out(n3), o2[LEANA ? 0 : (K & 1)], o3[LEANA ? 0 : (K & 1)], o4[LEANA ? 0 : (K & 1)]); \
+        float4 r = solve_ab(PSM_BOX(n0), PSM_BOX(n1), PSM_BOX(n2), PSM_BOX(n3), o2[LEANA ? 0 : (K & 1)], o3[LEANA ? 0 : (K & 1)], o4[LEANA ? 0 : (K & 1)]); \
         if ((DST) != nullptr && mvalid) (DST)[K * PC_MCOLS] = r;                                    \
         __builtin_amdgcn_sched_barrier(0);                                                          \
     }
@@ -351,12 +363,23 @@ void k_cvf_pc(
             PSM_STEP_PA(0, 0, none) PSM_STEP_PA(1, 1, none) PSM_STEP_PA(2, 2, none) PSM_STEP_PA(3, 3, none)
             PSM_STEP_PA(0, 4, none) PSM_STEP_PA(1, 5, none) PSM_STEP_PA(2, 6, none) PSM_STEP_PA(3, 7, none)
         }
-        for (int b = 0; b < nbA; ++b) {
-            const int s0 = 8 + b * 4;
-            float4 *dst = &ring[b & (PC_RING - 1)][0][wave * PC_OUT_A + lane];
-            PSM_STEP_PA(0, s0, dst) PSM_STEP_PA(1, s0 + 1, dst) PSM_STEP_PA(2, s0 + 2, dst) PSM_STEP_PA(3, s0 + 3, dst)
-            PC_SYNC();
+#define PSM_BATCH_PA(B)                                                                            \
+        {                                                                                          \
+            const int s0 = 8 + (B) * 4;                                                            \
+            float4 *dst = &ring[(B) & (PC_RING - 1)][0][wave * PC_OUT_A + lane];                   \
+            PSM_STEP_PA(0, s0, dst) PSM_STEP_PA(1, s0 + 1, dst) PSM_STEP_PA(2, s0 + 2, dst) PSM_STEP_PA(3, s0 + 3, dst) \
+            PC_SYNC();                                                                             \
         }
+        // two batches per iteration: the s4 slots of the vertical trees change registers with every update, so only after eight
+        // steps is every value back in the register the loop header expects (one batch per iteration: 16 v_mov_b64 at the latch)
+#ifndef PSM_PC_UNROLL2
+#define PSM_PC_UNROLL2 1
+#endif
+        for (int b = 0; b < nbA; b += PSM_PC_UNROLL2 ? 2 : 1) {
+            PSM_BATCH_PA(b)
+            if (PSM_PC_UNROLL2 && __builtin_expect(b + 1 < nbA, 1)) PSM_BATCH_PA(b + 1)
+        }
+#undef PSM_BATCH_PA
         for (int b = nbA; b < iters; ++b) PC_SYNC();
 #undef PSM_STEP_PA
 #undef PSM_ISSUE_PA
@@ -475,8 +498,8 @@ void k_cvf_pc(
         }
         PC_SYNC();                               // iteration 0
         PC_SYNC();                               // iteration 1
-        for (int b = 2; b <= nbB + 1; ++b) {           // iteration b: consume feed batch c = b-2
-            const int c = b - 2;
+        // (two batches per loop iteration, as in the producer: no register moves of the s4 slots at the latch)
+        auto batch_b = [&](const int c) __attribute__((always_inline)) {   // consume feed batch c
             if (c >= 1) store_batch(c - 1);
             {
                 const int j0 = 4 * c;
@@ -491,13 +514,13 @@ void k_cvf_pc(
         double h2 = hsum8(a_cur.z, i1, i2, i4);                                                     \
         double h3 = hsum8(a_cur.w, i1, i2, i4);                                                     \
         double n0 = vstep<K>(t0, h0), n1 = vstep<K>(t1, h1), n2 = vstep<K>(t2, h2), n3 = vstep<K>(t3, h3); \
-        qv[K] = __fadd_rn(__fadd_rn(__fadd_rn(box_out(n3), __fmul_rn(box_out(n0), o1x[LEANG ? (K & 1) : K])),        \
-                                    __fmul_rn(box_out(n1), o1y[LEANG ? (K & 1) : K])), __fmul_rn(box_out(n2), o1z[LEANG ? (K & 1) : K])); \
+        qv[K] = __fadd_rn(__fadd_rn(__fadd_rn(PSM_BOX(n3), __fmul_rn(PSM_BOX(n0), o1x[LEANG ? (K & 1) : K])),        \
+                                    __fmul_rn(PSM_BOX(n1), o1y[LEANG ? (K & 1) : K])), __fmul_rn(PSM_BOX(n2), o1z[LEANG ? (K & 1) : K])); \
+        if (U8) {   /* q8 = sat_u8(rintf(q * 255)), NaN -> 0 (oracle: quant_u8); kept as a float: the selection is unchanged */ \
+            const float r_ = rintf(__fmul_rn(qv[K], 255.0f * QSCALE));   /* (255 * 2^-12 is exact: one rounding, as q * 255) */ \
+            qv[K] = !(r_ > 0.0f) ? 0.0f : (r_ > 255.0f ? 255.0f : r_);                              \
+        } else if (SCALED) qv[K] = __fmul_rn(qv[K], QSCALE);                                        \
         if (LEANS) {                                                                                \
-            if (U8) {                                                                               \
-                const float r_ = rintf(__fmul_rn(qv[K], 255.0f));                                   \
-                qv[K] = !(r_ > 0.0f) ? 0.0f : (r_ > 255.0f ? 255.0f : r_);                          \
-            }                                                                                       \
             const int j_ = j0 + K, yo_ = y0 + j_ - 7;                                               \
             float &kqK_ = K == 0 ? kq.x : (K == 1 ? kq.y : (K == 2 ? kq.z : kq.w));                 \
             const bool better_ = j_ >= 7 && yo_ < y1 && lane_out && dg != 0 && qv[K] < kqK_;        \
@@ -508,10 +531,6 @@ void k_cvf_pc(
         if (LEANG && !LEANB) PSM_ISSUE_PB(K & 1, j0 + K + 2)                                        \
         else if (LEANB) {                                                                           \
             PSM_ISSUE_PB(K & 1, j0 + K + 2)                                                         \
-            if (U8) {                                                                               \
-                const float r_ = rintf(__fmul_rn(qv[K], 255.0f));                                   \
-                qv[K] = !(r_ > 0.0f) ? 0.0f : (r_ > 255.0f ? 255.0f : r_);                          \
-            }                                                                                       \
             const int j_ = j0 + K, yo_ = y0 + j_ - 7;                                               \
             const long long key_ = pack_key_f32(qv[K], dg);                                         \
             if (j_ >= 7 && yo_ < y1 && lane_out && dg != 0 && qv[K] == qv[K] && key_ < kcur[K & 1]) \
@@ -532,13 +551,6 @@ void k_cvf_pc(
                 } else if constexpr (MODE == 2) {
                     // DispSel::CVSelect (src/DispSel.cpp:96-104) against the volume's shared key plane: strict '<' / lowest d on
                     // ties = signed minimum of pack_key_f32; d = 0 never a candidate; NaN never wins
-                    if (U8) {
-#pragma unroll
-                        for (int k = 0; k < 4; ++k) {
-                            const float r_ = rintf(__fmul_rn(qv[k], 255.0f));
-                            qv[k] = !(r_ > 0.0f) ? 0.0f : (r_ > 255.0f ? 255.0f : r_);
-                        }
-                    }
 #if PSM_KEY_NOATOMIC == 2   // experiment (invalid results): compute-only - the q values are summed into a register, one store per workgroup
                     acc_dbg += (qv[0] + qv[1]) + (qv[2] + qv[3]);
                     if (c == nbB - 1 && lane_out) keyp[(size_t)(y0 + lane % 4) * W + xb] = (long long)__float_as_int(acc_dbg);
@@ -564,13 +576,6 @@ void k_cvf_pc(
                 } else {
                     // DispSel::CVSelect (src/DispSel.cpp:96-104) over the slices of this chunk: strict '<', d = 0 never a
                     // candidate, NaN never wins.  Rows outside [y0, y1) and halo lanes keep (+inf, 0).
-                    if (U8) {   // q8 = sat_u8(rintf(q * 255)), NaN -> 0 (oracle: quant_u8); kept as a float: the selection below is unchanged
-#pragma unroll
-                        for (int k = 0; k < 4; ++k) {
-                            const float r_ = rintf(__fmul_rn(qv[k], 255.0f));
-                            qv[k] = !(r_ > 0.0f) ? 0.0f : (r_ > 255.0f ? 255.0f : r_);
-                        }
-                    }
                     float kn[4] = {kq.x, kq.y, kq.z, kq.w};
                     unsigned dn = kd4;
                     bool any = false;
@@ -595,6 +600,10 @@ void k_cvf_pc(
                 }
             }
             PC_SYNC();
+        };
+        for (int c = 0; c < nbB; c += PSM_PC_UNROLL2 ? 2 : 1) {
+            batch_b(c);
+            if (PSM_PC_UNROLL2 && __builtin_expect(c + 1 < nbB, 1)) batch_b(c + 1);
         }
         store_batch(nbB - 1);                          // iteration nbB+2
         PC_SYNC();
@@ -621,6 +630,7 @@ void k_cvf_pc(
             }
         }
     }
+#undef PSM_BOX
 #if PSM_PC_TIMING
     if (lane == 0 && MODE == 1) {
         atomicAdd(&g_pc_dbg[wave], q_work);
