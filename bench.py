@@ -6,15 +6,22 @@
 
 One "step" = one pass of the hot path over one synthetic stereo pair already resident in HBM:
 CostConst (gray/gradient + both cost volumes) -> CostFilter (guidance precompute + guided filter
-of both volumes) -> DispSel (WTA; for N > 1: the fused kernel's packed per-pixel minima over the local slices -> ONE RCCL
-all-reduce(MIN) per frame (or all-gather + device-side minimum) -> final maps).  Workload at N=1: BASELINE.json configs[3], 1920x1080, D=256,
-float32 - the configuration the metric is quoted on; for N > 1 the D slices of that same job are
-sharded over the ranks (total work fixed -> "scaling": "strong").
+of both volumes) -> DispSel (WTA).  Workload at N=1: BASELINE.json configs[3], 1920x1080, D=256, float32 - the
+configuration the metric is quoted on.  For N > 1 the same job is sharded over the ranks (total work fixed -> "scaling":
+"strong") and ONE invocation times both sharding axes:
+  value      - row stripes: rank g owns H/N output rows of both maps, all D slices; no minima leave the rank, the one
+               exchange per frame is an RCCL all-gather of the finished map rows (0.5 MB per rank at 1080p / 8)
+  alt_shard  - the configuration BASELINE configs[3] / the north star name literally: D/N slices per rank, one RCCL
+               all-gather of the packed per-pixel minima per frame (33 MB per rank), device-side minimum
+Both produce the same maps bit for bit (each record carries verified_vs_single_gpu and oracle_maps_equal); the row axis is
+the headline because it is the faster way to run the same job (no 33 MB collective, two-phase selection at full efficiency).
 
 Prints ONE JSON line (rank 0) with the contract fields plus
-  roofline     - dominant kernel: algorithmic HBM bytes per launch / its mean hipEvent duration
+  roofline     - dominant kernel (k_cvf_pc): algorithmic HBM bytes per launch / its mean duration over the launches OF THE
+                 TIMED REGION (time stamps the kernel takes itself, PSM_OPT_PROFILE 2 - no events, no separate pass)
   cpu_baseline - the CPU oracle (restatement of the reference pthreads path) timed on a bounded
-                 sample on this box's host cores (rank 0, N=1 only); a reported baseline.
+                 sample on this box's host cores (rank 0, N=1 only); a reported baseline
+  oracle_maps_equal - the maps the TIMED path left on the device == the oracle's maps of the same pair (whole D)
 """
 import argparse
 import json
@@ -37,10 +44,11 @@ CONFIGS = {
     "c1": (450, 375, 64, "synthetic 450x375 pair, D=64, 8-bit char mode (size of the shipped Cones pair, BASELINE configs[0])"),
     "c1x": (384, 288, 64, "synthetic 384x288 pair, D=64, 8-bit char mode (the size BASELINE configs[0] quotes)"),
 }
-# algorithmic bytes per voxel of the staged 8-bit pipeline: CVC 1 W; CVF stage A 1 R + 16 W, stage B 16 R + 1 W; WTA 1 R
-ALG_BYTES_U8 = {"cvf_fused": 34.0, "cvc": 1.0, "wta": 1.0, "pipeline": 36.0}
-# algorithmic HBM bytes per voxel (SURVEY.md 8d / DESIGN.md): stage A 4 R + 16 W, stage B 16 R + 4 W
-ALG_BYTES = {"cvf_fused": 40.0, "cvf_a": 20.0, "cvf_b": 20.0, "cvc": 4.0, "wta": 4.0, "box8": 8.0, "pipeline": 48.0}
+# algorithmic HBM bytes per voxel of the staged pipeline (SURVEY.md 8d / DESIGN.md): CVC 4 W; CVF stage A 4 R + 16 W, stage B
+# 16 R + 4 W; WTA 4 R.  8-bit mode: CVC 1 W; CVF 1 R + 16 W, 16 R + 1 W; WTA 1 R.
+ALG = {"f32": {"cvf_fused": 40.0, "cvf_a": 20.0, "cvc": 4.0, "wta": 4.0, "box8": 8.0, "pipeline": 48.0},
+       "u8": {"cvf_fused": 34.0, "cvf_a": 17.0, "cvc": 1.0, "wta": 1.0, "box8": 8.0, "pipeline": 36.0}}
+FORM_NAME = {0: "store", 1: "planes", 2: "keys"}
 
 
 def spawn_ranks(n):
@@ -58,7 +66,7 @@ def spawn_ranks(n):
     return subprocess.run(cmd, env=env).returncode
 
 
-def main():
+def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
@@ -66,50 +74,55 @@ def main():
     ap.add_argument("--config", default="c4", choices=sorted(CONFIGS))
     ap.add_argument("--dtype", default="", choices=["", "f32", "u8"], help="volume element type (default: f32, u8 for the c1 configs)")
     ap.add_argument("--seg-rows", type=int, default=-1, help="marching-kernel y segment (-1: library default)")
-    ap.add_argument("--waves", type=int, default=0, help="waves per workgroup (0: library default)")
     ap.add_argument("--variant", type=int, default=0)
-    ap.add_argument("--flags", type=int, default=-1, help="PSM_OPT_FLAGS tuning bits (-1: library default)")
+    ap.add_argument("--flags", type=int, default=-1, help="PSM_OPT_FLAGS bits (-1: library default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-oracle-check", action="store_true", help="N > 1: skip the oracle run that checks the maps (N = 1: it is the cpu_baseline run)")
     ap.add_argument("--cpu-sample-d", type=int, default=0,
                     help="disparities in the CPU-baseline sample (0 = auto: the whole D at 1080p and below (~10 s on 8 threads), "
                          "proportionally fewer for larger images)")
     ap.add_argument("--cpu-wide", action="store_true", help="also time the CPU baseline on min(64, host cores) threads (doubles its run time)")
     ap.add_argument("--force-dist", action="store_true", help="use the torch.distributed path even for N=1")
-    ap.add_argument("--exchange", default="allreduce", choices=["allreduce", "allgather", "none"],
-                    help="N>1 exchange step: one all_reduce(MIN) of the packed keys (default; ~2x33 MB per rank "
-                         "at 1080p whatever N) or one all_gather ((N-1)x33 MB per rank) + device-side minimum")
+    ap.add_argument("--exchange", default="", choices=["", "allreduce", "allgather", "none"],
+                    help="--shard disp, N>1: the one exchange step - all_gather of the packed keys ((N-1)x33 MB per rank at 1080p; "
+                         "the north star's wording, default of the alt_shard record) or one all_reduce(MIN) (~2x33 MB whatever N; "
+                         "default when --shard disp is the headline)")
     ap.add_argument("--shard", default="rows", choices=["rows", "disp"],
-                    help="N > 1: what a rank owns - 'rows': a stripe of H/N output rows of both volumes, all D slices (no minima "
-                         "exchanged, one all-gather of the finished map rows per frame); 'disp': D/N slices of both volumes, whole "
-                         "image (one collective on packed per-pixel minima per frame, --exchange)")
+                    help="N > 1: what a rank owns in the headline measurement - 'rows': a stripe of H/N output rows of both volumes, "
+                         "all D slices; 'disp': D/N slices of both volumes, whole image.  The other axis is timed as alt_shard")
+    ap.add_argument("--no-alt-shard", action="store_true", help="N > 1: do not time the other sharding axis")
     ap.add_argument("--lr-check", type=int, default=-1, choices=[-1, 0, 1],
                     help="PP left-right check on the GPU inside the step (BASELINE configs[4]); -1: on for config c5 only")
+    ap.add_argument("--pp", action="store_true", help="also time the post-processing stages (lrCheck, fillInv, wgtMedian: PP::processDM) "
+                                                      "on the finished maps and verify them against the oracle; never part of value")
+    ap.add_argument("--frame-loop", type=int, default=20, help="N=1: frames of the PCIe-inclusive frame loop (0: skip)")
     ap.add_argument("--box-bench", action="store_true", help="also time the plain box-filter pass")
     ap.add_argument("--fgf", type=int, default=0, choices=[0, 2, 4, 8],
                     help="diagnostic: aggregate with the Fast Guided Filter variant (CostFilter_FGF) at this subsample "
                          "rate instead of the full guided filter; not the north-star metric")
-    ap.add_argument("--no-overlap", action="store_true", help="(kept for old command lines; same as --no-frame-pipeline)")
     ap.add_argument("--no-frame-pipeline", action="store_true",
                     help="N>1: finish the exchange + merge of a frame inside its own step instead of one step later "
-                         "(default: a frame's all-reduce overlaps the next frame's filter; two key tensors)")
+                         "(default: a frame's collective overlaps the next frame's filter; two buffers)")
     ap.add_argument("--verify", action="store_true",
                     help="N=1: also compare the maps of the timed path with a fresh single-context run (always done for N>1)")
     ap.add_argument("--shard-sim", type=int, default=0,
-                    help="diagnostic: time only rank 0's disparity shard of a G-rank job on this GPU (no exchange); "
+                    help="diagnostic: time only rank 0's share of a G-rank job on this GPU (no exchange); "
                          "the JSON line is then NOT the headline metric")
-    args = ap.parse_args()
+    return ap.parse_args()
 
-    if args.no_overlap:
-        args.no_frame_pipeline = True
+
+def main():
+    args = parse_args()
     N = args.gpus
     if N < 1:
         raise SystemExit("bench.py: --gpus must be >= 1")
-    if args.shard == "disp" and N > CONFIGS[args.config][2]:
-        raise SystemExit(f"bench.py: --gpus {N} exceeds the {CONFIGS[args.config][2]} disparity slices of config {args.config} (one shard per rank)")
-    if args.shard == "rows" and (N > CONFIGS[args.config][1] or (N - 1) * -(-CONFIGS[args.config][1] // N) >= CONFIGS[args.config][1]):
+    Wc, Hc, Dc, _ = CONFIGS[args.config]
+    if args.shard == "disp" and N > Dc:
+        raise SystemExit(f"bench.py: --gpus {N} exceeds the {Dc} disparity slices of config {args.config} (one shard per rank)")
+    if args.shard == "rows" and (N > Hc or (N - 1) * -(-Hc // N) >= Hc):
         # (every rank decides this the same way, before any rendezvous: stripes of ceil(H / N) rows must leave the last rank some)
-        raise SystemExit(f"bench.py: --gpus {N}: stripes of {-(-CONFIGS[args.config][1] // N)} rows leave a rank without rows of the "
-                         f"{CONFIGS[args.config][1]}-row image of config {args.config} (one stripe per rank)")
+        raise SystemExit(f"bench.py: --gpus {N}: stripes of {-(-Hc // N)} rows leave a rank without rows of the "
+                         f"{Hc}-row image of config {args.config} (one stripe per rank)")
     if N > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
         # bare `python bench.py --gpus N`: become the launcher - one rank per GPU under torch.distributed.run on
         # 127.0.0.1 - and pass rank 0's single JSON line through
@@ -140,187 +153,249 @@ def main():
 
     import numpy as np
     import primestereomatch_amd as P
-    from primestereomatch_amd import capi, synth
+    from primestereomatch_amd import capi, stripes, synth
 
     W, H, D, desc = CONFIGS[args.config]
     dtype = args.dtype or ("u8" if args.config.startswith("c1") else "f32")
-    if dtype == "u8":
-        ALG_BYTES.update(ALG_BYTES_U8)
-        if not args.config.startswith("c1"):
-            desc = desc.replace("float32", "8-bit char mode")
-    rows_mode = args.shard == "rows" and not args.fgf and (use_dist or args.shard_sim > 1)
-    from primestereomatch_amd import stripes
-    parts = world if use_dist else max(args.shard_sim, 1)
-    rows_max, y0, y1 = H, 0, H
-    if rows_mode:
-        # stripes aligned at multiples of ceil(H / parts): the gathered tensor is the image
-        rows_max, y0, y1 = stripes.stripe_bounds(H, parts, rank if use_dist else 0)
-        if y1 <= y0:
-            raise SystemExit(f"bench.py: rank {rank} of {world} has no rows of the {H}-row image")
-        d0, d1 = 0, D
-    elif use_dist:
-        d0, d1 = D * rank // world, D * (rank + 1) // world
-    elif args.shard_sim > 1:
-        d0, d1 = 0, D // args.shard_sim
-    else:
-        d0, d1 = 0, D
+    alg = ALG[dtype]
+    if dtype == "u8" and not args.config.startswith("c1"):
+        desc = desc.replace("float32", "8-bit char mode")
     l, r, _ = synth.make_pair(W, H, D, seed=0)
-    de = P.DispEst(l, r, D, 8, True, device=local_rank, d_range=(d0, d1), dtype=dtype)
-    if args.seg_rows >= 0:
-        de.set_option(capi.PSM_OPT_SEG_ROWS, args.seg_rows)
-    if args.waves:
-        de.set_option(capi.PSM_OPT_WAVES, args.waves)
-    de.set_option(capi.PSM_OPT_KERNEL_VARIANT, args.variant)
-    if args.flags >= 0:
-        de.set_option(capi.PSM_OPT_FLAGS, args.flags)
-    de.set_option(capi.PSM_OPT_ASYNC, 1)
-    if rows_mode:
-        de.set_rows(y0, y1)
-
-    keys_local = keys_all = None
-    kbuf = []
-    pending = []                 # (work handles, key buffer) of the frame whose merge is still outstanding
-    frame = [0]
+    voxels_per_step = 2.0 * W * H * D           # both volumes, all ranks
+    # BASELINE configs[4]: "+ PP left-right check on-GPU" - lrCheck (src/PP.cpp:17-50) on the finished maps, part of the step
+    lrc = (args.lr_check == 1 or (args.lr_check < 0 and args.config == "c5")) and not (args.shard_sim > 1)
+    side_stream = None
     if use_dist:
-        HW2 = 2 * H * W
-        kbuf = [torch.empty(HW2, dtype=torch.int64, device="cuda") for _ in range(2)]
-        keys_local = kbuf[0]
-        keys_all = torch.empty(world * HW2 if args.exchange == "allgather" else 1, dtype=torch.int64, device="cuda")
-        if rows_mode:
-            # the maps of a frame are written by the library straight into one of two torch tensors (psm_set_map_buffer);
-            # the stripe rows go through one all_gather per frame: [world][2][rows_max][W] uint8 = the two whole maps
-            mbuf = [torch.zeros(HW2 + 4, dtype=torch.uint8, device="cuda") for _ in range(2)]
-            send = torch.zeros(2 * rows_max * W, dtype=torch.uint8, device="cuda")
-            recv = torch.zeros(world * 2 * rows_max * W, dtype=torch.uint8, device="cuda")
         # one non-default torch stream carries both our kernels and the RCCL collective, so the
         # exchange is ordered against the kernels without host synchronisation
         side_stream = torch.cuda.Stream()
         torch.cuda.set_stream(side_stream)
-        de.set_stream(side_stream.cuda_stream)
 
-    if args.fgf:
-        de.setSubsampleRate(args.fgf)
-
-    pipelined = use_dist and (args.exchange == "allreduce" or rows_mode) and not args.no_frame_pipeline and not args.fgf
-    # BASELINE configs[4]: "+ PP left-right check on-GPU" - lrCheck (src/PP.cpp:17-50) on the finished maps, part of the step
-    lrc = (args.lr_check == 1 or (args.lr_check < 0 and args.config == "c5")) and not (args.shard_sim > 1)
-
-    def finish_pending():
-        # exchange of an earlier frame -> final maps (the collective ran on RCCL's stream meanwhile)
-        while pending:
-            works, kb = pending.pop(0)
-            for w_ in works:
-                w_.wait()
-            if rows_mode:
-                stripes.assemble(recv, world, H, W, rows_max, kb)    # [rank][side][row][x] -> [side][y][x]
-                de.set_map_buffer(kb.data_ptr(), whole=True)
-            else:
-                de.DispSelect_merge(kb.data_ptr(), 1, download=False)
+    def single_gpu_maps():
+        """The same pair through a fresh unsharded context on this GPU: what every sharded run must reproduce bit for bit."""
+        with P.DispEst(l, r, D, 8, True, device=local_rank, dtype=dtype) as ref:
+            if args.fgf:
+                ref.setSubsampleRate(args.fgf)
+            ref.CostConst_GPU()
+            ref.CostFilter_FGF_GPU() if args.fgf else ref.CostFilter_GPU()
+            ref.DispSelect_GPU()
+            out = [ref.lDisMap.copy(), ref.rDisMap.copy()]
             if lrc:
-                de.LRCheck_device()
+                ref.LRCheck_GPU()
+                out += [ref.lValid.copy(), ref.rValid.copy()]
+        return out
 
-    def stripe_exchange(mb, async_op):
-        stripes.pack_stripe(mb, y0, y1, send, H, W, rows_max)
-        return dist.all_gather_into_tensor(recv, send, async_op=async_op)      # the one exchange step (RCCL)
-
-    def step():
-        de.CostConst_GPU()
+    def measure(shard, exchange):
+        """One timed measurement of the step under a sharding axis; returns the record (with the live context in it)."""
+        rows_mode = shard == "rows" and not args.fgf and (use_dist or args.shard_sim > 1)
+        parts = world if use_dist else max(args.shard_sim, 1)
+        rows_max, y0, y1 = H, 0, H
+        if rows_mode:
+            # stripes aligned at multiples of ceil(H / parts): the gathered tensor is the image
+            rows_max, y0, y1 = stripes.stripe_bounds(H, parts, rank if use_dist else 0)
+            if y1 <= y0:
+                raise SystemExit(f"bench.py: rank {rank} of {world} has no rows of the {H}-row image")
+            d0, d1 = 0, D
+        elif use_dist:
+            d0, d1 = D * rank // world, D * (rank + 1) // world
+        elif args.shard_sim > 1:
+            d0, d1 = 0, D // args.shard_sim
+        else:
+            d0, d1 = 0, D
+        de = P.DispEst(l, r, D, 8, True, device=local_rank, d_range=(d0, d1), dtype=dtype)
+        if args.seg_rows >= 0:
+            de.set_option(capi.PSM_OPT_SEG_ROWS, args.seg_rows)
+        de.set_option(capi.PSM_OPT_KERNEL_VARIANT, args.variant)
+        if args.flags >= 0:
+            de.set_option(capi.PSM_OPT_FLAGS, args.flags)
+        de.set_option(capi.PSM_OPT_ASYNC, 1)
+        if rows_mode:
+            de.set_rows(y0, y1)
         if args.fgf:
-            de.CostFilter_FGF_GPU()
+            de.setSubsampleRate(args.fgf)
+        keys_local = keys_all = None
+        kbuf = []
+        pending = []                 # (work handles, buffer) of the frame whose merge is still outstanding
+        frame = [0]
+        if use_dist:
+            HW2 = 2 * H * W
+            kbuf = [torch.empty(HW2, dtype=torch.int64, device="cuda") for _ in range(2)]
+            keys_local = kbuf[0]
+            keys_all = torch.empty(world * HW2 if exchange == "allgather" else 1, dtype=torch.int64, device="cuda")
+            if rows_mode:
+                # the maps of a frame are written by the library straight into one of two torch tensors (psm_set_map_buffer);
+                # the stripe rows go through one all_gather per frame: [world][2][rows_max][W] uint8 = the two whole maps
+                mbuf = [torch.zeros(HW2 + 4, dtype=torch.uint8, device="cuda") for _ in range(2)]
+                send = torch.zeros(2 * rows_max * W, dtype=torch.uint8, device="cuda")
+                recv = torch.zeros(world * 2 * rows_max * W, dtype=torch.uint8, device="cuda")
+            de.set_stream(side_stream.cuda_stream)
+        pipelined = use_dist and (exchange == "allreduce" or rows_mode) and not args.no_frame_pipeline and not args.fgf
+
+        def finish_pending():
+            # exchange of an earlier frame -> final maps (the collective ran on RCCL's stream meanwhile)
+            while pending:
+                works, kb = pending.pop(0)
+                for w_ in works:
+                    w_.wait()
+                if rows_mode:
+                    stripes.assemble(recv, world, H, W, rows_max, kb)    # [rank][side][row][x] -> [side][y][x]
+                    de.set_map_buffer(kb.data_ptr(), whole=True)
+                else:
+                    de.DispSelect_merge(kb.data_ptr(), 1, download=False)
+                if lrc:
+                    de.LRCheck_device()
+
+        def stripe_exchange(mb, async_op):
+            stripes.pack_stripe(mb, y0, y1, send, H, W, rows_max)
+            return dist.all_gather_into_tensor(recv, send, async_op=async_op)      # the one exchange step (RCCL)
+
+        def step():
+            de.CostConst_GPU()
+            if args.fgf:
+                de.CostFilter_FGF_GPU()
+                if use_dist:
+                    de.DispSelect_partial(keys_local.data_ptr())
+                    dist.all_reduce(keys_local, op=dist.ReduceOp.MIN)
+                    de.DispSelect_merge(keys_local.data_ptr(), 1, download=False)
+                elif args.shard_sim > 1:
+                    de.DispSelect_partial()
+                else:
+                    de.DispSelect_device()
+                return
+            if rows_mode and use_dist:
+                # Row stripes: nothing of the cost volumes or their minima leaves the rank; the finished rows of both maps are
+                # gathered - asynchronously, behind the next frame's filter when pipelined (maps alternate between two tensors).
+                mb = mbuf[frame[0] & 1]
+                frame[0] += 1
+                de.set_map_buffer(mb.data_ptr())
+                de.CostFilter_GPU()
+                de.DispSelect_device()
+                finish_pending()
+                if pipelined:
+                    pending.append(((stripe_exchange(mb, True),), mb))
+                else:
+                    stripe_exchange(mb, False)
+                    pending.append(((), mb))
+                    finish_pending()
+                return
+            if pipelined:
+                # Frame pipeline, ONE collective per frame: the fused kernel leaves the packed minima of both volumes directly
+                # in this frame's key tensor; the all-reduce(MIN) over the ranks is asynchronous and has the whole next
+                # frame's filter to complete - its merge is issued after that filter, so no kernel of ours ever waits for a
+                # collective that is still running.  Keys alternate between two tensors.
+                kb = kbuf[frame[0] & 1]
+                frame[0] += 1
+                de.set_key_buffer(kb.data_ptr())
+                de.CostFilter_GPU()
+                finish_pending()
+                w_ = dist.all_reduce(kb, op=dist.ReduceOp.MIN, async_op=True)
+                pending.append(((w_,), kb))
+                return
             if use_dist:
-                de.DispSelect_partial(keys_local.data_ptr())
-                dist.all_reduce(keys_local, op=dist.ReduceOp.MIN)
-                de.DispSelect_merge(keys_local.data_ptr(), 1, download=False)
-            elif args.shard_sim > 1:
+                de.set_key_buffer(keys_local.data_ptr())
+            de.CostFilter_GPU()
+            if use_dist:
+                if exchange == "none":       # diagnostic only: cost of the torch collective call itself
+                    de.DispSelect_merge(keys_local.data_ptr(), 1, download=False)
+                elif exchange == "allreduce":
+                    dist.all_reduce(keys_local, op=dist.ReduceOp.MIN)     # the one exchange step (RCCL)
+                    de.DispSelect_merge(keys_local.data_ptr(), 1, download=False)
+                else:
+                    dist.all_gather_into_tensor(keys_all, keys_local)     # the one exchange step (RCCL)
+                    de.DispSelect_merge(keys_all.data_ptr(), world, download=False)
+            elif args.shard_sim > 1 and not rows_mode:
                 de.DispSelect_partial()
             else:
                 de.DispSelect_device()
-            return
-        if rows_mode and use_dist:
-            # Row stripes: nothing of the cost volumes or their minima leaves the rank; the finished rows of both maps are
-            # gathered - asynchronously, behind the next frame's filter when pipelined (maps alternate between two tensors).
-            mb = mbuf[frame[0] & 1]
-            frame[0] += 1
-            de.set_map_buffer(mb.data_ptr())
-            de.CostFilter_GPU()
-            de.DispSelect_device()
+            if lrc and not (use_dist and exchange == "none"):
+                de.LRCheck_device()
+
+        def sync():
             finish_pending()
-            if pipelined:
-                pending.append(((stripe_exchange(mb, True),), mb))
-            else:
-                stripe_exchange(mb, False)
-                pending.append(((), mb))
-                finish_pending()
-            return
-        if pipelined:
-            # Frame pipeline, ONE collective per frame: the fused kernel leaves the packed minima of both volumes directly
-            # in this frame's key tensor; the all-reduce(MIN) over the ranks is asynchronous and has the whole next
-            # frame's filter to complete - its merge is issued after that filter, so no kernel of ours ever waits for a
-            # collective that is still running.  Keys alternate between two tensors.
-            kb = kbuf[frame[0] & 1]
-            frame[0] += 1
-            de.set_key_buffer(kb.data_ptr())
-            de.CostFilter_GPU()
-            finish_pending()
-            w_ = dist.all_reduce(kb, op=dist.ReduceOp.MIN, async_op=True)
-            pending.append(((w_,), kb))
-            return
-        if use_dist:
-            de.set_key_buffer(keys_local.data_ptr())
-        de.CostFilter_GPU()
-        if use_dist:
-            if args.exchange == "none":       # diagnostic only: cost of the torch collective call itself
-                de.DispSelect_merge(keys_local.data_ptr(), 1, download=False)
-            elif args.exchange == "allreduce":
-                dist.all_reduce(keys_local, op=dist.ReduceOp.MIN)     # the one exchange step (RCCL)
-                de.DispSelect_merge(keys_local.data_ptr(), 1, download=False)
-            else:
-                dist.all_gather_into_tensor(keys_all, keys_local)     # the one exchange step (RCCL)
-                de.DispSelect_merge(keys_all.data_ptr(), world, download=False)
-        elif args.shard_sim > 1 and not rows_mode:
-            de.DispSelect_partial()
-        else:
-            de.DispSelect_device()
-        if lrc and not (use_dist and args.exchange == "none"):
-            de.LRCheck_device()
+            if use_dist:
+                torch.cuda.synchronize()
+            de.synchronize()
 
-    def sync():
-        finish_pending()
-        if use_dist:
-            torch.cuda.synchronize()
-        de.synchronize()
+        def barrier():
+            if use_dist:
+                dist.barrier()
 
-    def barrier():
-        if use_dist:
-            dist.barrier()
-
-    for _ in range(args.warmup):
-        step()
-    sync(); barrier(); sync()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    sync(); barrier(); sync()
-    elapsed = time.perf_counter() - t0
-    if use_dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    ms_per_step = 1e3 * elapsed / args.steps
-    voxels_per_step = 2.0 * W * H * D           # both volumes, all ranks
-    value = voxels_per_step / (elapsed / args.steps)
-
-    # ---- per-step times (SURVEY.md 8d asks for the median): each step bracketed by its own synchronisation; the
-    # frame-pipelined N>1 path finishes a frame's exchange one step later, so its steps are only meaningful in bulk ----
-    step_ms = []
-    for _ in range(max(3, min(args.steps, 20))):
+        for _ in range(args.warmup):
+            step()
+        # the fused filter kernel stamps its own start / end from here on: two atomics per workgroup, no events between the
+        # kernels - the launches of the timed region itself are what roofline reports
+        de.set_option(capi.PSM_OPT_PROFILE, 2)
         sync()
-        ts = time.perf_counter()
-        step()
-        sync()
-        step_ms.append(1e3 * (time.perf_counter() - ts))
-    step_ms.sort()
-    median_ms = step_ms[len(step_ms) // 2]
+        de.filter_launch_times()
+        sync(); barrier(); sync()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        sync(); barrier(); sync()
+        elapsed = time.perf_counter() - t0
+        launch_times = de.filter_launch_times()
+        de.set_option(capi.PSM_OPT_PROFILE, 0)
+        if use_dist:
+            t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        rec = {"shard": shard if (use_dist or args.shard_sim > 1) else None,
+               "exchange": (("all_gather of map rows" if rows_mode else exchange) if use_dist else None),
+               "ms_per_step": 1e3 * elapsed / args.steps, "value": voxels_per_step / (elapsed / args.steps)}
+        # ---- per-step times (SURVEY.md 8d asks for the median): each step bracketed by its own synchronisation; the
+        # frame-pipelined N>1 path finishes a frame's exchange one step later, so its steps are only meaningful in bulk ----
+        step_ms = []
+        for _ in range(max(3, min(args.steps, 20))):
+            sync()
+            ts = time.perf_counter()
+            step()
+            sync()
+            step_ms.append(1e3 * (time.perf_counter() - ts))
+        step_ms.sort()
+        rec["median_ms_per_step"] = round(step_ms[len(step_ms) // 2], 4)
+        # ---- the launches of the fused kernel inside the timed region, by form ----
+        by_form = {}
+        for ms, f in launch_times:
+            by_form.setdefault(f, []).append(ms)
+        rec["filter_launches"] = {FORM_NAME.get(f, str(f)): {"avg_ms": round(sum(v) / len(v), 4), "min_ms": round(min(v), 4),
+                                                             "max_ms": round(max(v), 4), "per_step": len(v) / args.steps}
+                                  for f, v in sorted(by_form.items())}
+        rec["filter_ms_per_step"] = sum(ms for ms, _ in launch_times) / args.steps if launch_times else None
+        rec["geometry"] = {"rows": [y0, y1], "slices": [d0, d1], "rows_max": rows_max, "parts": parts, "rows_mode": rows_mode}
+        rec["sync"], rec["step"], rec["de"] = sync, step, de
+        return rec
+
+    def check_maps(rec, ref_maps, oracle_maps):
+        """The maps the timed path left on the device against the one-GPU run and against the oracle (rank 0)."""
+        de = rec["de"]
+        got = [m.copy() for m in de.download_maps()]
+        if lrc:
+            got += [m.copy() for m in de.download_valid()]
+        out = {}
+        if ref_maps is not None:
+            out["verified_vs_single_gpu"] = bool(all(np.array_equal(a, b) for a, b in zip(ref_maps, got)))
+            if not out["verified_vs_single_gpu"]:
+                print("bench.py: MAPS OF THE TIMED PATH DIFFER FROM THE ONE-GPU RUN", file=sys.stderr)
+        if oracle_maps is not None:
+            nl, nr = int(np.count_nonzero(got[0] != oracle_maps[0])), int(np.count_nonzero(got[1] != oracle_maps[1]))
+            out["oracle_maps_equal"] = nl == 0 and nr == 0
+            out["oracle_map_mismatches"] = [nl, nr]
+            if nl or nr:
+                print(f"bench.py: MAPS OF THE TIMED PATH DIFFER FROM THE ORACLE'S ({nl} + {nr} pixels)", file=sys.stderr)
+        return out
+
+    # ================= headline measurement =================
+    exchange = args.exchange or ("allreduce" if args.shard == "disp" else "allgather")
+    head = measure(args.shard, exchange)
+    de, sync, step = head["de"], head["sync"], head["step"]
+    geo = head["geometry"]
+    (y0, y1), (d0, d1), rows_mode = geo["rows"], geo["slices"], geo["rows_mode"]
+    ms_per_step, value = head["ms_per_step"], head["value"]
+
+    # ---- the maps the timed region left on the device (before anything else runs on this context) ----
+    timed_maps = None
+    if rank == 0 and args.shard_sim <= 1:
+        timed_maps = [m.copy() for m in de.download_maps()]
 
     # ---- PCIe legs the reference's stage timers include (src/StereoMatch.cpp:227-237), never part of `value` ----
     pcie = None
@@ -336,8 +411,43 @@ def main():
         d2h = 1e3 * (time.perf_counter() - ts)
         pcie = {"h2d_ms": round(h2d, 3), "d2h_ms": round(d2h, 3), "h2d_bytes": int(l.nbytes + r.nbytes), "d2h_bytes": 2 * W * H,
                 "note": "u8 pair in, two u8 maps out; excluded from value"}
+        if not use_dist and args.frame_loop > 0 and not args.fgf:
+            # the reference's use is a frame loop (src/main.cpp:64-73) whose stage timers include the copies: pair i+1
+            # travels (psm_upload_pair_async) and the maps of frame i-1 return (psm_download_maps_async) while frame i computes
+            nf = args.frame_loop
 
-    # ---- per-kernel device time (hipEvents on the launch stream), separate pass -----------
+            def frame(i, last):
+                de.CostConst_GPU()                     # adopts the pair staged during the previous frame
+                if not last:
+                    de.setInputImages_async(l, r)      # next frame's pair: staged + H2D on the copy stream
+                de.CostFilter_GPU()
+                de.DispSelect_device()
+                if lrc:
+                    de.LRCheck_device()
+                if i > 0:
+                    de.download_maps_wait()            # the previous frame's maps have arrived
+                de.download_maps_async()
+
+            de.setInputImages(l, r)
+            for i in range(3):
+                frame(i, False)
+            de.download_maps_wait(); sync()
+            de.CostConst_GPU(); sync()                 # (consume the staged pair: the timed loop starts with a resident one)
+            ts = time.perf_counter()
+            for i in range(nf):
+                frame(i, i + 1 == nf)
+            lm, rm = (m.copy() for m in de.download_maps_wait())
+            sync()
+            loop_ms = 1e3 * (time.perf_counter() - ts) / nf
+            pcie["frame_loop"] = {"frames": nf, "ms_per_frame": round(loop_ms, 4), "over_step_ms": round(loop_ms - ms_per_step, 4),
+                                  "maps_equal_timed_path": bool(np.array_equal(lm, timed_maps[0]) and np.array_equal(rm, timed_maps[1])),
+                                  "note": "H2D of every frame's pair + D2H of every frame's maps inside the loop, overlapped with the "
+                                          "kernels (psm_upload_pair_async / psm_download_maps_async); unpipelined it would be "
+                                          f"{ms_per_step + h2d + d2h:.3f} ms"}
+            step(); sync()
+
+    # ---- per-kernel device time of the OTHER kernels (hipEvents on the launch stream), separate pass: it perturbs the step
+    # by a few %, so the fused filter's times are NOT taken from it (filter_launches are the timed region's own) ----
     de.set_option(capi.PSM_OPT_PROFILE, 1)
     de.reset_kernel_times()
     prof_steps = max(2, min(args.steps, 5))
@@ -351,77 +461,154 @@ def main():
     for k, nm in names.items():
         tot, n = de.kernel_time_ms(k)
         if n:
-            kern[nm] = {"avg_ms": tot / n, "launches_per_step": n / prof_steps}
+            kern[nm] = {"avg_ms": tot / n, "launches_per_step": n / prof_steps, "source": "hipEvent pass (separate; perturbs the step)"}
     de.set_option(capi.PSM_OPT_PROFILE, 0)
-    # voxels per launch of the filter kernel = the step's 2*W*H*Dloc over its launches per step: 1 (both volumes in one
-    # launch), 2 (one launch per volume - or, from 112 local slices up, the two phases of the select form: every 5th slice
-    # of both volumes through the minima planes, then the other slices of both volumes against the key plane; the two
-    # are instantiations of the same kernel, so avg_launch_ms is their mean and alg bytes / launch the mean as well)
-    lps = max(1, round(kern.get("cvf_fused", {}).get("launches_per_step", 2)))   # (other filter forms: one side per launch)
-    vox_per_launch = 2.0 * W * (y1 - y0) * (d1 - d0) / lps                        # (this rank's rows and slices)
-    if args.fgf:   # per launch pair (setup + model + smooth + apply of one side): cost read at 1/s^2, model planes, q write
-        ALG_BYTES["cvf_fgf"] = 4.0 + 68.0 / (args.fgf * args.fgf)
-    # the default fused kernel also builds the costs and runs the WTA over its slices ("select" mode): it is credited
-    # with the whole staged pipeline's algorithmic bytes (CVC 4 + CVF 40 + WTA 4); --flags 8192 is the storing form (CVF only)
-    select_mode = not args.fgf and args.variant == 0 and not (max(args.flags, 0) & (16 | 512 | 8192))
+    fl = head["filter_launches"]
+    if fl and not args.fgf:
+        # the dominant kernel's entry comes from the timed region: mean over all its launches (planes and key phase)
+        n_l = sum(v["per_step"] for v in fl.values())
+        kern["cvf_fused"] = {"avg_ms": head["filter_ms_per_step"] / n_l, "launches_per_step": n_l,
+                             "source": "time stamps taken by the kernel inside the timed region (PSM_OPT_PROFILE 2)", "by_form": fl}
+    other_ms = sum(v["avg_ms"] * v["launches_per_step"] for nm, v in kern.items() if nm != "cvf_fused")
+    kernels_sum = (head["filter_ms_per_step"] or 0.0) + other_ms
+    # select form: the fused kernel also builds the costs and runs the WTA over its slices - it is credited with the whole
+    # staged pipeline's algorithmic bytes (CVC + CVF + WTA); PSM_FLAG_STORE_FILTERED is the storing form (CVF only)
+    fl_bits = max(args.flags, 0)
+    select_mode = not args.fgf and args.variant == 0 and not (fl_bits & capi.PSM_FLAG_STORE_FILTERED)
+    algb = dict(alg)
     if select_mode:
-        ALG_BYTES["cvf_fused"] = ALG_BYTES["pipeline"]
-    fl = max(args.flags, 0)
-    two_phase = select_mode and not (fl & (2097152 | 524288 | 262144 | 65536 | 16384)) and ((d1 - d0) >= 112 or (fl & 1048576))
-    dom = max(("cvf_fgf",) if args.fgf else ("cvf_fused", "cvf_a", "cvf_b"), key=lambda k: kern.get(k, {"avg_ms": 0})["avg_ms"])
+        algb["cvf_fused"] = alg["pipeline"]
+    if args.fgf:   # per launch pair (setup + model + smooth + apply of one side): cost read at 1/s^2, model planes, q write
+        algb["cvf_fgf"] = 4.0 + 68.0 / (args.fgf * args.fgf)
+    dom = max(("cvf_fgf",) if args.fgf else ("cvf_fused", "cvf_a"), key=lambda k: kern.get(k, {"avg_ms": 0})["avg_ms"])
+    lps = max(1, round(kern[dom]["launches_per_step"]))
+    vox_per_launch = 2.0 * W * (y1 - y0) * (d1 - d0) / lps                        # (this rank's rows and slices)
     dom_ms = kern[dom]["avg_ms"]
-    achieved = ALG_BYTES[dom] * vox_per_launch / (dom_ms * 1e-3) / 1e9
+    achieved = algb[dom] * vox_per_launch / (dom_ms * 1e-3) / 1e9
+    two_phase = select_mode and "keys" in fl and "planes" in fl
     roofline = {"bound": "hbm", "kernel": ("k_cvf_pc (select mode: CVC+CVF+WTA fused" + (", two phases = two launches per step)" if two_phase else ")"))
                 if (select_mode and dom == "cvf_fused") else "k_" + dom,
-                "alg_bytes_per_voxel": ALG_BYTES[dom], "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+                "alg_bytes_per_voxel": algb[dom], "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
-                "alg_bytes_per_launch": ALG_BYTES[dom] * vox_per_launch, "avg_launch_ms": round(dom_ms, 4),
-                "note": "achieved/frac credit the fused kernel with the staged pipeline's algorithmic bytes (SURVEY.md 8d); "
-                        "its physical HBM rate is traffic_GBs - the kernel is VALU-issue bound, not HBM bound",
-                "pipeline_alg_GBs": round(ALG_BYTES["pipeline"] * value / 1e9, 1),
-                "pipeline_frac": round(ALG_BYTES["pipeline"] * value / 1e9 / HBM_PEAK_GBS, 4)}
+                "alg_bytes_per_launch": algb[dom] * vox_per_launch, "avg_launch_ms": round(dom_ms, 4),
+                "launch_time_source": kern[dom]["source"],
+                "note": "achieved / frac credit the fused kernel with the staged pipeline's ALGORITHMIC bytes (SURVEY.md 8d); they are "
+                        "an algorithmic-equivalent rate, not bandwidth utilisation: the kernel's physical HBM rate is traffic_GBs "
+                        "(traffic_frac of peak) and what bounds it is VALU issue (valu)",
+                "pipeline_alg_GBs": round(alg["pipeline"] * value / 1e9, 1),
+                "pipeline_frac": round(alg["pipeline"] * value / 1e9 / HBM_PEAK_GBS, 4)}
     traffic_file = os.path.join(ROOT, "profiles", "traffic.json")
-    if os.path.exists(traffic_file):
+    if os.path.exists(traffic_file) and world == 1 and not args.shard_sim and select_mode:
         try:
             tr = json.load(open(traffic_file))
-            key = f"{args.config}:k_{dom}"
-            if key in tr and world == 1:
+            key = f"{args.config}:{dtype}:k_{dom}"
+            if key in tr:
                 roofline["traffic"] = tr[key]    # HBM bytes per launch from rocprofv3 PMC passes (not measured in this run)
-                roofline["traffic_source"] = tr.get("_source", "profiles/traffic.json (rocprofv3 --pmc passes of scripts/gpu_run.sh)")
+                roofline["traffic_source"] = tr.get("_source", "profiles/traffic.json")
+                roofline["traffic_session"] = tr.get("_session")      # box / date of the PMC session the figure comes from
                 roofline["traffic_GBs"] = round(tr[key] / (dom_ms * 1e-3) / 1e9, 1)   # physical HBM rate of the kernel
-                vi = tr.get(key + "_valu_insts")
-                if vi:
-                    # what bounds it: VALU issue.  256 CUs x 4 SIMDs, one wave-instruction per 4 cycles and SIMD, 2.4 GHz peak
-                    # engine clock (MI355X_MICROARCH.md) -> fraction of the issue slots the launch filled
-                    roofline["valu"] = {"wave_insts_per_launch": vi, "issue_slot_frac_at_2.4GHz": round(vi * 4.0 / (1024 * 2.4e9 * dom_ms * 1e-3), 4),
-                                        "source": "SQ_INSTS_VALU, " + roofline["traffic_source"].replace("{rd,wr}", "sq")}
+                roofline["traffic_frac"] = round(tr[key] / (dom_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+                vi, s4 = tr.get(key + "_valu_insts"), tr.get(key + "_four_cycle_share")
+                if vi and s4:
+                    # What bounds the kernel.  Wave-instructions per launch (SQ_INSTS_VALU) split into the part's two VALU rate
+                    # classes by the static instruction mix of the kernel's loop bodies (scripts/isa_mix.py): fp64 adds, fp64<->fp32
+                    # conversions and DPP moves take 4 cycles per wave64, plain fp32 / integer ops 2; sustained issue rates
+                    # measured on this part with the whole chip busy (scripts/exp/rate.hip): 0.50 G/s and 0.86 G/s per SIMD.
+                    simds = 1024
+                    bound_ms = 1e3 * vi * (s4 / 0.50e9 + (1.0 - s4) / 0.86e9) / simds
+                    roofline["valu"] = {"wave_insts_per_launch": vi, "four_cycle_share": s4,
+                                        "bound_ms_at_measured_issue_rates": round(bound_ms, 4),
+                                        "frac_of_valu_bound": round(bound_ms / dom_ms, 4),
+                                        "source": "SQ_INSTS_VALU (rocprofv3 PMC pass, " + str(tr.get("_session")) + "), mix from scripts/isa_mix.py"}
         except Exception:
             pass
     for nm, v in kern.items():
-        if nm in ALG_BYTES:
-            v["alg_GBs"] = round(ALG_BYTES[nm] * vox_per_launch / (v["avg_ms"] * 1e-3) / 1e9, 1)
+        if nm in algb:
+            v["alg_GBs"] = round(algb[nm] * vox_per_launch / (v["avg_ms"] * 1e-3) / 1e9, 1)
         v["avg_ms"] = round(v["avg_ms"], 4)
 
-    # ---- result check (outside the timed region): the maps the timed path left on the device ------------------
-    # against an unsharded single-context run of the same pair on this GPU.  With N > 1 this covers the RCCL
-    # exchange itself: rank 0's merged maps must equal the one-GPU maps bit for bit.
-    verified = None
-    if rank == 0 and args.shard_sim <= 1 and (use_dist or args.verify):
-        got_l, got_r = (m.copy() for m in de.download_maps())
+    # ---- CPU baseline: the oracle, driven like the reference pthreads path; its maps also check the timed path's ----
+    cpu = None
+    oracle_maps = None
+    O = None
+    want_oracle = rank == 0 and args.shard_sim <= 1 and not args.fgf and \
+        ((world == 1 and not args.no_cpu_baseline) or (world > 1 and not args.no_oracle_check))
+    if want_oracle:
+        from oracle import psm_oracle_py as O   # checker / baseline only - never on the GPU path
+        cores = os.cpu_count() or 1
+        threads = min(8, cores)                 # MAX_CPU_THREADS (include/ComFunc.h:52)
+        sd = args.cpu_sample_d if args.cpu_sample_d > 0 else int(256.0 * (1920 * 1080) / (W * H))
+        sd = max(2, min(sd, D))
+        if world > 1:
+            sd, threads = D, min(32, cores)     # N > 1: a checker run only (no cpu_baseline in the line)
+        tcpu = time.perf_counter()
+        res = (O.pipeline_u8 if dtype == "u8" else O.pipeline_f32)(l, r, sd, threads=threads)
+        tcpu = time.perf_counter() - tcpu
+        if sd == D:
+            oracle_maps = [res["ldisp"], res["rdisp"]]
+        if world == 1:
+            stage_s = (res["cvc_ms"] + res["cvf_ms"] + res["dispsel_ms"]) * 1e-3
+            cpu = {"value": round(2.0 * W * H * sd / stage_s, 1), "unit": "voxels/s", "cores": threads,
+                   "kind": "port", "host_cores": cores,
+                   "sample": f"same {W}x{H} pair, first {sd} of {D} disparities (2*W*H*{sd} voxels), "
+                             f"{threads} pthreads in the reference's per-d block pattern; "
+                             f"cvc {res['cvc_ms']:.0f} ms, cvf {res['cvf_ms']:.0f} ms, dispsel {res['dispsel_ms']:.0f} ms "
+                             f"(wall {tcpu:.1f} s)"}
+            # the same restatement on more host cores (SURVEY.md 8d asks for 8 threads and for the box's core count):
+            # context only, the contract's cpu_baseline is the 8-thread figure above
+            wide = min(64, cores)
+            if args.cpu_wide and wide > threads:
+                resw = (O.pipeline_u8 if dtype == "u8" else O.pipeline_f32)(l, r, sd, threads=wide)
+                sw = (resw["cvc_ms"] + resw["cvf_ms"] + resw["dispsel_ms"]) * 1e-3
+                cpu["wide"] = {"value": round(2.0 * W * H * sd / sw, 1), "cores": wide}
+
+    # ---- result checks (outside the timed region): the maps the timed path left on the device against an unsharded
+    # single-context run of the same pair on this GPU (with N > 1 this covers the RCCL exchange itself) and the oracle ----
+    checks = {}
+    ref_maps = None
+    if rank == 0 and args.shard_sim <= 1:
         de.set_option(capi.PSM_OPT_ASYNC, 0)
-        with P.DispEst(l, r, D, 8, True, device=local_rank, dtype=dtype) as ref:
-            if args.fgf:
-                ref.setSubsampleRate(args.fgf)
-            ref.CostConst_GPU()
-            ref.CostFilter_FGF_GPU() if args.fgf else ref.CostFilter_GPU()
-            ref.DispSelect_GPU()
-            verified = bool(np.array_equal(ref.lDisMap, got_l) and np.array_equal(ref.rDisMap, got_r))
-            if lrc:      # the validity masks of the timed path against those of the one-GPU run
-                got_lv, got_rv = (m.copy() for m in de.download_valid())
-                ref.LRCheck_GPU()
-                verified = verified and bool(np.array_equal(ref.lValid, got_lv) and np.array_equal(ref.rValid, got_rv))
-        if not verified:
-            print("bench.py: MAPS OF THE TIMED PATH DIFFER FROM THE ONE-GPU RUN", file=sys.stderr)
+        if use_dist or args.verify:
+            ref_maps = single_gpu_maps()
+        checks = check_maps(head, ref_maps, oracle_maps)
+        if timed_maps is not None and oracle_maps is not None:      # (the maps downloaded right after the timed region, too)
+            checks["oracle_maps_equal"] = bool(checks["oracle_maps_equal"] and np.array_equal(timed_maps[0], oracle_maps[0])
+                                               and np.array_equal(timed_maps[1], oracle_maps[1]))
+        de.set_option(capi.PSM_OPT_ASYNC, 1)
+
+    # ---- post-processing stages on the finished maps (PP::processDM: lrCheck, fillInv, wgtMedian; src/PP.cpp:405-410) ----
+    pp = None
+    if args.pp and rank == 0 and not use_dist and args.shard_sim <= 1:
+        de.set_option(capi.PSM_OPT_ASYNC, 0)
+        pp = {}
+        for it in range(2):                      # second pass: scratch allocated, clocks up
+            step(); sync()
+            raw_l, raw_r = (m.copy() for m in de.download_maps())
+            t = time.perf_counter(); de.LRCheck_device(); de.synchronize(); pp["lr_check_ms"] = round(1e3 * (time.perf_counter() - t), 4)
+            lv, rv = (m.copy() for m in de.download_valid())
+            t = time.perf_counter(); de._ck(de._lib.psm_fill_invalid(de._h, None, None, 0), "fill"); de.synchronize()
+            pp["fill_inv_ms"] = round(1e3 * (time.perf_counter() - t), 4)
+            t = time.perf_counter(); de._ck(de._lib.psm_wgt_median(de._h, None, None, 0), "wmf"); de.synchronize()
+            pp["wgt_median_ms"] = round(1e3 * (time.perf_counter() - t), 4)
+        out_l, out_r = (m.copy() for m in de.download_maps())
+        sw, ev = de.wgt_median_stats()
+        pp["invalid_frac"] = [round(float(1.0 - lv.mean()), 4), round(float(1.0 - rv.mean()), 4)]
+        pp["wgt_median_sweeps"], pp["wgt_median_evals"] = sw, ev
+        if O is None:
+            from oracle import psm_oracle_py as O
+        elv, erv = O.lr_check(raw_l, raw_r)
+        ok = bool(np.array_equal(lv, elv) and np.array_equal(rv, erv))
+        if ok:
+            t = time.perf_counter()
+            fl_, fr_ = O.fill_inv(raw_l, elv), O.fill_inv(raw_r, erv)
+            lf, rf = O.u8_to_f32(l), O.u8_to_f32(r)
+            el = O.wgt_median(lf, fl_, elv, D, right=False)
+            er = O.wgt_median(rf, fr_, erv, D, right=True)
+            pp["oracle_s"] = round(time.perf_counter() - t, 2)
+            ok = bool(np.array_equal(out_l, el) and np.array_equal(out_r, er))
+        pp["verified_vs_oracle"] = ok
+        pp["note"] = "stage wall times incl. launch + synchronisation, maps resident on the device; not part of value"
+        de.set_option(capi.PSM_OPT_ASYNC, 1)
 
     box = None
     if args.box_bench and not use_dist:
@@ -433,37 +620,36 @@ def main():
         tot, n = de.kernel_time_ms(capi.PSM_K_BOX)
         de.set_option(capi.PSM_OPT_PROFILE, 0)
         bms = tot / n
-        box = {"avg_ms": round(bms, 4), "alg_GBs": round(8.0 * vox_per_launch / (bms * 1e-3) / 1e9, 1),
-               "read_GBs": round(4.0 * vox_per_launch / (bms * 1e-3) / 1e9, 1),
-               "read_frac_of_peak": round(4.0 * vox_per_launch / (bms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+        bv = 1.0 * W * H * (d1 - d0)             # one volume
+        box = {"avg_ms": round(bms, 4), "alg_GBs": round(8.0 * bv / (bms * 1e-3) / 1e9, 1),
+               "read_GBs": round(4.0 * bv / (bms * 1e-3) / 1e9, 1),
+               "read_frac_of_peak": round(4.0 * bv / (bms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+               "fused_pass_equivalent_ms": round(ms_per_step / 16.0, 4),
+               "fused_pass_equivalent_read_frac": round(4.0 * bv / (ms_per_step / 16.0 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+               "note": "the north star's '>= 60 % of HBM-read roofline on the CVF box-filter pass': a stand-alone pass that writes as much as "
+                       "it reads cannot reach it (read_frac_of_peak); inside the fused kernel the 16 box passes of a frame take "
+                       "ms_per_step / 16 each (fused_pass_equivalent_*) - only in that accounting is it met"}
+    de.close()
 
-    # ---- CPU baseline: the oracle, driven like the reference pthreads path ------------------
-    cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        from oracle import psm_oracle_py as O   # checker / baseline only - never on the GPU path
-        cores = os.cpu_count() or 1
-        threads = min(8, cores)                 # MAX_CPU_THREADS (include/ComFunc.h:52)
-        sd = args.cpu_sample_d if args.cpu_sample_d > 0 else int(256.0 * (1920 * 1080) / (W * H))
-        sd = max(2, min(sd, D))
-        tcpu = time.perf_counter()
-        res = (O.pipeline_u8 if dtype == "u8" else O.pipeline_f32)(l, r, sd, threads=threads)
-        tcpu = time.perf_counter() - tcpu
-        stage_s = (res["cvc_ms"] + res["cvf_ms"] + res["dispsel_ms"]) * 1e-3
-        cpu = {"value": round(2.0 * W * H * sd / stage_s, 1), "unit": "voxels/s", "cores": threads,
-               "kind": "port", "host_cores": cores,
-               "sample": f"same {W}x{H} pair, first {sd} of {D} disparities (2*W*H*{sd} voxels), "
-                         f"{threads} pthreads in the reference's per-d block pattern; "
-                         f"cvc {res['cvc_ms']:.0f} ms, cvf {res['cvf_ms']:.0f} ms, dispsel {res['dispsel_ms']:.0f} ms "
-                         f"(wall {tcpu:.1f} s)"}
-        # the same restatement on more host cores (SURVEY.md 8d asks for 8 threads and for the box's core count):
-        # context only, the contract's cpu_baseline is the 8-thread figure above
-        wide = min(64, cores)
-        if args.cpu_wide and wide > threads:
-            resw = (O.pipeline_u8 if dtype == "u8" else O.pipeline_f32)(l, r, sd, threads=wide)
-            sw = (resw["cvc_ms"] + resw["cvf_ms"] + resw["dispsel_ms"]) * 1e-3
-            cpu["wide"] = {"value": round(2.0 * W * H * sd / sw, 1), "cores": wide}
+    # ================= the other sharding axis (N > 1) =================
+    alt = None
+    if use_dist and not args.no_alt_shard and not args.fgf:
+        other = "disp" if args.shard == "rows" else "rows"
+        ok_axis = (other == "disp" and world <= D) or (other == "rows" and (world - 1) * -(-H // world) < H)
+        if ok_axis:
+            a = measure(other, args.exchange or "allgather")
+            alt = {"shard": other, "exchange": a["exchange"], "ms_per_step": a["ms_per_step"], "value": a["value"],
+                   "median_ms_per_step": a["median_ms_per_step"], "filter_launches": a["filter_launches"],
+                   "parallelism": (f"D sharded over {world} ranks + 1 RCCL {a['exchange']} of packed minima per frame" if other == "disp"
+                                   else f"{world} row stripes + 1 RCCL all_gather of the map rows per frame"),
+                   "note": ("the configuration BASELINE configs[3] / the north star name (D slices sharded, one all-gather of per-pixel minima); "
+                            "same maps as the headline axis" if other == "disp" else "row stripes; same maps as the headline axis")}
+            if rank == 0:
+                a["sync"]()
+                a["de"].set_option(capi.PSM_OPT_ASYNC, 0)
+                alt.update(check_maps(a, ref_maps, oracle_maps))
+            a["de"].close()
 
-    seed_stride = de.seed_stride()        # what the library's in-place tuner chose for this geometry (0: not in use)
     if rank == 0:
         out = {
             "metric": "cost-volume voxels/s (CVC+CVF+WTA)" if not args.fgf else f"cost-volume voxels/s (CVC+CVF_FGF s={args.fgf}+WTA)",
@@ -473,14 +659,19 @@ def main():
             "data": "synthetic",
             "config": {"workload": desc, "W": W, "H": H, "D": D, "voxels_per_step": voxels_per_step,
                        "parallelism": "1 GPU" if world == 1 and not use_dist else
-                                      (f"{world} row stripes of {rows_max} rows (all {D} slices each) + 1 RCCL all_gather of the map rows per frame"
-                                       if rows_mode else f"D sharded over {world} ranks + 1 RCCL {args.exchange} of packed minima"),
-                       "kernel_variant": args.variant, "shard_sim": args.shard_sim, "seed_stride": seed_stride, "lr_check_on_gpu": bool(lrc), "shard": (args.shard if (use_dist or args.shard_sim > 1) else None)},
+                                      (f"{world} row stripes of {geo['rows_max']} rows (all {D} slices each) + 1 RCCL all_gather of the map rows per frame"
+                                       if rows_mode else f"D sharded over {world} ranks + 1 RCCL {exchange} of packed minima"),
+                       "kernel_variant": args.variant, "shard_sim": args.shard_sim, "lr_check_on_gpu": bool(lrc),
+                       "shard": head["shard"]},
             "roofline": roofline, "cpu_baseline": cpu, "kernels": kern,
-            "median_ms_per_step": round(median_ms, 4), "pcie": pcie,
+            "kernels_sum_ms_per_step": round(kernels_sum, 4), "kernels_sum_le_step": bool(kernels_sum <= ms_per_step * 1.005),
+            "median_ms_per_step": head["median_ms_per_step"], "pcie": pcie,
         }
-        if verified is not None:
-            out["verified_vs_single_gpu"] = verified
+        out.update(checks)
+        if alt:
+            out["alt_shard"] = alt
+        if pp:
+            out["pp"] = pp
         if box:
             out["box_filter_pass"] = box
         if json_fd is not None:
@@ -488,10 +679,10 @@ def main():
         else:
             print(json.dumps(out))
             sys.stdout.flush()
-    de.close()
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
+    return 0
 
 
 if __name__ == "__main__":

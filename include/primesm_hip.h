@@ -49,35 +49,30 @@ enum { PSM_K_PREP = 0, PSM_K_CVC = 1, PSM_K_GUIDE = 2, PSM_K_CVF_A = 3, PSM_K_CV
 enum {
     PSM_OPT_ASYNC = 0,          /* 1: stage calls only enqueue; use psm_synchronize()        */
     PSM_OPT_KERNEL_VARIANT = 1, /* 0: marching kernels (default), 1: direct per-voxel kernels */
-    PSM_OPT_PROFILE = 2,        /* 1: bracket every kernel launch with hipEvents              */
+    PSM_OPT_PROFILE = 2,        /* 1: bracket every kernel launch with hipEvents (psm_kernel_time_ms); 2: the fused filter
+                                   kernel stamps its own start / end instead (psm_filter_launch_times) */
     PSM_OPT_SEG_ROWS = 3,       /* rows per y-segment of the marching kernels (0 = auto)      */
     PSM_OPT_WAVES = 4,          /* waves (disparity slices) per workgroup: 1,2,4,8            */
-    PSM_OPT_FLAGS = 5           /* tuning bits: 1 = nontemporal stores in the two-stage filter; 2,4 = block traversal
-                                   order of its stage A; 64 = plain (4-byte store) CVC kernel; 16 = two-stage guided
-                                   filter instead of the fused one; 128 = psm_cost_construct always writes the cost
-                                   volumes (default: they stay virtual and the fused filter builds the costs
-                                   on the fly; any other reader materialises them first); 256 = two-pass
-                                   guidance kernels; 512 = two-columns-per-lane variant of the fused filter
-                                   (widths that are multiples of 4); 4096 = psm_cost_filter_fgf always writes
-                                   the filtered volumes (default: they stay virtual - low-resolution models -
-                                   and the WTA consumes those directly); 8192 = psm_cost_filter always writes the
-                                   filtered volumes (default: the fused kernel runs the WTA over the local slices
-                                   itself and the filtered volumes stay virtual - packed per-pixel minima - until
-                                   something other than psm_disp_select* reads them); 16384 = two-columns-per-lane,
-                                   channel-split variant of that kernel (k_cvf_q2); 65536 = psm_cost_filter launches
-                                   every kernel once per volume (default: both volumes per launch); 262144 = the
-                                   select-mode kernel updates one shared plane of packed keys per volume by 64-bit
-                                   atomicMin (default: private minima planes + a reduction kernel); 524288 = resident
-                                   workgroups take the slices of their (column group, segment) pair dynamically from a
-                                   device counter (default: static chunks of slices per workgroup); 1048576 / 2097152 =
-                                   force / disable the two-phase selection of psm_cost_filter (default: on from 112
-                                   local slices - every 5th slice through the minima planes, the rest against the
-                                   seeded key plane); 4194304 = psm_wgt_median runs its row-dataflow form only;
-                                   8388608 = at most 2 sweeps of its parallel form (test hook for the fall-back);
-                                   16777216 = in-place tuning of the seeding stride of the two-phase selection
-                                   (the strides 5, 4, 6 are timed twice each on frames 4-9 of a geometry and the
-                                   fastest kept; default: 5, and 4 from 4 Mpixel up).
-                                   No flag changes any result. */
+    PSM_OPT_FLAGS = 5           /* PSM_FLAG_* bits below; no flag changes any result */
+};
+
+/* PSM_OPT_FLAGS bits.  The default (0) is the product path: cost volumes and filtered volumes stay virtual, the fused
+ * kernel runs CVC + CVF + WTA in one pass (two phases from 112 local slices up).  The flags select the forms that
+ * materialise a volume - what a host that reads volumes gets anyway, on demand - and test hooks. */
+enum psm_flag {
+    PSM_FLAG_MATERIALISE_COSTS = 128,   /* psm_cost_construct always writes the cost volumes (default: they stay virtual
+                                           and the fused filter builds the costs on the fly; any other reader
+                                           materialises them first) */
+    PSM_FLAG_FGF_STORE = 4096,          /* psm_cost_filter_fgf always writes the filtered volumes (default: they stay
+                                           virtual - low-resolution models - and the WTA consumes those directly) */
+    PSM_FLAG_STORE_FILTERED = 8192,     /* psm_cost_filter always writes the filtered volumes (storing form of the fused
+                                           kernel + a separate WTA; default: select forms, packed per-pixel minima) */
+    PSM_FLAG_TWO_PHASE_ON = 1048576,    /* force / disable the two-phase selection of psm_cost_filter (default: on from */
+    PSM_FLAG_TWO_PHASE_OFF = 2097152,   /* 112 local slices - every 5th slice through minima planes, the rest against
+                                           the seeded key plane) */
+    PSM_FLAG_WMF_DATAFLOW = 4194304,    /* psm_wgt_median runs its row-dataflow form only */
+    PSM_FLAG_WMF_TWO_SWEEPS = 8388608,  /* ... at most 2 sweeps of its parallel form (test hook for the fall-back) */
+    PSM_FLAGS_ALL = 128 | 4096 | 8192 | 1048576 | 2097152 | 4194304 | 8388608
 };
 
 /* Number of usable HIP devices; 0 if none.  Replaces openCLdevicepoll()
@@ -181,6 +176,21 @@ int psm_disp_merge_ctx(psm_ctx *root, psm_ctx *const *shards, int nshards, uint8
 
 int psm_download_maps(psm_ctx *ctx, uint8_t *lmap, uint8_t *rmap, size_t stride);
 
+/* ---- frame loop (src/main.cpp:64-73: one pair after the other; the reference's stage timers include the copies,
+ * src/StereoMatch.cpp:227-237): the PCIe legs next to the kernels ----
+ * psm_upload_pair_async: as psm_upload_pair, but for the NEXT frame: the images are copied to page-locked staging memory
+ * before the call returns (the caller's buffers are free again) and travel on the context's copy stream into a second image
+ * slot while the current frame is being computed; the next psm_cost_construct adopts that pair (its kernels wait for the
+ * copy on the device) - so it is called right after psm_cost_construct of the current frame:
+ *   psm_cost_construct(i); psm_upload_pair_async(pair i+1); psm_cost_filter(i); psm_disp_select(i, NULL, NULL, 0);
+ *   psm_download_maps_async(); psm_download_maps_wait(...)   <- typically one frame later: the maps of frame i-1
+ * psm_download_maps_async starts the D2H copy of the current maps (after the kernels that produce them, before any
+ * later kernel overwrites them) and returns; psm_download_maps_wait blocks until they have arrived and hands them over
+ * (lmap / rmap as psm_download_maps).  One upload and one download may be in flight. */
+int psm_upload_pair_async(psm_ctx *ctx, const void *l, const void *r, int channels, size_t stride_bytes, int depth);
+int psm_download_maps_async(psm_ctx *ctx);
+int psm_download_maps_wait(psm_ctx *ctx, uint8_t *lmap, uint8_t *rmap, size_t stride);
+
 /* "next" row: PP lrCheck on the device (src/PP.cpp:17-50) on the maps of the last
  * psm_disp_select/psm_disp_merge.  lvalid/rvalid: H x W bytes (0/1), pitch `stride`; either
  * may be NULL (results stay on the device). */
@@ -226,10 +236,6 @@ int psm_set_map_buffer(psm_ctx *ctx, void *dev_maps, int whole);
 int psm_gather_rows_ctx(psm_ctx *root, psm_ctx *const *stripes, int nstripes, uint8_t *lmap, uint8_t *rmap, size_t stride);
 
 /* ---- debug / bench entry points (no counterpart in the reference) ---- */
-/* Stride of the seeding phase of the two-phase selection the in-place tuner settled on for the current geometry
- * (0: still measuring, or the two-phase selection is not in use). */
-int psm_debug_seed_stride(psm_ctx *ctx);
-
 /* Replace the device maps and validity masks (any may be NULL = keep) - lets the post-processing stages run on maps
  * that did not come from this context's WTA.  H rows of W bytes, pitch `stride`; map values must be < max_disp. */
 int psm_upload_maps(psm_ctx *ctx, const uint8_t *lmap, const uint8_t *rmap, const uint8_t *lvalid, const uint8_t *rvalid,
@@ -259,6 +265,11 @@ int psm_stage_time_us(psm_ctx *ctx, int stage, double *us);
  * and launch count of a kernel class since the last psm_reset_kernel_times(). */
 int psm_kernel_time_ms(psm_ctx *ctx, int kernel, double *total_ms, int *launches);
 int psm_reset_kernel_times(psm_ctx *ctx);
+/* With PSM_OPT_PROFILE=2: duration in ms (first workgroup start to last workgroup end, device constant-rate clock) and form
+ * (1 = minima planes, 2 = key plane, 0 = storing) of every launch of the fused filter kernel since the last call, in launch
+ * order; at most max_launches (the library keeps 4096).  Costs two 64-bit atomics per workgroup and no events or
+ * synchronisation between kernels, so it can stay on inside a timed region.  Resets the record. */
+int psm_filter_launch_times(psm_ctx *ctx, double *ms, int *form, int max_launches, int *n_launches);
 
 /* geometry queries */
 int psm_get_info(const psm_ctx *ctx, int *width, int *height, int *max_disp, int *d_begin,

@@ -20,6 +20,10 @@ PSM_STAGE_CVC, PSM_STAGE_CVF, PSM_STAGE_DISPSEL, PSM_STAGE_PP = 0, 1, 2, 3
 (PSM_K_PREP, PSM_K_CVC, PSM_K_GUIDE, PSM_K_CVF_A, PSM_K_CVF_B, PSM_K_WTA, PSM_K_MERGE, PSM_K_BOX,
  PSM_K_LRC, PSM_K_CVF_F, PSM_K_FGF, PSM_K_WMF) = range(12)
 PSM_OPT_ASYNC, PSM_OPT_KERNEL_VARIANT, PSM_OPT_PROFILE, PSM_OPT_SEG_ROWS, PSM_OPT_WAVES, PSM_OPT_FLAGS = range(6)
+# enum psm_flag (PSM_OPT_FLAGS bits)
+PSM_FLAG_MATERIALISE_COSTS, PSM_FLAG_FGF_STORE, PSM_FLAG_STORE_FILTERED = 128, 4096, 8192
+PSM_FLAG_TWO_PHASE_ON, PSM_FLAG_TWO_PHASE_OFF = 1048576, 2097152
+PSM_FLAG_WMF_DATAFLOW, PSM_FLAG_WMF_TWO_SWEEPS = 4194304, 8388608
 
 # every symbol include/primesm_hip.h declares: (name, restype, argtypes)
 _vp, _i, _sz = C.c_void_p, C.c_int, C.c_size_t
@@ -34,6 +38,7 @@ SYMBOLS = [
     ("psm_set_stream", _i, [_vp, _vp]),
     ("psm_synchronize", _i, [_vp]),
     ("psm_upload_pair", _i, [_vp, _vp, _vp, _i, _sz, _i]),
+    ("psm_upload_pair_async", _i, [_vp, _vp, _vp, _i, _sz, _i]),
     ("psm_cost_construct", _i, [_vp]),
     ("psm_cost_filter", _i, [_vp]),
     ("psm_cost_filter_side", _i, [_vp, _i]),
@@ -46,11 +51,12 @@ SYMBOLS = [
     ("psm_disp_merge", _i, [_vp, _vp, _i, _vp, _vp, _sz]),
     ("psm_disp_merge_ctx", _i, [_vp, C.POINTER(_vp), _i, _vp, _vp, _sz]),
     ("psm_download_maps", _i, [_vp, _vp, _vp, _sz]),
+    ("psm_download_maps_async", _i, [_vp]),
+    ("psm_download_maps_wait", _i, [_vp, _vp, _vp, _sz]),
     ("psm_lr_check", _i, [_vp, _vp, _vp, _sz]),
     ("psm_fill_invalid", _i, [_vp, _vp, _vp, _sz]),
     ("psm_wgt_median", _i, [_vp, _vp, _vp, _sz]),
     ("psm_wgt_median_stats", _i, [_vp, _vp, _vp]),
-    ("psm_debug_seed_stride", _i, [_vp]),
     ("psm_set_rows", _i, [_vp, _i, _i]),
     ("psm_set_map_buffer", _i, [_vp, _vp, _i]),
     ("psm_gather_rows_ctx", _i, [_vp, _vp, _i, _vp, _vp, _sz]),
@@ -64,6 +70,7 @@ SYMBOLS = [
     ("psm_stage_time_us", _i, [_vp, _i, _pd]),
     ("psm_kernel_time_ms", _i, [_vp, _i, _pd, _pi]),
     ("psm_reset_kernel_times", _i, [_vp]),
+    ("psm_filter_launch_times", _i, [_vp, _pd, _pi, _i, _pi]),
     ("psm_get_info", _i, [_vp, _pi, _pi, _pi, _pi, _pi, _pi, _pi]),
 ]
 

@@ -1,0 +1,176 @@
+// psm_api_pp.cpp - the post-processing rows behind the C ABI: lrCheck, fillInv and the plain weighted
+// median of PP::processDM (src/PP.cpp:17-247,405-410) on the device maps of the last DispSelect.  The reference runs these
+// on the CPU; here they sit behind the same boundary so that the maps never leave the device between the stages.
+#include "psm_ctx.h"
+
+using namespace psm;
+
+extern "C" {
+
+int psm_lr_check(psm_ctx *c, uint8_t *lvalid, uint8_t *rvalid, size_t stride)
+{
+    if (!c) return 1;
+    if (!c->have_maps) return fail(c, "psm_lr_check: no disparity maps computed");
+    if (c->have_rows) return fail(c, "psm_lr_check: the maps hold this context's row stripe only (gather the stripes first)");
+    if (bind(c)) return 1;
+    const double t0 = now_us();
+    const size_t HW = (size_t)c->W * c->H;
+    {
+        Prof p(c, PSM_K_LRC);
+        launch_lr_check(c->stream, c->maps, c->maps + HW, c->W, c->H, c->valid, c->valid + HW);
+    }
+    if (check_launch(c, "lr_check")) return 1;
+    c->have_valid = true;
+    if (copy_maps_out(c, c->valid, lvalid, rvalid, stride)) return 1;
+    return end_stage(c, PSM_STAGE_PP, t0);
+}
+
+int psm_fill_invalid(psm_ctx *c, uint8_t *lmap, uint8_t *rmap, size_t stride)
+{
+    if (!c) return 1;
+    if (!c->have_maps || !c->have_valid) return fail(c, "psm_fill_invalid: needs disparity maps and psm_lr_check");
+    if (bind(c)) return 1;
+    const double t0 = now_us();
+    const size_t HW = (size_t)c->W * c->H;
+    {
+        Prof p(c, PSM_K_LRC);
+        launch_fill_inv(c->stream, c->maps, c->valid, c->W, c->H);
+        launch_fill_inv(c->stream, c->maps + HW, c->valid + HW, c->W, c->H);
+    }
+    if (check_launch(c, "fill_inv")) return 1;
+    // have_valid stays set: the mask still says which pixels the L-R check rejected, which is what the next stage of
+    // PP::processDM (wgtMedian, src/PP.cpp:405-410) filters
+    if (copy_maps_out(c, c->maps, lmap, rmap, stride)) return 1;
+    if (!c->opt_async) PSM_HIP(c, hipStreamSynchronize(c->stream));
+    c->stage_us[PSM_STAGE_PP] += now_us() - t0;
+    return 0;
+}
+
+// The row-dataflow form of wgtMedian: exact for any input, but as sequential as the reference wherever invalid pixels chain
+static int wgt_median_dataflow(psm_ctx *c, int side)
+{
+    const size_t HW = (size_t)c->W * c->H, nn = (size_t)c->H * (c->W + 1);
+    if (!c->wm) PSM_HIP(c, hipMalloc((void **)&c->wm, (nn + c->H + 1) * sizeof(int)));
+    int *nxt = c->wm, *prog = c->wm + nn, *err = prog + c->H;
+    PSM_HIP(c, hipMemsetAsync(err, 0, sizeof(int), c->stream));
+    {
+        Prof p(c, PSM_K_WMF);
+        launch_wgt_median(c->stream, c->maps + side * HW, c->valid + side * HW, c->g[side].g1, c->W, c->H, c->D, side, nxt, prog, err);
+    }
+    if (check_launch(c, "wgt_median")) return 1;
+    int herr = 0;
+    PSM_HIP(c, hipMemcpyAsync(&herr, err, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    PSM_HIP(c, hipStreamSynchronize(c->stream));
+    if (herr) {
+        // the kernel gave up on unfinished rows: the in-place maps are partially filtered - not results
+        c->have_maps = false;
+        c->have_valid = false;
+        return fail(c, "psm_wgt_median: row pipeline stalled (watchdog); the device maps are no longer valid - select again");
+    }
+    c->wm_sweeps[side] = -1;
+    c->wm_evals[side] = 0;
+    return 0;
+}
+
+int psm_wgt_median(psm_ctx *c, uint8_t *lmap, uint8_t *rmap, size_t stride)
+{
+    if (!c) return 1;
+    if (!c->have_maps || !c->have_valid) return fail(c, "psm_wgt_median: needs disparity maps and psm_lr_check");
+    if (!c->have_images) return fail(c, "psm_wgt_median: no image pair uploaded (colour weights)");
+    if (c->W < 9 || c->H < 9) return fail(c, "psm_wgt_median: image %dx%d smaller than the 19x19 window's wrap allows", c->W, c->H);
+    if (bind(c)) return 1;
+    const double t0 = now_us();
+    if (!c->have_g1 && run_prep(c)) return 1;
+    const size_t HW = (size_t)c->W * c->H;
+    // PSM_FLAG_WMF_DATAFLOW: dataflow form only; PSM_FLAG_WMF_TWO_SWEEPS: at most 2 sweeps (test hook for the fall-back)
+    const bool dataflow_only = (c->march.flags & PSM_FLAG_WMF_DATAFLOW) != 0;
+    const int CAP = (c->march.flags & PSM_FLAG_WMF_TWO_SWEEPS) ? 2 : 96, CHK = 4;
+    bool done[2] = {false, false};
+    if (!dataflow_only) {
+        // parallel form: sweeps to the fixed point of the in-place recursion (psm_pp.hip), both maps side by side
+        const size_t nb = (HW + 255) / 256 * 256, ncnt = 2 * (size_t)(96 + 2);
+        const size_t per_side = 2 * nb + (4 * nb + ncnt) * sizeof(int);
+        if (!c->wm_par) PSM_HIP(c, hipMalloc((void **)&c->wm_par, 2 * per_side));
+        uint8_t *orig[2], *newv[2];
+        int *stamp[2], *list[2][2], *chg[2], *cnt[2];
+        for (int s = 0; s < 2; ++s) {
+            uint8_t *b = c->wm_par + s * per_side;
+            orig[s] = b; newv[s] = b + nb;
+            int *ip = reinterpret_cast<int *>(b + 2 * nb);
+            stamp[s] = ip; list[s][0] = ip + nb; list[s][1] = ip + 2 * nb; chg[s] = ip + 3 * nb; cnt[s] = ip + 4 * nb;
+            PSM_HIP(c, hipMemcpyAsync(orig[s], c->maps + s * HW, HW, hipMemcpyDeviceToDevice, c->stream));
+            PSM_HIP(c, hipMemsetAsync(stamp[s], 0, nb * sizeof(int), c->stream));
+            PSM_HIP(c, hipMemsetAsync(cnt[s], 0, ncnt * sizeof(int), c->stream));
+            launch_wm_seed(c->stream, c->valid + s * HW, c->W, c->H, list[s][0], cnt[s]);
+        }
+        std::vector<int> hc(2 * ncnt);
+        int sw = 0;
+        while (sw < CAP && !(done[0] && done[1])) {
+            const int upto = sw + CHK < CAP ? sw + CHK : CAP;
+            {
+                Prof p(c, PSM_K_WMF);
+                for (; sw < upto; ++sw)
+                    for (int s = 0; s < 2; ++s)
+                        if (!done[s])
+                            launch_wm_sweep(c->stream, c->maps + s * HW, orig[s], c->valid + s * HW, c->g[s].g1, c->W, c->H, c->D, s,
+                                            list[s][sw & 1], cnt[s] + 2 * sw, newv[s], chg[s], cnt[s] + 2 * sw + 1, stamp[s], sw + 1,
+                                            list[s][(sw + 1) & 1], cnt[s] + 2 * (sw + 1));
+            }
+            if (check_launch(c, "wgt_median (sweeps)")) return 1;
+            for (int s = 0; s < 2; ++s)
+                PSM_HIP(c, hipMemcpyAsync(hc.data() + s * ncnt, cnt[s], ncnt * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+            PSM_HIP(c, hipStreamSynchronize(c->stream));
+            for (int s = 0; s < 2; ++s) {
+                if (done[s]) continue;
+                long long ev = 0;
+                for (int k = 0; k < sw; ++k) {
+                    ev += hc[s * ncnt + 2 * k];
+                    if (hc[s * ncnt + 2 * k + 1] == 0) {      // sweep k changed nothing: fixed point
+                        done[s] = true;
+                        c->wm_sweeps[s] = k + 1;
+                        c->wm_evals[s] = ev;
+                        break;
+                    }
+                }
+            }
+        }
+        // no fixed point within CAP sweeps (long chains of pixels that keep flipping each other): start over from the input
+        // with the dataflow form, which is exact for any input
+        for (int s = 0; s < 2; ++s)
+            if (!done[s]) PSM_HIP(c, hipMemcpyAsync(c->maps + s * HW, orig[s], HW, hipMemcpyDeviceToDevice, c->stream));
+    }
+    for (int s = 0; s < 2; ++s)
+        if (!done[s] && wgt_median_dataflow(c, s)) return 1;
+    if (copy_maps_out(c, c->maps, lmap, rmap, stride)) return 1;
+    c->stage_us[PSM_STAGE_PP] += now_us() - t0;
+    return 0;
+}
+
+int psm_wgt_median_stats(psm_ctx *c, int *sweeps, long long *evals)
+{
+    if (!c) return 1;
+    for (int s = 0; s < 2; ++s) {
+        if (sweeps) sweeps[s] = c->wm_sweeps[s];
+        if (evals) evals[s] = c->wm_evals[s];
+    }
+    return 0;
+}
+
+int psm_upload_maps(psm_ctx *c, const uint8_t *lmap, const uint8_t *rmap, const uint8_t *lvalid, const uint8_t *rvalid, size_t stride)
+{
+    if (!c) return 1;
+    if (stride == 0) stride = c->W;
+    if (stride < (size_t)c->W) return fail(c, "psm_upload_maps: stride %zu < width %d", stride, c->W);
+    if (bind(c)) return 1;
+    const size_t HW = (size_t)c->W * c->H;
+    const uint8_t *src[4] = {lmap, rmap, lvalid, rvalid};
+    uint8_t *dst[4] = {c->maps, c->maps + HW, c->valid, c->valid + HW};
+    for (int i = 0; i < 4; ++i)
+        if (src[i]) PSM_HIP(c, hipMemcpy2DAsync(dst[i], c->W, src[i], stride, c->W, c->H, hipMemcpyHostToDevice, c->stream));
+    PSM_HIP(c, hipStreamSynchronize(c->stream));
+    if (lmap && rmap) { c->have_maps = true; c->have_valid = false; c->have_rows = false; c->rows_y0 = 0; c->rows_y1 = c->H; }   // whole maps
+    if (lvalid && rvalid && c->have_maps) c->have_valid = true;
+    return 0;
+}
+
+}  // extern "C"

@@ -21,8 +21,7 @@ struct Guidance {
 struct March {       // geometry of the marching kernels
     int seg_rows;    // output rows per y-segment (0 = auto)
     int waves;       // waves (= disparity slices) per workgroup: 1,2,4,8
-    int flags;       // PSM_OPT_FLAGS (include/primesm_hip.h): bit 0 nontemporal stores of 4-byte outputs, bits 1-2
-                     // block traversal order of stage A, bit 6 plain CVC kernel, ...
+    int flags;       // PSM_OPT_FLAGS (include/primesm_hip.h)
     int ybeg = 0, yend = 0;   // row stripe of the select-form filter (psm_set_rows): output rows [ybeg, yend) of the whole
                               // image; yend <= ybeg: all rows
     int y0(int H) const { (void)H; return yend > ybeg ? ybeg : 0; }
@@ -33,61 +32,50 @@ struct March {       // geometry of the marching kernels
 // image -> g1 (planarise, scale, gray, x-gradient).  src: device copy of the interleaved image.
 void launch_prep(hipStream_t s, const void *src, size_t pitch, int depth_f32, int W, int H, float4 *g1, const void *src1 = nullptr,
                  float4 *g11 = nullptr);
-// g1 -> g2,g3,g4.  hs9: scratch, 9*H*W doubles.
-void launch_guidance(hipStream_t s, Guidance g, double *hs9, int W, int H, int two_pass, const Guidance *second = nullptr,
-                     int ybeg = 0, int yend = 0);   // [ybeg, yend): rows of g2..g4 to produce (single-pass form; default all)
+// g1 -> g2,g3,g4 (second != NULL: both images in one launch; [ybeg, yend): rows of g2..g4 to produce, default all)
+void launch_guidance(hipStream_t s, Guidance g, int W, int H, const Guidance *second = nullptr, int ybeg = 0, int yend = 0);
 // cost volume slices [d_begin, d_begin+Dloc) of one side.  base: g1 of the side's own image.
 void launch_cvc(hipStream_t s, const float4 *g1_base, const float4 *g1_other, float *vol, int W, int H,
-                int d_begin, int Dloc, int right, int flags, int ybeg, int yend);
-// guided filter halves.  variant 0 = marching, 1 = direct per-voxel.
-// [ybeg, yend): output rows of this launch (the arithmetic always refers to the full H-row planes)
+                int d_begin, int Dloc, int right, int ybeg, int yend);
+// Stage A of the guided filter alone (the debug entry psm_filter_stage_a; tests compare (a0,a1,a2,b) with the oracle's
+// intermediates).  variant 0 = marching, 1 = direct per-voxel.  [ybeg, yend): output rows of this launch (the arithmetic
+// always refers to the full H-row planes).  Stage B alone exists in the direct formulation only (cross-check).
 void launch_cvf_a(hipStream_t s, int variant, March m, const float *vol, float4 *ab, Guidance g, int W,
                   int H, int Dloc, int ybeg, int yend);
-void launch_cvf_b(hipStream_t s, int variant, March m, const float4 *ab, float *vol, Guidance g, int W,
-                  int H, int Dloc, int ybeg, int yend);
+void launch_cvf_b_direct(hipStream_t s, const float4 *ab, float *vol, Guidance g, int W, int H, int Dloc);
 // fused stage A+B: vin -> vout (distinct buffers), output rows [ybeg, yend) within [4, H-3)
 // cvc_mode 0: read the cost slices from vin; 1/2: build the left/right costs on the fly from the g1 planes
 void launch_cvf_fused(hipStream_t s, March m, const float *vin, float *vout, Guidance g, int W, int H, int Dloc,
                       int ybeg, int yend, const float4 *g1_other, int d_begin, int cvc_mode);
-// The same kernel with the winner-takes-all fused in ("select" mode): the filtered volume is never written; per pixel
-// the packed WTA key over the local slices goes to keys[H*W] and / or the disparity to map[H*W] (either may be NULL).
-// scratch: pc_plan(...).scratch_bytes() bytes (chunk planes).
+// The same kernel with the winner-takes-all fused in ("select" forms): the filtered volume is never written.
+//   plane form: per pixel the running minimum over chunks of DC slices in scratch planes -> launch_chunk_min* -> packed WTA keys
+//   key form:   64-bit atomicMin on a key plane that already holds good bounds (second phase of the two-phase selection)
+struct PcDev { int nxcd = 0, cus_per_xcd = 0; };
+PcDev pc_dev();                                                  // of the device the calling thread is bound to
+enum { PC_STORE = 0, PC_PLANES = 1, PC_KEYS = 2, PC_BOTH = 4 };  // forms of pc_plan (PC_BOTH: both volumes per launch)
 struct PcPlan {
-    int ngroups, nsegs, seg_rows, DC, nchunks, nbmax;
-    int NW;                                                      // dynamic form: workgroups (= planes) per pair, else 0
+    int ngroups, nsegs, seg_rows, DC, nchunks, nbmax, nxcd;
     size_t rec_per_chunk;                                        // records per chunk plane
     int rec_bytes;                                               // bytes per record (costs + disparities)
     size_t scratch_bytes() const { return rec_per_chunk * (size_t)nchunks * rec_bytes; }
 };
-PcPlan pc_plan(int W, int rows, int Dloc, int seg_rows_opt, int mode);
-PcPlan pc_plan_cols(int W, int rows, int Dloc, int seg_rows_opt, int mode, int cols);
+PcPlan pc_plan(int W, int rows, int Dloc, int seg_rows_opt, int form);
+int pc_seed_stride(int W, int H);                                // S of the two-phase selection: every S-th slice seeds the key plane
+// ts (may be NULL): slot of this launch in a buffer of 3 x PC_TS_SLOTS 64-bit words {first workgroup start | last workgroup
+// end | form} in ticks of the device's constant-rate clock (PSM_OPT_PROFILE 2, psm_filter_launch_times)
+constexpr int PC_TS_SLOTS = 4096;
+// one volume per launch (costs read from vin, cvc_mode 0, or built on the fly, 1 / 2; p4_*: 8-bit char mode)
 void launch_cvf_select(hipStream_t s, March m, const float *vin, Guidance g, int W, int H, int Dloc, const float4 *g1_other,
-                       int d_begin, int cvc_mode, void *scratch, int *cnt = nullptr, const uint8_t *p4_own = nullptr,
-                       const uint8_t *p4_other = nullptr, int sel = 0, int step = 1);
-void launch_chunk_min(hipStream_t s, March m, int W, int H, int Dloc, void *scratch, long long *keys, uint8_t *map, int dynamic = 0);
-// Select mode with a shared key plane per volume (default): the packed minima over the local slices go straight to keys
-// (H*W per volume; both-volumes form: [2][H][W]) by 64-bit atomicMin - no chunk planes, no reduction kernel.
-void launch_cvf_select_keys(hipStream_t s, March m, const float *vin, Guidance g, int W, int H, int Dloc, const float4 *g1_other,
-                            int d_begin, int cvc_mode, long long *keys, const uint8_t *p4_own = nullptr, const uint8_t *p4_other = nullptr,
-                            int init = 1, int sel = 0, int step = 1);
+                       int d_begin, int cvc_mode, void *scratch, unsigned long long *ts = nullptr, const uint8_t *p4_own = nullptr,
+                       const uint8_t *p4_other = nullptr);
+void launch_chunk_min(hipStream_t s, March m, int W, int H, int Dloc, void *scratch, long long *keys, uint8_t *map);
+// both volumes per launch (costs on the fly): g[0] / g[1] = guidance of the left / right image; keys / map: [2][H][W];
+// Dloc slices, which ones: (sel, step) - 0: all, 1: every step-th, 2: the others
+void launch_cvf_select2(hipStream_t s, March m, const Guidance *g, int W, int H, int Dloc, int d_begin, void *scratch,
+                        unsigned long long *ts = nullptr, const uint8_t *const *p4 = nullptr, int sel = 0, int step = 1);
+void launch_chunk_min2sides(hipStream_t s, March m, int W, int H, int Dloc, void *scratch, long long *keys, uint8_t *map);
 void launch_cvf_select_keys2(hipStream_t s, March m, const Guidance *g, int W, int H, int Dloc, int d_begin, long long *keys,
-                             const uint8_t *const *p4 = nullptr, int init = 1, int sel = 0, int step = 1, int unit = 1);
-// both volumes per launch (costs on the fly): g[0] / g[1] = guidance of the left / right image; scratch: 2 x scratch_bytes();
-// keys / map: [2][H][W]
-void launch_cvf_select2(hipStream_t s, March m, const Guidance *g, int W, int H, int Dloc, int d_begin, void *scratch, int *cnt = nullptr,
-                        const uint8_t *const *p4 = nullptr, int sel = 0, int step = 1);
-void launch_chunk_min2sides(hipStream_t s, March m, int W, int H, int Dloc, void *scratch, long long *keys, uint8_t *map, int dynamic = 0);
-// Select mode with two columns per lane and the channels split over the waves (psm_q2.hip): the default product kernel
-// when the costs are built on the fly (cvc_mode 1 / 2).  scratch: q2_plan(...).scratch_bytes() bytes.
-PcPlan q2_plan(int W, int H, int Dloc, int seg_rows_opt);
-void launch_cvf_q2(hipStream_t s, March m, Guidance g, int W, int H, int Dloc, const float4 *g1_other, int d_begin, int cvc_mode,
-                   void *scratch);
-void launch_chunk_min2(hipStream_t s, March m, int W, int H, int Dloc, void *scratch, long long *keys, uint8_t *map);
-// two-columns-per-lane form of the fused filter (psm_pc2.hip); reads planar copies of the guidance (launch_soa:
-// 14 planes of H*W floats per side; only_g1: planes 0..3 only).  Needs W % 4 == 0.
-void launch_soa(hipStream_t s, Guidance g, int W, int H, float *soa, int only_g1);
-void launch_cvf_pc2(hipStream_t s, const float *vin, float *vout, const float *soa, const float *soa_other, int W, int H, int Dloc,
-                    int ybeg, int yend, int d_begin, int cvc_mode, int seg_rows);
+                             unsigned long long *ts = nullptr, const uint8_t *const *p4 = nullptr, int init = 1, int sel = 0, int step = 1);
 // plain 8x8 box filter of every slice (the north-star kernel in isolation)
 void launch_box8(hipStream_t s, int variant, March m, const float *vol, float *out, int W, int H, int Dloc);
 // WTA over local slices -> packed keys (keys != NULL) and/or final map (map != NULL)

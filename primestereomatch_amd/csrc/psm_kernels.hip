@@ -69,87 +69,15 @@ void launch_prep(hipStream_t s, const void *src, size_t pitch, int depth_f32, in
 
 // ------------------------------------------------------------------------------------------
 // guidance precompute (CVF::preprocess, src/CVF.cpp:44-70, + the d-invariant part of the solve,
-// src/CVF.cpp:120-132).  Two passes over 9 channels: I0,I1,I2,I0I0,I0I1,I0I2,I1I1,I1I2,I2I2.
+// src/CVF.cpp:120-132): 9 channels I0,I1,I2,I0I0,I0I1,I0I2,I1I1,I1I2,I2I2.  One wave marches a 56-column strip down a
+// segment of rows with nine sliding trees - the same machinery as the volume kernels.  (Round 1's two-pass form
+// wrote and re-read 149 MB of fp64 row sums per side; this work does not shrink when the job is sharded over GPUs.)
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_guide_h(const float4 *g1, int W, int H, double *hs9)
-{
-    int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
-    if (x >= W) return;
-    double t[9][8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        float4 g = g1[(size_t)y * W + r101(x - 4 + i, W)];
-        t[0][i] = g.x;
-        t[1][i] = g.y;
-        t[2][i] = g.z;
-        t[3][i] = __fmul_rn(g.x, g.x);
-        t[4][i] = __fmul_rn(g.x, g.y);
-        t[5][i] = __fmul_rn(g.x, g.z);
-        t[6][i] = __fmul_rn(g.y, g.y);
-        t[7][i] = __fmul_rn(g.y, g.z);
-        t[8][i] = __fmul_rn(g.z, g.z);
-    }
-    const size_t HW = (size_t)H * W;
-#pragma unroll
-    for (int c = 0; c < 9; ++c)
-        hs9[c * HW + (size_t)y * W + x] = t8(t[c][0], t[c][1], t[c][2], t[c][3], t[c][4], t[c][5], t[c][6], t[c][7]);
-}
-
-__global__ __launch_bounds__(256) void k_guide_v(const double *hs9, int W, int H, float4 *g2, float4 *g3, float2 *g4)
-{
-    int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
-    if (x >= W) return;
-    const size_t HW = (size_t)H * W;
-    int ry[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) ry[j] = r101(y - 4 + j, H);
-    float m[9];
-#pragma unroll
-    for (int c = 0; c < 9; ++c) {
-        const double *h = hs9 + c * HW + x;
-        m[c] = box_out(t8(h[(size_t)ry[0] * W], h[(size_t)ry[1] * W], h[(size_t)ry[2] * W], h[(size_t)ry[3] * W],
-                          h[(size_t)ry[4] * W], h[(size_t)ry[5] * W], h[(size_t)ry[6] * W], h[(size_t)ry[7] * W]));
-    }
-    // var_k = box(I_c*I_c') - mean_c*mean_c'   (src/CVF.cpp:58-68)
-    const float eps = 0.0001f;  // GIF_EPS, include/ComFunc.h:50
-    float v0 = __fsub_rn(m[3], __fmul_rn(m[0], m[0]));
-    float v1 = __fsub_rn(m[4], __fmul_rn(m[0], m[1]));
-    float v2 = __fsub_rn(m[5], __fmul_rn(m[0], m[2]));
-    float v3 = __fsub_rn(m[6], __fmul_rn(m[1], m[1]));
-    float v4 = __fsub_rn(m[7], __fmul_rn(m[1], m[2]));
-    float v5 = __fsub_rn(m[8], __fmul_rn(m[2], m[2]));
-    // src/CVF.cpp:120-128
-    float a11 = __fadd_rn(v0, eps), a12 = v1, a13 = v2;
-    float a21 = v1, a22 = __fadd_rn(v3, eps), a23 = v4;
-    float a31 = v2, a32 = v4, a33 = __fadd_rn(v5, eps);
-    // src/CVF.cpp:129-132
-    float X = __fsub_rn(__fmul_rn(a33, a22), __fmul_rn(a32, a23));
-    float Y = __fsub_rn(__fmul_rn(a33, a12), __fmul_rn(a32, a13));
-    float Z = __fsub_rn(__fmul_rn(a23, a12), __fmul_rn(a22, a13));
-    float det = __fadd_rn(__fsub_rn(__fmul_rn(a11, X), __fmul_rn(a21, Y)), __fmul_rn(a31, Z));
-    float inv = __fdiv_rn(1.0f, det);
-    // adjugate entries as written at src/CVF.cpp:133-147 (the matrix is symmetric, so the
-    // nine expressions take six distinct values bit for bit)
-    float A00 = __fsub_rn(__fmul_rn(a33, a22), __fmul_rn(a32, a23));
-    float A01 = __fsub_rn(__fmul_rn(a31, a23), __fmul_rn(a33, a21));
-    float A02 = __fsub_rn(__fmul_rn(a32, a21), __fmul_rn(a31, a22));
-    float A11 = __fsub_rn(__fmul_rn(a33, a11), __fmul_rn(a31, a13));
-    float A12 = __fsub_rn(__fmul_rn(a31, a12), __fmul_rn(a32, a11));
-    float A22 = __fsub_rn(__fmul_rn(a22, a11), __fmul_rn(a21, a12));
-    size_t o = (size_t)y * W + x;
-    g2[o] = make_float4(m[0], m[1], m[2], inv);
-    g3[o] = make_float4(A00, A01, A02, A11);
-    g4[o] = make_float2(A12, A22);
-}
-
-// Single-pass form of the two kernels above: one wave marches a 56-column strip down a 64-row segment
-// with nine sliding trees (I0,I1,I2 and the six products) - the same machinery as the volume kernels.
-// Replaces 149 MB of fp64 scratch traffic per side; matters because this work does not shrink when the
-// disparity range is sharded over GPUs.
 struct GuideM { float m[9]; };
 __device__ __forceinline__ void guide_finish(const float *m, float4 &g2, float4 &g3, float2 &g4)
-{   // identical arithmetic to k_guide_v (src/CVF.cpp:58-68,120-147)
-    const float eps = 0.0001f;
+{   // var_k = box(I_c*I_c') - mean_c*mean_c' (src/CVF.cpp:58-68); Sigma + eps I, DET (src/CVF.cpp:120-132); adjugate entries as
+    // written at src/CVF.cpp:133-147 (the matrix is symmetric, so the nine expressions take six distinct values bit for bit)
+    const float eps = 0.0001f;  // GIF_EPS, include/ComFunc.h:50
     float v0 = __fsub_rn(m[3], __fmul_rn(m[0], m[0]));
     float v1 = __fsub_rn(m[4], __fmul_rn(m[0], m[1]));
     float v2 = __fsub_rn(m[5], __fmul_rn(m[0], m[2]));
@@ -220,25 +148,19 @@ __global__ __launch_bounds__(64) void k_guide_march(const float4 *g1, int W, int
     }
 }
 
-void launch_guidance(hipStream_t s, Guidance g, double *hs9, int W, int H, int two_pass, const Guidance *second, int ybeg, int yend)
-{   // second != NULL (single-pass form only): the guidance of both images in one launch; [ybeg, yend) (single-pass form only,
-    // yend <= ybeg: all rows): the rows of g2..g4 to produce - a row stripe of the filter needs its own rows + 4 either side
-    if (!two_pass) {
-        if (yend <= ybeg) { ybeg = 0; yend = H; }
-        const int rows = yend - ybeg;
-        // one wave per (strip, segment): ~2048 waves over both images = one resident round (two per SIMD at 199 VGPRs), 8..64 rows each
-        const int nstrips = (W + 55) / 56;
-        const int waves = second ? 1024 : 2048;                  // per image
-        int seg_rows = 8;                                        // shortest segment whose waves fit one round
-        while (seg_rows < 64 && nstrips * ((rows + seg_rows - 1) / seg_rows) > waves) ++seg_rows;
-        const int nsegs = (rows + seg_rows - 1) / seg_rows;
-        hipLaunchKernelGGL(k_guide_march, dim3(nstrips * nsegs, second ? 2 : 1), dim3(64), 0, s, (const float4 *)g.g1, W, H, nstrips, seg_rows, g.g2, g.g3, g.g4,
-                           second ? *second : Guidance{}, ybeg, yend);
-        return;
-    }
-    dim3 grid((W + 255) / 256, H);
-    hipLaunchKernelGGL(k_guide_h, grid, dim3(256), 0, s, (const float4 *)g.g1, W, H, hs9);
-    hipLaunchKernelGGL(k_guide_v, grid, dim3(256), 0, s, (const double *)hs9, W, H, g.g2, g.g3, g.g4);
+void launch_guidance(hipStream_t s, Guidance g, int W, int H, const Guidance *second, int ybeg, int yend)
+{   // second != NULL: the guidance of both images in one launch; [ybeg, yend) (yend <= ybeg: all rows): the rows of g2..g4
+    // to produce - a row stripe of the filter needs its own rows + 4 either side
+    if (yend <= ybeg) { ybeg = 0; yend = H; }
+    const int rows = yend - ybeg;
+    // one wave per (strip, segment): ~2048 waves over both images = one resident round (two per SIMD at 199 VGPRs), 8..64 rows each
+    const int nstrips = (W + 55) / 56;
+    const int waves = 8 * pc_dev().nxcd * pc_dev().cus_per_xcd / (second ? 2 : 1);   // per image
+    int seg_rows = 8;                                        // shortest segment whose waves fit one round
+    while (seg_rows < 64 && nstrips * ((rows + seg_rows - 1) / seg_rows) > waves) ++seg_rows;
+    const int nsegs = (rows + seg_rows - 1) / seg_rows;
+    hipLaunchKernelGGL(k_guide_march, dim3(nstrips * nsegs, second ? 2 : 1), dim3(64), 0, s, (const float4 *)g.g1, W, H, nstrips, seg_rows, g.g2, g.g3, g.g4,
+                       second ? *second : Guidance{}, ybeg, yend);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -314,7 +236,7 @@ __global__ __launch_bounds__(256) void k_cvc_t(const float4 *__restrict__ base, 
 }
 
 void launch_cvc(hipStream_t s, const float4 *g1_base, const float4 *g1_other, float *vol, int W, int H,
-                int d_begin, int Dloc, int right, int flags, int ybeg, int yend)
+                int d_begin, int Dloc, int right, int ybeg, int yend)
 {
     if (yend <= ybeg) return;
     const int rows = yend - ybeg;
@@ -325,7 +247,7 @@ void launch_cvc(hipStream_t s, const float4 *g1_base, const float4 *g1_other, fl
         if (right) hipLaunchKernelGGL(KERNEL<true>, grid, dim3(256), 0, s, g1_base, g1_other, vol, W, H, d_begin, Dloc, ybeg); \
         else hipLaunchKernelGGL(KERNEL<false>, grid, dim3(256), 0, s, g1_base, g1_other, vol, W, H, d_begin, Dloc, ybeg);      \
     }
-    if (!(flags & 64) && (W & 3) == 0) PSM_LAUNCH_CVC(k_cvc_t, (W + 255) / 256)
+    if ((W & 3) == 0) PSM_LAUNCH_CVC(k_cvc_t, (W + 255) / 256)   // (k_cvc: widths that are not a multiple of 4)
     else PSM_LAUNCH_CVC(k_cvc, (W + 255) / 256)
 #undef PSM_LAUNCH_CVC
 }
@@ -342,46 +264,22 @@ struct MarchPos {
     bool ok, ovalid;
 };
 
-// Block -> (column strip, y segment, slice group).  Blocks are observed to be dispatched
-// round-robin over the 8 XCDs (block b -> XCD b%8); every XCD gets a contiguous range of
-// (strip,segment) pairs and walks the slice groups of one pair back to back, so the pair's
-// guidance stays in that XCD's L2 while all D slices stream past it.  Speed only - nothing
-// depends on the placement.
-// Block -> (column strip, y segment, slice group).  Blocks are observed to be dispatched in id
-// order, round-robin over the 8 XCDs (block b -> XCD b%8).  `order` picks the traversal:
-//   0: every XCD owns a contiguous range of (strip,segment) pairs and walks the slice groups of
-//      one pair back to back (guidance stays in that XCD's L2; DRAM sees 1000+ scattered streams)
-//   1: every XCD owns a contiguous range of strips; ids sweep strips fastest, then slice groups,
-//      then segments: all XCDs work on the same rows of the same slices at the same time (whole
-//      image rows are fetched together -> DRAM page locality) and an XCD still re-uses the
-//      guidance of its few strips for every slice group.
-//   2: as 1 but segments before slice groups.
-// Speed only - nothing depends on the placement.
+// Block -> (column strip, y segment, slice group).  Blocks are observed to be dispatched round-robin over the XCDs
+// (block b -> XCD b % nxcd); every XCD gets a contiguous range of (strip, segment) pairs and walks the slice groups of
+// one pair back to back, so the pair's guidance stays in that XCD's L2 while all D slices stream past it.  Speed only -
+// nothing depends on the placement.
 template <int NW>
-__device__ __forceinline__ MarchPos march_pos(int W, int ybeg, int yend, int Dloc, int nstrips, int nsegs, int seg_rows, int nzg, int order)
+__device__ __forceinline__ MarchPos march_pos(int W, int ybeg, int yend, int Dloc, int nstrips, int nsegs, int seg_rows, int nzg, int nxcd)
 {
     MarchPos p;
-    int id = blockIdx.x;
-    int xcd = id & 7, j = id >> 3;
-    int zg, strip, seg;
-    bool ok;
-    if (order == 0) {
-        const int npairs = nstrips * nsegs;
-        const int p8 = (npairs + 7) >> 3;
-        zg = j % nzg;
-        int pl = j / nzg;
-        int pair = xcd * p8 + pl;
-        ok = pl < p8 && pair < npairs;
-        strip = pair % nstrips;
-        seg = pair / nstrips;
-    } else {
-        const int s8 = (nstrips + 7) >> 3;   // strips per XCD
-        int sl = j % s8, rest = j / s8;
-        strip = xcd * s8 + sl;
-        if (order == 1) { zg = rest % nzg; seg = rest / nzg; }
-        else            { seg = rest % nsegs; zg = rest / nsegs; }
-        ok = strip < nstrips && seg < nsegs && zg < nzg;
-    }
+    const int id = blockIdx.x;
+    const int xcd = id % nxcd, j = id / nxcd;
+    const int npairs = nstrips * nsegs;
+    const int ppx = (npairs + nxcd - 1) / nxcd;
+    const int zg = j % nzg, pl = j / nzg;
+    const int pair = xcd * ppx + pl;
+    const bool ok = pl < ppx && pair < npairs;
+    const int strip = pair % nstrips, seg = pair / nstrips;
     int wave = threadIdx.x >> 6;
     p.lane = threadIdx.x & 63;
     p.d = zg * NW + wave;
@@ -405,27 +303,17 @@ __device__ __forceinline__ MarchPos march_pos(int W, int ybeg, int yend, int Dlo
 // registers of step s.  vmcnt retires in order, so the only wait per step is for data issued
 // three steps earlier; with 3-4 waves per SIMD that covers the HBM/L2 latency.  The 4-slot
 // register rings are indexed with compile-time constants (unroll by 4).
-//
-// Store policy: a wave-wide dword store reaches the L2 as four 64-byte partial-line writes and
-// each allocates the line with a fill read from HBM (measured: k_cvc read as many bytes as it
-// wrote).  NT = nontemporal stores for the 4-byte-per-lane outputs.
 typedef float f4v __attribute__((ext_vector_type(4)));
-template <bool NT>
-__device__ __forceinline__ void store_f32(float *p, float v)
-{
-    if (NT) __builtin_nontemporal_store(v, p); else *p = v;
-}
 
 // ---- stage A: p -> (a0,a1,a2,b) -------------------------------------------------------------
 template <int NW>
 __global__ __launch_bounds__(NW * 64) void k_cvf_a(const float *__restrict__ vol, float4 *__restrict__ ab,
                                                   const float4 *__restrict__ G1, const float4 *__restrict__ G2,
                                                   const float4 *__restrict__ G3, const float2 *__restrict__ G4,
-                                                  int W, int H, int Dloc, int nstrips, int nsegs, int seg_rows, int nzg, int order,
+                                                  int W, int H, int Dloc, int nstrips, int nsegs, int seg_rows, int nzg, int nxcd,
                                                   int ybeg, int yend)
 {
-    const bool nt_store = (order & 4) != 0;
-    const MarchPos pos = march_pos<NW>(W, ybeg, yend, Dloc, nstrips, nsegs, seg_rows, nzg, order & 3);
+    const MarchPos pos = march_pos<NW>(W, ybeg, yend, Dloc, nstrips, nsegs, seg_rows, nzg, nxcd);
     if (!pos.ok) return;
     PSM_LANE_IDX();
     const size_t HW = (size_t)H * W;
@@ -468,9 +356,7 @@ __global__ __launch_bounds__(NW * 64) void k_cvf_a(const float *__restrict__ vol
         double n0 = vstep<K>(t0, h0), n1 = vstep<K>(t1, h1), n2 = vstep<K>(t2, h2), n3 = vstep<K>(t3, h3); \
         float4 r = solve_ab(box_out(n0), box_out(n1), box_out(n2), box_out(n3), o2[K], o3[K], o4[K]); \
         if (step >= 7 && step < n && pos.ovalid) {                                                  \
-            float4 *dst_ = abd + (size_t)(ybase + step - 3) * W + pos.xo;                           \
-            if (nt_store) { f4v rv_ = {r.x, r.y, r.z, r.w}; __builtin_nontemporal_store(rv_, (f4v *)dst_); } \
-            else *dst_ = r;                                                                         \
+            abd[(size_t)(ybase + step - 3) * W + pos.xo] = r;                                       \
         }                                                                                           \
         __builtin_amdgcn_sched_barrier(0);                                                          \
     }
@@ -480,7 +366,7 @@ __global__ __launch_bounds__(NW * 64) void k_cvf_a(const float *__restrict__ vol
 #undef PSM_ISSUE_A
 }
 
-// ---- kernels with 4-byte outputs (stage B, plain box) ------------------------------------------
+// ---- plain box filter: 4-byte outputs -----------------------------------------------------------
 // A wave-row of 56 floats is 224 bytes: 1.75 cache lines at an odd offset.  Written straight from
 // the lanes it costs partial-line writes plus a fill read per line (measured ~3 TB/s).  So the four
 // waves of a workgroup take four ADJACENT strips of one slice (224 columns = 7 full 128-byte lines),
@@ -535,57 +421,6 @@ __device__ __forceinline__ void flush_rows_x4(float *lds_buf, const float (&qb)[
                 if (pos.xg + c < W) row[c] = lds_buf[pos.wave * X4_COLS + c];
         }
     }
-}
-
-// ---- stage B: (a0,a1,a2,b) -> q -------------------------------------------------------------
-template <bool VEC4>
-__global__ __launch_bounds__(256) void k_cvf_b(const float4 *__restrict__ ab, float *__restrict__ vol,
-                                              const float4 *__restrict__ G1, int W, int H, int Dloc,
-                                              int ngroups, int nsegs, int seg_rows, int ybeg, int yend)
-{
-    __shared__ __attribute__((aligned(16))) float lds[2][4 * X4_COLS];
-    const MarchPosX4 pos = march_pos_x4(W, ybeg, yend, Dloc, ngroups, nsegs, seg_rows);
-    if (!pos.ok) return;
-    PSM_LANE_IDX();
-    const size_t HW = (size_t)H * W;
-    const float4 *abd = ab + (size_t)pos.d * HW;
-    float *vd = vol + (size_t)pos.d * HW;
-    VTree t0 = {}, t1 = {}, t2 = {}, t3 = {};
-    const int n = (pos.y1 - pos.y0) + 7;
-    const int ybase = pos.y0 - 4;
-    const int xoc = min(pos.xo, W - 1);
-
-    float4 ain[4];   // (a0,a1,a2,b) at (input row, input column)
-    float4 o1[4];    // g1 at (output row, output column)
-#define PSM_ISSUE_B(SLOT, STEP)                                                         \
-    {                                                                                   \
-        ain[SLOT] = abd[(size_t)r101c(ybase + (STEP), H) * W + pos.cs];                 \
-        int yo_ = ybase + (STEP) - 3;                                                   \
-        yo_ = yo_ < 0 ? 0 : (yo_ > H - 1 ? H - 1 : yo_);                                \
-        o1[SLOT] = G1[(size_t)yo_ * W + xoc];                                           \
-    }
-    PSM_ISSUE_B(0, 0) __builtin_amdgcn_sched_barrier(0);
-    PSM_ISSUE_B(1, 1) __builtin_amdgcn_sched_barrier(0);
-    PSM_ISSUE_B(2, 2) __builtin_amdgcn_sched_barrier(0);
-    for (int i = 0; i < n; i += 4) {
-        float qb[4];
-#define PSM_STEP_B(K)                                                                               \
-    {                                                                                               \
-        const int step = i + K;                                                                     \
-        PSM_ISSUE_B((K + 3) & 3, step + 3)                                                          \
-        double h0 = hsum8(ain[K].x, i1, i2, i4);                                                    \
-        double h1 = hsum8(ain[K].y, i1, i2, i4);                                                    \
-        double h2 = hsum8(ain[K].z, i1, i2, i4);                                                    \
-        double h3 = hsum8(ain[K].w, i1, i2, i4);                                                    \
-        double n0 = vstep<K>(t0, h0), n1 = vstep<K>(t1, h1), n2 = vstep<K>(t2, h2), n3 = vstep<K>(t3, h3); \
-        qb[K] = recombine(box_out(n0), box_out(n1), box_out(n2), box_out(n3), o1[K]);               \
-        __builtin_amdgcn_sched_barrier(0);                                                          \
-    }
-        PSM_STEP_B(0) PSM_STEP_B(1) PSM_STEP_B(2) PSM_STEP_B(3)
-#undef PSM_STEP_B
-        flush_rows_x4<VEC4>(lds[(i >> 2) & 1], qb, pos, vd, W, ybase, i, n);
-    }
-#undef PSM_ISSUE_B
 }
 
 // ---- plain box filter of every slice ----------------------------------------------------------
@@ -710,7 +545,7 @@ __global__ __launch_bounds__(256) void k_box8_direct(const float *__restrict__ v
 }
 
 struct MarchGrid {
-    int nstrips, nsegs, seg_rows, nzg, nblocks, order;
+    int nstrips, nsegs, seg_rows, nzg, nblocks, nxcd;
 };
 static MarchGrid march_grid(March m, int W, int H, int Dloc)
 {   // H = number of output rows of this launch
@@ -723,14 +558,8 @@ static MarchGrid march_grid(March m, int W, int H, int Dloc)
     if (g.seg_rows > H) g.seg_rows = H;
     g.nsegs = (H + g.seg_rows - 1) / g.seg_rows;
     g.nzg = (Dloc + m.waves - 1) / m.waves;
-    g.order = (m.flags >> 1) & 3;
-    if (g.order == 3) g.order = 0;
-    if (g.order == 0) {
-        int npairs = g.nstrips * g.nsegs;
-        g.nblocks = 8 * ((npairs + 7) / 8) * g.nzg;
-    } else {
-        g.nblocks = 8 * ((g.nstrips + 7) / 8) * g.nsegs * g.nzg;
-    }
+    g.nxcd = pc_dev().nxcd;
+    g.nblocks = g.nxcd * ((g.nstrips * g.nsegs + g.nxcd - 1) / g.nxcd) * g.nzg;
     return g;
 }
 
@@ -740,17 +569,6 @@ static MarchGrid march_grid(March m, int W, int H, int Dloc)
     case 2: hipLaunchKernelGGL(KERNEL<2>, dim3(g.nblocks), dim3(128), 0, s, __VA_ARGS__); break;        \
     case 8: hipLaunchKernelGGL(KERNEL<8>, dim3(g.nblocks), dim3(512), 0, s, __VA_ARGS__); break;        \
     default: hipLaunchKernelGGL(KERNEL<4>, dim3(g.nblocks), dim3(256), 0, s, __VA_ARGS__); break;       \
-    }
-#define PSM_DISPATCH_NW_NT(NWV, NTV, KERNEL, ...)                                                                          \
-    switch ((NWV) * 2 + ((NTV) ? 1 : 0)) {                                                                                 \
-    case 2: hipLaunchKernelGGL(HIP_KERNEL_NAME(KERNEL<1, false>), dim3(g.nblocks), dim3(64), 0, s, __VA_ARGS__); break;    \
-    case 3: hipLaunchKernelGGL(HIP_KERNEL_NAME(KERNEL<1, true>), dim3(g.nblocks), dim3(64), 0, s, __VA_ARGS__); break;     \
-    case 4: hipLaunchKernelGGL(HIP_KERNEL_NAME(KERNEL<2, false>), dim3(g.nblocks), dim3(128), 0, s, __VA_ARGS__); break;   \
-    case 5: hipLaunchKernelGGL(HIP_KERNEL_NAME(KERNEL<2, true>), dim3(g.nblocks), dim3(128), 0, s, __VA_ARGS__); break;    \
-    case 16: hipLaunchKernelGGL(HIP_KERNEL_NAME(KERNEL<8, false>), dim3(g.nblocks), dim3(512), 0, s, __VA_ARGS__); break;  \
-    case 17: hipLaunchKernelGGL(HIP_KERNEL_NAME(KERNEL<8, true>), dim3(g.nblocks), dim3(512), 0, s, __VA_ARGS__); break;   \
-    case 9: hipLaunchKernelGGL(HIP_KERNEL_NAME(KERNEL<4, true>), dim3(g.nblocks), dim3(256), 0, s, __VA_ARGS__); break;    \
-    default: hipLaunchKernelGGL(HIP_KERNEL_NAME(KERNEL<4, false>), dim3(g.nblocks), dim3(256), 0, s, __VA_ARGS__); break;  \
     }
 
 static int norm_waves(int w) { return (w == 1 || w == 2 || w == 8) ? w : 4; }
@@ -768,25 +586,13 @@ void launch_cvf_a(hipStream_t s, int variant, March m, const float *vol, float4 
     m.waves = norm_waves(m.waves);
     MarchGrid g = march_grid(m, W, yend - ybeg, Dloc);
     PSM_DISPATCH_NW(m.waves, k_cvf_a, vol, ab, (const float4 *)gd.g1, (const float4 *)gd.g2, (const float4 *)gd.g3,
-                    (const float2 *)gd.g4, W, H, Dloc, g.nstrips, g.nsegs, g.seg_rows, g.nzg, g.order | ((m.flags & 1) ? 4 : 0), ybeg, yend)
+                    (const float2 *)gd.g4, W, H, Dloc, g.nstrips, g.nsegs, g.seg_rows, g.nzg, g.nxcd, ybeg, yend)
 }
 
-void launch_cvf_b(hipStream_t s, int variant, March m, const float4 *ab, float *vol, Guidance gd, int W, int H, int Dloc,
-                  int ybeg, int yend)
+void launch_cvf_b_direct(hipStream_t s, const float4 *ab, float *vol, Guidance gd, int W, int H, int Dloc)
 {
-    if (yend <= ybeg) return;
-    if (variant == 1) {
-        dim3 grid((W + 255) / 256, H, Dloc);
-        hipLaunchKernelGGL(k_cvf_b_direct, grid, dim3(256), 0, s, ab, vol, (const float4 *)gd.g1, W, H);
-        return;
-    }
-    MarchGrid g = march_grid(m, W, yend - ybeg, Dloc);
-    const int ngroups = (W + X4_COLS - 1) / X4_COLS;
-    const int nblocks = ngroups * Dloc * g.nsegs;
-    if ((W & 3) == 0)
-        hipLaunchKernelGGL(k_cvf_b<true>, dim3(nblocks), dim3(256), 0, s, ab, vol, (const float4 *)gd.g1, W, H, Dloc, ngroups, g.nsegs, g.seg_rows, ybeg, yend);
-    else
-        hipLaunchKernelGGL(k_cvf_b<false>, dim3(nblocks), dim3(256), 0, s, ab, vol, (const float4 *)gd.g1, W, H, Dloc, ngroups, g.nsegs, g.seg_rows, ybeg, yend);
+    dim3 grid((W + 255) / 256, H, Dloc);
+    hipLaunchKernelGGL(k_cvf_b_direct, grid, dim3(256), 0, s, ab, vol, (const float4 *)gd.g1, W, H);
 }
 
 void launch_box8(hipStream_t s, int variant, March m, const float *vol, float *out, int W, int H, int Dloc)

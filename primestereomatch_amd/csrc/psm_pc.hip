@@ -63,22 +63,13 @@ typedef float f4v __attribute__((ext_vector_type(4)));
 #ifndef PSM_PC_ATTR
 #define PSM_PC_ATTR
 #endif
-// Occupancy of the key form (MODE 2, 5/6 of the slices of a 256-slice volume): four workgroups per CU instead of three.
+// Occupancy of the key form (MODE 2, 4/5 of the slices of a 256-slice volume): four workgroups per CU instead of three.
 // The kernel is latency-sensitive at 3 waves per SIMD (barrier waits, LDS round trips); 128 VGPRs need a shorter load
-// look-ahead (PSM_PC_LEAN bit 0: consumer G1 / keys two rows ahead instead of a batch; bit 1: producer guidance planes issued
-// at the start of their own step, partner pixels right after the cost is formed) and cost 4 spilled registers per producer batch.
-// Measured at 1080p x 256: key phase 6.36 -> 5.86 ms (PSM_PC_LEAN 1 or 3; 0 with the cap: 65 spills, 12.7 ms per frame).
-// PSM_PC_OCC4 == 2 caps the plane form (MODE 1) as well; its own register diet (PSM_PC_LEAN bits 4-7: G1 two rows ahead, the
-// producer changes, selection row by row inside the steps, role constants recomputed per slice from an opaque lane index so
-// that they do not stay alive through the other role's code) gets it from 159 to 139 registers / 9 spills under the cap, but
-// there the shorter look-ahead costs what the fourth workgroup gains (720p x 128 1.91 vs 1.92 ms, 450 x 375 x 64 0.32 vs 0.31,
-// 8-bit 450 x 375 0.45 vs 0.32): off by default.
-#ifndef PSM_PC_OCC4
-#define PSM_PC_OCC4 1
-#endif
-#ifndef PSM_PC_LEAN
-#define PSM_PC_LEAN 3
-#endif
+// look-ahead - consumer: G1 / keys two rows ahead instead of a batch, selection row by row inside the steps; producer: guidance
+// planes issued at the start of their own step, partner pixels right after the cost is formed - and cost 4 spilled registers
+// per producer batch.  Measured at 1080p x 256: key phase 6.36 -> 5.86 ms (the same cap without the diet: 65 spills, 12.7 ms
+// per frame).  The plane form (MODE 1) stays at three workgroups per CU: its own diet got it from 159 to 139 registers / 9
+// spills under the cap, but there the shorter look-ahead costs what the fourth workgroup gains.
 constexpr int PC_RING = 4;   // batches of four model rows kept in LDS
 #ifndef PSM_PC_NT
 #define PSM_PC_NT 1          // MODE 0: nontemporal stores of the output rows (the volume is next read long after it left the L2)
@@ -92,9 +83,6 @@ template <> struct PcLayout<2> : PcLayout<1> {};
 #define PSM_K_LD_AUX 0       // cache policy of MODE 1's record loads.  A record is only ever read by the lane that wrote it
 #endif                       // (one slice earlier), and a thread always observes its own stores: plain cached loads are
                              // coherent here.  (16 = sc1 bypasses the L2 as well: measured 25 % slower kernel.)
-#ifndef PSM_KEY_NOATOMIC
-#define PSM_KEY_NOATOMIC 0   // experiment (invalid results): skip the atomics
-#endif
 #ifndef PSM_KEY_LD_AUX
 #define PSM_KEY_LD_AUX 16    // cache policy of MODE 2's key loads: 16 = sc1 (agent scope: never from this CU's L1)
 #endif
@@ -141,24 +129,17 @@ struct PcSide {
     unsigned *kdisp;
 };
 
-// MODE 1, dynamic form: NW workgroups per (column group, segment) pair, all resident at once, take the pair's slices one
-// after the other from a device counter (ascending d) and keep their running minima in ONE plane each - NW planes per
-// volume instead of Dloc / DC, all workgroups finish within one slice of each other (no tail), and stores to the plane
-// become rare (a lane rewrites its record only when one of its four rows improved).  cnt == NULL: static chunks of DC.
-struct PcDyn {
-    int *cnt;      // one zeroed counter per (side, pair)
-    int NW;
-    // Which local slices this launch covers (Dloc = their number): sel 0 all (index i = local slice i); sel 1 every
-    // step-th slice (i -> i * step); sel 2 the others (i -> (i / (step-1)) * step + i % (step-1) + 1).  Two-phase
-    // selection: a first launch reduces every step-th slice to the key plane, a MODE 2 launch then runs the rest
-    // against that plane - its consumer lanes find a tight bound there and issue an atomic only a few times per pixel.
-    // unit > 1 (sel 2 only): the same pattern in units of `unit` slices - the multiples of unit that are not multiples of
-    // unit * step (a middle phase of a three-phase selection).
-    int sel, step, unit;
+// Which local slices a launch covers (Dloc = their number): sel 0 all (index i = local slice i); sel 1 every step-th slice
+// (i -> i * step); sel 2 the others (i -> (i / (step-1)) * step + i % (step-1) + 1).  Two-phase selection: a first launch
+// reduces every step-th slice to the key plane, a MODE 2 launch then runs the rest against that plane - its consumer lanes
+// find a tight bound there and issue an atomic only a few times per pixel.
+struct PcSel {
+    int sel, step;
+    int nxcd;      // XCDs of the device (blocks are dispatched round-robin over them)
 };
-__device__ __forceinline__ int pc_slice(const PcDyn &o, int i)
+__device__ __forceinline__ int pc_slice(const PcSel &o, int i)
 {
-    return o.sel == 1 ? i * o.step : (o.sel == 2 ? ((i / (o.step - 1)) * o.step + i % (o.step - 1) + 1) * o.unit : i);
+    return o.sel == 1 ? i * o.step : (o.sel == 2 ? (i / (o.step - 1)) * o.step + i % (o.step - 1) + 1 : i);
 }
 
 // CVC = 0: the cost slice is read from `vin`.  CVC = 1 (left volume) / 2 (right volume): the cost volume is never
@@ -171,14 +152,12 @@ __device__ __forceinline__ int pc_slice(const PcDyn &o, int i)
 // of oracle/psm_oracle.h, in one pass and without an 8-bit volume in memory.
 template <bool VEC4, int CVC, int MODE, bool U8 = false>
 __global__ __launch_bounds__(64 * (PcLayout<MODE>::NA + PcLayout<MODE>::NB)) PSM_PC_ATTR
-#if PSM_PC_OCC4   // the key form (MODE 2) capped at 128 VGPRs = four workgroups per CU
-__attribute__((amdgpu_waves_per_eu((MODE == 2 || (MODE == 1 && PSM_PC_OCC4 == 2)) ? 4 : 1, (MODE == 2 || (MODE == 1 && PSM_PC_OCC4 == 2)) ? 4 : 8)))
-#endif
+__attribute__((amdgpu_waves_per_eu(MODE == 2 ? 4 : 1, MODE == 2 ? 4 : 8)))   // the key form capped at 128 VGPRs = four workgroups per CU
 void k_cvf_pc(
     const float *__restrict__ vin, float *__restrict__ vout, const float4 *__restrict__ G1a, const float4 *__restrict__ G2a,
     const float4 *__restrict__ G3a, const float2 *__restrict__ G4a, int W, int H, int Dloc, int ngroups, int nsegs, int seg_rows,
     int ybeg, int yend, const float4 *__restrict__ Gothera, int d_begin, int DC, float *__restrict__ kcosta, unsigned *__restrict__ kdispa, int nbmax,
-    PcSide side1, PcDyn dyn)
+    PcSide side1, PcSel dyn, unsigned long long *__restrict__ ts)
 {
     const bool right = CVC == 2 || (CVC == 3 && blockIdx.y == 1);      // buildCV_right arithmetic (uniform)
     const bool s1 = CVC == 3 && blockIdx.y == 1;
@@ -208,24 +187,24 @@ void k_cvf_pc(
     // the top and bottom of the image, which are earlier/later rows of the same ring - is still present.
     __shared__ __attribute__((aligned(16))) float4 ring[PC_RING][4][PC_MCOLS];
     __shared__ __attribute__((aligned(16))) float qbuf[MODE == 0 ? 2 : 1][MODE == 0 ? 4 : 1][MODE == 0 ? PC_COLS : 4];   // MODE 0: output rows, two batches
-    // Workgroup -> (column group, segment, slice chunk).  Blocks are observed to go round-robin over the 8 XCDs
-    // (block b -> XCD b%8): every XCD owns a contiguous range of (group, segment) pairs and walks the
+    // Workgroup -> (column group, segment, slice chunk).  Blocks are observed to go round-robin over the XCDs
+    // (block b -> XCD b % nxcd): every XCD owns a contiguous range of (group, segment) pairs and walks the
     // chunks of one pair back to back, so the guidance rows its resident workgroups are reading (few
     // pairs, neighbouring rows, many slices) fit its 4 MB L2 instead of coming from the MALL.  Speed only.
-#ifndef PSM_PC_NODYN
-#define PSM_PC_NODYN 0
-#endif
-    const bool dynamic = !PSM_PC_NODYN && MODE == 1 && dyn.cnt != nullptr;
-    const int nchunks = dynamic ? dyn.NW : (Dloc + DC - 1) / DC;
+    const int nchunks = (Dloc + DC - 1) / DC;
     int id = blockIdx.x;
     const int npairs = ngroups * nsegs;               // (column group, segment) pairs
-    // work items (pair, chunk), pair-major; XCD x takes the x-th eighth of them: a contiguous range of pairs whose chunks
+    // work items (pair, chunk), pair-major; XCD x takes the x-th share of them: a contiguous range of pairs whose chunks
     // run back to back, and equal work per XCD whatever the pair count
     const int nitems = npairs * nchunks;
-    const int ipx = (nitems + 7) >> 3;
-    const int xcd = id & 7, jj = id >> 3;
+    const int ipx = (nitems + dyn.nxcd - 1) / dyn.nxcd;
+    const int xcd = id % dyn.nxcd, jj = id / dyn.nxcd;
     const int item = xcd * ipx + jj;
     if (jj >= ipx || item >= nitems) return;
+    if (ts != nullptr && threadIdx.x == 0) {          // PSM_OPT_PROFILE 2: when did the first workgroup of this launch start
+        (void)__hip_atomic_fetch_min(ts, (unsigned long long)wall_clock64(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (blockIdx.x == 0 && blockIdx.y == 0) ts[2 * PC_TS_SLOTS] = (unsigned long long)MODE;
+    }
     const int pair = item / nchunks, ch = item % nchunks;
     const int g = pair % ngroups, seg = pair / ngroups;
     // (which hardware wave takes which role does not matter: swapping / interleaving the producer and consumer
@@ -249,29 +228,16 @@ void k_cvf_pc(
     unsigned long long q_work = 0, q_wait = 0, q_mark = __builtin_readcyclecounter();
 #endif
     const int nds = MODE == 1 ? DC : 1;               // MODE 0 / 2 always run with DC == 1 (one slice per workgroup)
-    __shared__ int s_next;
     bool first = true;                                // no slice processed yet: the plane holds nothing
-    for (int ds = 0; ; ++ds) {                        // the slices of this chunk / this workgroup's share of the pair, ascending d
-    int d;
-    if (MODE == 1 && dynamic) {
-        if (threadIdx.x == 0) s_next = atomicAdd(dyn.cnt + (s1 ? npairs : 0) + pair, 1);
-        __syncthreads();                              // (the next write of s_next is many barriers away)
-        d = __builtin_amdgcn_readfirstlane(s_next);
-    } else {
-        if (ds >= nds) break;
-        d = ch * DC + ds;
-    }
+    for (int ds = 0; ds < nds; ++ds) {                // the slices of this chunk, ascending d
+    const int d = ch * DC + ds;
     if (MODE == 1 && d >= Dloc) break;                // uniform over the workgroup
     if (is_a) {
         // ---------------- producer: stage A ----------------
         // step s reads input row mstart-5+s; from step 8 on it yields model row mstart+(s-8)
         const int xa0 = xm0 + wave * PC_OUT_A;        // first model column of this wave
-        // (plane form, several slices per workgroup: the per-lane constants of a role are recomputed per slice from an opaque
-        // copy of the lane index - hoisted out of the slice loop they would stay alive through the other role's code)
-        int lane_r = lane;
-        if (MODE == 1 && (PSM_PC_LEAN & 128)) asm volatile("" : "+v"(lane_r));
-        const int ci = r101c(xa0 - 4 + lane_r, W);    // input column of this lane
-        const int xa = xa0 + lane_r;                  // model column of this lane
+        const int ci = r101c(xa0 - 4 + lane, W);      // input column of this lane
+        const int xa = xa0 + lane;                    // model column of this lane
         const int xac = xa < 0 ? 0 : (xa > W - 1 ? W - 1 : xa);
         const bool mvalid = lane < PC_OUT_A;
         const float *vd = vin + (size_t)pc_slice(dyn, d) * HW;
@@ -284,7 +250,7 @@ void k_cvf_pc(
         float pin[2];
         float4 oth[2], gin[2], o2[2], o3[2];
         float2 o4[2];
-        constexpr bool LEANA = (PSM_PC_LEAN & 2) != 0 && (MODE == 2 || (MODE == 1 && (PSM_PC_LEAN & 32)));
+        constexpr bool LEANA = MODE == 2;             // short look-ahead (128-VGPR diet of the key form)
         // raw buffer loads: descriptors and row offsets in scalar registers, one constant 32-bit byte offset per lane
         // (psm_create keeps W*H < 2^27, so every byte offset into a 16-byte plane fits 31 bits)
         const __amdgpu_buffer_rsrc_t rG1 = pc_rsrc(G1, (unsigned)HW * 16u), rG2 = pc_rsrc(G2, (unsigned)HW * 16u);
@@ -314,7 +280,7 @@ void k_cvf_pc(
             o4[SLOT] = pc_load2(rG4, vxa >> 1, oa_ * 8);                                \
         }                                                                               \
     }
-#define PSM_ISSUE_PA2(STEP)   /* PSM_PC_LEAN: the guidance planes of step STEP, issued when the step starts */ \
+#define PSM_ISSUE_PA2(STEP)   /* key form: the guidance planes of step STEP, issued when the step starts */ \
     {                                                                                   \
         int ya_ = mstart - 8 + (STEP);                                                  \
         ya_ = ya_ < 0 ? 0 : (ya_ > H - 1 ? H - 1 : ya_);                                \
@@ -390,12 +356,10 @@ void k_cvf_pc(
         const int wb = wave - PC_NA;
         const int bwidth = wb < PC_NB - 1 ? PC_OUT_B : PC_COLS - (PC_NB - 1) * PC_OUT_B;
         const int xb0 = xg + wb * PC_OUT_B;           // first output column of this wave
-        int lane_r = lane;                            // (see the producer branch)
-        if (MODE == 1 && (PSM_PC_LEAN & 128)) asm volatile("" : "+v"(lane_r));
-        const int xmod = xb0 - 4 + lane_r;            // model column this lane consumes
+        const int xmod = xb0 - 4 + lane;              // model column this lane consumes
         int mc = r101(xmod, W) - xm0;                 // REFLECT_101 of the model planes, as ring column
         mc = mc < 0 ? 0 : (mc > PC_MCOLS - 1 ? PC_MCOLS - 1 : mc);
-        const int xb = xb0 + lane_r;                  // output column of this lane
+        const int xb = xb0 + lane;                    // output column of this lane
         const int xbc = min(xb, W - 1);
         float *od = vout + (MODE == 0 ? (size_t)pc_slice(dyn, d) * HW : 0);
         const int amax = 4 * nbA - 1;
@@ -420,22 +384,12 @@ void k_cvf_pc(
         long long *const keyp = reinterpret_cast<long long *>(kcost);
         const __amdgpu_buffer_rsrc_t rKy = pc_rsrc(MODE == 2 ? (const void *)keyp : (const void *)G1, (unsigned)HW * 8u);
         long long kcur[4] = {0, 0, 0, 0};
-        float acc_dbg = 0.f; (void)acc_dbg;
-#define PSM_KEY_LOAD1(SLOT, J)   /* PSM_PC_LEAN: the key of feed row J alone */                     \
+#define PSM_KEY_LOAD1(SLOT, J)   /* the key of feed row J */                                         \
     {                                                                                              \
         int yk_ = y0 + (J) - 7;                                                                    \
         yk_ = yk_ < 0 ? 0 : (yk_ > H - 1 ? H - 1 : yk_);                                           \
         const pc_u2 v_ = __builtin_amdgcn_raw_buffer_load_b64(rKy, xbc * 8, yk_ * W * 8, PSM_KEY_LD_AUX); \
         kcur[SLOT] = (long long)(((unsigned long long)v_.y << 32) | v_.x);                         \
-    }
-#define PSM_KEY_LOAD(C)                                                                            \
-    {                                                                                              \
-        _Pragma("unroll") for (int k_ = 0; k_ < 4; ++k_) {                                         \
-            int yk_ = y0 + 4 * (C) + k_ - 7;                                                       \
-            yk_ = yk_ < 0 ? 0 : (yk_ > H - 1 ? H - 1 : yk_);                                       \
-            const pc_u2 v_ = __builtin_amdgcn_raw_buffer_load_b64(rKy, xbc * 8, yk_ * W * 8, PSM_KEY_LD_AUX); \
-            kcur[k_] = (long long)(((unsigned long long)v_.y << 32) | v_.x);                       \
-        }                                                                                          \
     }
         const __amdgpu_buffer_rsrc_t rG1 = pc_rsrc(G1, (unsigned)HW * 16u);
         const int vxb = xbc * 16;
@@ -482,20 +436,15 @@ void k_cvf_pc(
             }
             }
         };
-        constexpr bool LEANB = (PSM_PC_LEAN & 1) != 0 && MODE == 2;
-        constexpr bool LEANG = LEANB || ((PSM_PC_LEAN & 16) != 0 && MODE == 1);   // G1 of the output rows two rows ahead instead of a batch
-        constexpr bool LEANS = (PSM_PC_LEAN & 64) != 0 && MODE == 1;              // plane form: selection row by row inside the steps
+        constexpr bool LEANB = MODE == 2;   // key form: G1 of the output rows and the keys two rows ahead instead of a batch, selection inside the steps
         PSM_ISSUE_PB(0, 0) PSM_ISSUE_PB(1, 1)
-        if (!LEANG) { PSM_ISSUE_PB(2, 2) PSM_ISSUE_PB(3, 3) }
+        if (!LEANB) { PSM_ISSUE_PB(2, 2) PSM_ISSUE_PB(3, 3) }
         if constexpr (MODE == 1) {
             if (!first) {                              // records of batch 0, written by this wave one slice earlier (L1 bypassed)
                 PSM_K_LOAD(0)
             }
         }
-        if constexpr (MODE == 2) {
-            if (LEANB) { PSM_KEY_LOAD1(0, 0) PSM_KEY_LOAD1(1, 1) }
-            else PSM_KEY_LOAD(0)
-        }
+        if constexpr (MODE == 2) { PSM_KEY_LOAD1(0, 0) PSM_KEY_LOAD1(1, 1) }
         PC_SYNC();                               // iteration 0
         PC_SYNC();                               // iteration 1
         // (two batches per loop iteration, as in the producer: no register moves of the s4 slots at the latch)
@@ -505,7 +454,6 @@ void k_cvf_pc(
                 const int j0 = 4 * c;
                 float4 a_cur = *model_of(j0), a_nxt;
                 float qv[4];
-                bool anyb = false; (void)anyb;
 #define PSM_STEP_PB(K)                                                                              \
     {                                                                                               \
         if (K < 3) a_nxt = *model_of(j0 + K + 1);     /* model row of the next feed, one step ahead */ \
@@ -514,22 +462,13 @@ void k_cvf_pc(
         double h2 = hsum8(a_cur.z, i1, i2, i4);                                                     \
         double h3 = hsum8(a_cur.w, i1, i2, i4);                                                     \
         double n0 = vstep<K>(t0, h0), n1 = vstep<K>(t1, h1), n2 = vstep<K>(t2, h2), n3 = vstep<K>(t3, h3); \
-        qv[K] = __fadd_rn(__fadd_rn(__fadd_rn(PSM_BOX(n3), __fmul_rn(PSM_BOX(n0), o1x[LEANG ? (K & 1) : K])),        \
-                                    __fmul_rn(PSM_BOX(n1), o1y[LEANG ? (K & 1) : K])), __fmul_rn(PSM_BOX(n2), o1z[LEANG ? (K & 1) : K])); \
+        qv[K] = __fadd_rn(__fadd_rn(__fadd_rn(PSM_BOX(n3), __fmul_rn(PSM_BOX(n0), o1x[LEANB ? (K & 1) : K])),        \
+                                    __fmul_rn(PSM_BOX(n1), o1y[LEANB ? (K & 1) : K])), __fmul_rn(PSM_BOX(n2), o1z[LEANB ? (K & 1) : K])); \
         if (U8) {   /* q8 = sat_u8(rintf(q * 255)), NaN -> 0 (oracle: quant_u8); kept as a float: the selection is unchanged */ \
             const float r_ = rintf(__fmul_rn(qv[K], 255.0f * QSCALE));   /* (255 * 2^-12 is exact: one rounding, as q * 255) */ \
             qv[K] = !(r_ > 0.0f) ? 0.0f : (r_ > 255.0f ? 255.0f : r_);                              \
         } else if (SCALED) qv[K] = __fmul_rn(qv[K], QSCALE);                                        \
-        if (LEANS) {                                                                                \
-            const int j_ = j0 + K, yo_ = y0 + j_ - 7;                                               \
-            float &kqK_ = K == 0 ? kq.x : (K == 1 ? kq.y : (K == 2 ? kq.z : kq.w));                 \
-            const bool better_ = j_ >= 7 && yo_ < y1 && lane_out && dg != 0 && qv[K] < kqK_;        \
-            kqK_ = better_ ? qv[K] : kqK_;                                                          \
-            kd4 = better_ ? ((kd4 & ~(0xffu << (8 * K))) | ((unsigned)dg << (8 * K))) : kd4;        \
-            anyb |= better_;                                                                        \
-        }                                                                                           \
-        if (LEANG && !LEANB) PSM_ISSUE_PB(K & 1, j0 + K + 2)                                        \
-        else if (LEANB) {                                                                           \
+        if (LEANB) {                                                                                \
             PSM_ISSUE_PB(K & 1, j0 + K + 2)                                                         \
             const int j_ = j0 + K, yo_ = y0 + j_ - 7;                                               \
             const long long key_ = pack_key_f32(qv[K], dg);                                         \
@@ -546,33 +485,8 @@ void k_cvf_pc(
 #pragma unroll
                     for (int k = 0; k < 4; ++k)
                         if (lane < bwidth) qbuf[c & 1][k][wb * PC_OUT_B + lane] = qv[k];
-                } else if constexpr (LEANB) {
-                    // (selection done row by row inside the steps)
                 } else if constexpr (MODE == 2) {
-                    // DispSel::CVSelect (src/DispSel.cpp:96-104) against the volume's shared key plane: strict '<' / lowest d on
-                    // ties = signed minimum of pack_key_f32; d = 0 never a candidate; NaN never wins
-#if PSM_KEY_NOATOMIC == 2   // experiment (invalid results): compute-only - the q values are summed into a register, one store per workgroup
-                    acc_dbg += (qv[0] + qv[1]) + (qv[2] + qv[3]);
-                    if (c == nbB - 1 && lane_out) keyp[(size_t)(y0 + lane % 4) * W + xb] = (long long)__float_as_int(acc_dbg);
-#else
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        const int j_ = j0 + k, yo_ = y0 + j_ - 7;
-                        const long long key_ = pack_key_f32(qv[k], dg);
-                        if (j_ >= 7 && yo_ < y1 && lane_out && dg != 0 && qv[k] == qv[k] && key_ < kcur[k] && !PSM_KEY_NOATOMIC)
-                            (void)__hip_atomic_fetch_min(keyp + (size_t)yo_ * W + xb, key_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    }
-                    if (c + 1 < nbB) PSM_KEY_LOAD(c + 1)               // keys of the next batch's rows
-#endif
-                } else if constexpr (LEANS) {
-                    // (selection done row by row inside the steps; kq / kd4 hold the updated records of this batch)
-                    if (lane < bwidth && (first || anyb)) {
-                        const pc_u4 kv = {__float_as_uint(kq.x), __float_as_uint(kq.y), __float_as_uint(kq.z), __float_as_uint(kq.w)};
-                        __builtin_amdgcn_raw_buffer_store_b128(kv, rKc, lane * 16, c * (PC_COLS * 16), 0);
-                        __builtin_amdgcn_raw_buffer_store_b32(kd4, rKd, lane * 4, c * (PC_COLS * 4), 0);
-                    }
-                    if (first) { kq = make_float4(__builtin_inff(), __builtin_inff(), __builtin_inff(), __builtin_inff()); kd4 = 0; }
-                    else if (c + 1 < nbB) PSM_K_LOAD(c + 1)            // records of the next batch
+                    // (DispSel::CVSelect against the volume's shared key plane: done row by row inside the steps)
                 } else {
                     // DispSel::CVSelect (src/DispSel.cpp:96-104) over the slices of this chunk: strict '<', d = 0 never a
                     // candidate, NaN never wins.  Rows outside [y0, y1) and halo lanes keep (+inf, 0).
@@ -608,29 +522,15 @@ void k_cvf_pc(
         store_batch(nbB - 1);                          // iteration nbB+2
         PC_SYNC();
 #undef PSM_ISSUE_PB
-#undef PSM_KEY_LOAD
 #undef PSM_KEY_LOAD1
 #undef PSM_K_LOAD
     }
     if (MODE == 1) __builtin_amdgcn_s_waitcnt(0);      // the chunk planes of this slice are in the L2 before the next slice reads them
     first = false;
     }   // slices of the chunk
-    if constexpr (MODE == 1) {
-        if (dynamic && first && !is_a) {
-            // this workgroup came too late for any slice: its plane must still read "no candidate"
-            const int wb = wave - PC_NA;
-            const int bw = wb < PC_NB - 1 ? PC_OUT_B : PC_COLS - (PC_NB - 1) * PC_OUT_B;
-            const size_t krec = (size_t)(ch * npairs + pair) * nbmax * PC_COLS + wb * PC_OUT_B;
-            float4 *kc = reinterpret_cast<float4 *>(kcost) + krec;
-            unsigned *kd = kdisp + krec;
-            const float inf = __builtin_inff();
-            for (int c = 0; c < nbB && lane < bw; ++c) {
-                kc[c * PC_COLS + lane] = make_float4(inf, inf, inf, inf);
-                kd[c * PC_COLS + lane] = 0u;
-            }
-        }
-    }
 #undef PSM_BOX
+    if (ts != nullptr && threadIdx.x == 0)            // ... and when did the last one end (all waves have passed the last barrier)
+        (void)__hip_atomic_fetch_max(ts + PC_TS_SLOTS, (unsigned long long)wall_clock64(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #if PSM_PC_TIMING
     if (lane == 0 && MODE == 1) {
         atomicAdd(&g_pc_dbg[wave], q_work);
@@ -714,70 +614,56 @@ __global__ __launch_bounds__(256) void k_fill_keys(long long *__restrict__ keys,
     if (i < n) keys[i] = pack_key_f32(__builtin_inff(), 0);
 }
 
-// Segment count k (and, for MODE 1, slices per chunk DC): every segment re-walks 14 halo rows, and the launch runs in
-// rounds of resident workgroups - per XCD ceil(pairs/8) (column group, segment) pairs x chunks over 32 CUs x 3
-// workgroups.  Cost model, fitted to measurements at 1080p (DC = 1, 2, 4, 8, 16: 4.39, 4.41, 4.46, 4.71, 4.99 ms
-// for kernel + reduction): (rounds + 1/2) x rows walked per workgroup - the last round is on average half empty, which
-// is what makes long-running workgroups (large DC) expensive - plus two row-steps per chunk plane for the reduction.
-PcPlan pc_plan(int W, int H, int Dloc, int seg_rows_opt, int mode)
+// What the planner needs to know about the device the calling thread is bound to: XCDs (blocks go round-robin over them, each
+// has its own L2) and CUs per XCD - from the runtime, not assumed (MI355X: 8 x 32).
+PcDev pc_dev()
 {
-    return pc_plan_cols(W, H, Dloc, seg_rows_opt, mode, mode != 0 ? PcLayout<1>::COLS : PcLayout<0>::COLS);
+    static PcDev cache[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    PcDev &d = cache[dev];
+    if (d.nxcd == 0) {
+        int nx = 0, cus = 0;
+        if (hipDeviceGetAttribute(&nx, hipDeviceAttributeNumberOfXccs, dev) != hipSuccess || nx < 1) nx = 1;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
+        (void)hipGetLastError();
+        d.cus_per_xcd = cus / nx > 0 ? cus / nx : 1;
+        d.nxcd = nx;
+    }
+    return d;
 }
 
-PcPlan pc_plan_cols(int W, int H, int Dloc, int seg_rows_opt, int mode_in, int cols)
-{   // mode_in: 0 store; 1 select with chunk planes, 2 the same with both volumes per launch (twice the work items per launch);
-    // 3 select with a shared key plane (one slice per workgroup, no reduction afterwards), 4 the same with both volumes per launch;
-    // 5 select with chunk planes and dynamic slice distribution (NW resident workgroups per pair), 6 the same with both volumes
-    const int mode = (mode_in == 1 || mode_in == 2) ? 1 : 0, sides = (mode_in == 2 || mode_in == 4 || mode_in == 6) ? 2 : 1;
-    if (mode_in == 5 || mode_in == 6) {
-        // all workgroups resident at once (256 CUs x 3): NW = slots / pairs per pair; a workgroup walks ~Dloc / NW slices of
-        // rows / k + 14 rows each.  Pick the k with the smallest makespan.
-        PcPlan pl;
-        pl.ngroups = (W + cols - 1) / cols;
-        const int slots = 768, kmax = H / 64 > 1 ? H / 64 : 1;
-        long best = -1;
-        int bk = 1, bnw = 1;
-        for (int kk = 1; kk <= kmax && kk <= 32; ++kk) {
-            if (seg_rows_opt > 0 && kk != (H + seg_rows_opt - 1) / seg_rows_opt) continue;
-            const int np = sides * pl.ngroups * kk;
-            int nw = slots / np;
-            nw = nw < 1 ? 1 : (nw > Dloc ? Dloc : nw);
-            const char *e = getenv("PSM_PC_NW");
-            if (e && atoi(e) > 0) nw = atoi(e) > Dloc ? Dloc : atoi(e);
-            const long rounds = ((long)np * nw + slots - 1) / slots;
-            const long c = rounds * ((Dloc + nw - 1) / nw) * ((H + kk - 1) / kk + 14);
-            if (best < 0 || c < best) { best = c; bk = kk; bnw = nw; }
-        }
-        pl.seg_rows = seg_rows_opt > 0 ? seg_rows_opt : (H + bk - 1) / bk;
-        if (pl.seg_rows > H) pl.seg_rows = H;
-        pl.nsegs = (H + pl.seg_rows - 1) / pl.seg_rows;
-        pl.DC = 1;
-        pl.NW = bnw;
-        pl.nchunks = bnw;
-        pl.nbmax = (pl.seg_rows + 7 + 3) / 4;
-        pl.rec_per_chunk = (size_t)pl.ngroups * pl.nsegs * pl.nbmax * PcLayout<1>::COLS;
-        pl.rec_bytes = 20;
-        return pl;
-    }
-    const int rows = H;
+#ifdef PSM_EXPERIMENTS   // tuning knobs of experiment builds only (none changes a result); the product reads no environment
+static int pc_env(const char *name) { const char *e = getenv(name); return e ? atoi(e) : 0; }
+#else
+static int pc_env(const char *) { return 0; }
+#endif
+
+// Segment count k (and, for the plane form, slices per chunk DC): every segment re-walks 14 halo rows, and the launch runs in
+// rounds of resident workgroups - per XCD ceil(pairs / nxcd) (column group, segment) pairs x chunks over cus_per_xcd CUs x 3
+// workgroups (key form: x 4).  Cost model, fitted to measurements at 1080p (DC = 1, 2, 4, 8, 16: 4.39, 4.41, 4.46, 4.71,
+// 4.99 ms for kernel + reduction): (rounds + 1/2) x rows walked per workgroup - the last round is on average half empty,
+// which is what makes long-running workgroups (large DC) expensive - plus two row-steps per chunk plane for the reduction.
+PcPlan pc_plan(int W, int rows, int Dloc, int seg_rows_opt, int form)
+{   // form: PC_STORE; PC_PLANES (select with chunk planes) / PC_KEYS (select against a shared key plane, one slice per
+    // workgroup, no reduction afterwards), each + PC_BOTH when one launch covers both volumes (twice the work items)
+    const bool planes = (form & 3) == PC_PLANES, keys = (form & 3) == PC_KEYS;
+    const int sides = (form & PC_BOTH) ? 2 : 1;
+    const int cols = (form & 3) == PC_STORE ? PcLayout<0>::COLS : PcLayout<1>::COLS;
+    const PcDev dev = pc_dev();
     PcPlan pl;
+    pl.nxcd = dev.nxcd;
     pl.ngroups = (W + cols - 1) / cols;
     const int kmax = rows / 64 > 1 ? rows / 64 : 1;
     int dcs[5] = {1, 2, 4, 8, 16};
-    int ndc = mode == 1 ? 5 : 1;
-    if (mode == 1) {   // tuning / experiments: PSM_PC_DC forces the slices per chunk
-        const char *e = getenv("PSM_PC_DC");
-        if (e && atoi(e) > 0) { dcs[0] = atoi(e); ndc = 1; }
-    }
+    int ndc = planes ? 5 : 1;
+    if (planes && pc_env("PSM_PC_DC") > 0) { dcs[0] = pc_env("PSM_PC_DC"); ndc = 1; }
+    const long slots = pc_env("PSM_PC_SLOTS") > 0 ? pc_env("PSM_PC_SLOTS") : (long)dev.cus_per_xcd * (keys ? 4 : 3);   // resident workgroups per XCD
     auto cost_of = [&](int dc, int kk) -> long {
         const int nch = (Dloc + dc - 1) / dc;
-        const long per_xcd = ((long)sides * pl.ngroups * kk * nch + 7) / 8;
-        static const int slots_env = getenv("PSM_PC_SLOTS") ? atoi(getenv("PSM_PC_SLOTS")) : 0;
-        const long slots = slots_env > 0 ? slots_env : ((mode_in == 3 || mode_in == 4) && PSM_PC_OCC4 ? 128 : 96);   // resident workgroups per XCD: 32 CUs x 3 (key form: x 4)
-        static const int tail_env = getenv("PSM_PC_TAIL") ? atoi(getenv("PSM_PC_TAIL")) : -1;
-        const long tail2 = tail_env >= 0 ? tail_env : 1;                             // 2 x the tail allowance in rounds
-        const long rounds2 = 2 * ((per_xcd + slots - 1) / slots) + ((mode_in == 3 || mode_in == 4) ? tail2 : 1);   // 2 x (rounds + 1/2)
-        return rounds2 * dc * ((rows + kk - 1) / kk + 14) / 2 + (mode == 1 ? 2L * sides * nch : 0);
+        const long per_xcd = ((long)sides * pl.ngroups * kk * nch + dev.nxcd - 1) / dev.nxcd;
+        const long rounds2 = 2 * ((per_xcd + slots - 1) / slots) + 1;   // 2 x (rounds + 1/2)
+        return rounds2 * dc * ((rows + kk - 1) / kk + 14) / 2 + (planes ? 2L * sides * nch : 0);
     };
     auto allowed = [&](int dc, int kk) { return (dc == dcs[0] || dc <= Dloc) && (seg_rows_opt <= 0 || kk == (rows + seg_rows_opt - 1) / seg_rows_opt); };
     long best = -1;
@@ -792,7 +678,6 @@ PcPlan pc_plan_cols(int W, int H, int Dloc, int seg_rows_opt, int mode_in, int c
     if (pl.seg_rows > rows) pl.seg_rows = rows;
     pl.nsegs = (rows + pl.seg_rows - 1) / pl.seg_rows;
     pl.DC = bdc;
-    pl.NW = 0;
     pl.nchunks = (Dloc + bdc - 1) / bdc;
     pl.nbmax = (pl.seg_rows + 7 + 3) / 4;                            // consumer batches of a full segment
     pl.rec_per_chunk = (size_t)pl.ngroups * pl.nsegs * pl.nbmax * PcLayout<1>::COLS;
@@ -800,18 +685,25 @@ PcPlan pc_plan_cols(int W, int H, int Dloc, int seg_rows_opt, int mode_in, int c
     return pl;
 }
 
+int pc_seed_stride(int W, int H)
+{   // every S-th slice goes through the minima planes and seeds the key plane: 5, 4 from 4 Mpixel up
+    const int e = pc_env("PSM_PC_S");
+    return e > 1 ? e : ((size_t)W * H >= ((size_t)1 << 22) ? 4 : 5);
+}
+
+static int pc_blocks(const PcPlan &pl, int chunks) { return pl.nxcd * ((pl.ngroups * pl.nsegs * chunks + pl.nxcd - 1) / pl.nxcd); }
+
+// Storing form (MODE 0): vin (or, cvc_mode 1 / 2, the costs built on the fly) -> vout, one slice per workgroup.
 void launch_cvf_fused(hipStream_t s, March m, const float *vin, float *vout, Guidance gd, int W, int H, int Dloc,
                       int ybeg, int yend, const float4 *g1_other, int d_begin, int cvc_mode)
 {
     if (yend <= ybeg) return;
-    const int rows = yend - ybeg;
-    const PcPlan pl = pc_plan(W, rows, Dloc, m.seg_rows, 0);
-    const int nblocks = 8 * ((pl.ngroups * pl.nsegs * Dloc + 7) / 8);
-    const dim3 blk(64 * (PcLayout<0>::NA + PcLayout<0>::NB));
+    const PcPlan pl = pc_plan(W, yend - ybeg, Dloc, m.seg_rows, PC_STORE);
+    const dim3 grid(pc_blocks(pl, Dloc)), blk(64 * (PcLayout<0>::NA + PcLayout<0>::NB));
 #define PSM_LAUNCH_PC(V4, CV)                                                                                              \
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_cvf_pc<V4, CV, 0>), dim3(nblocks), blk, 0, s, vin, vout, (const float4 *)gd.g1,   \
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_cvf_pc<V4, CV, 0>), grid, blk, 0, s, vin, vout, (const float4 *)gd.g1,            \
                        (const float4 *)gd.g2, (const float4 *)gd.g3, (const float2 *)gd.g4, W, H, Dloc, pl.ngroups, pl.nsegs, \
-                       pl.seg_rows, ybeg, yend, g1_other, d_begin, 1, (float *)nullptr, (unsigned *)nullptr, 0, PcSide{}, PcDyn{nullptr, 0, 0, 1, 1})
+                       pl.seg_rows, ybeg, yend, g1_other, d_begin, 1, (float *)nullptr, (unsigned *)nullptr, 0, PcSide{}, PcSel{0, 1, pl.nxcd}, (unsigned long long *)nullptr)
     const bool v4 = (W & 3) == 0;
     if (cvc_mode == 1) { if (v4) PSM_LAUNCH_PC(true, 1); else PSM_LAUNCH_PC(false, 1); }
     else if (cvc_mode == 2) { if (v4) PSM_LAUNCH_PC(true, 2); else PSM_LAUNCH_PC(false, 2); }
@@ -819,78 +711,32 @@ void launch_cvf_fused(hipStream_t s, March m, const float *vin, float *vout, Gui
 #undef PSM_LAUNCH_PC
 }
 
+// Select form with chunk planes (MODE 1), one volume: costs read from vin (cvc_mode 0) or built on the fly (1 / 2; p4_own !=
+// NULL: 8-bit char mode).  scratch: pc_plan(..., PC_PLANES).scratch_bytes().
 void launch_cvf_select(hipStream_t s, March m, const float *vin, Guidance gd, int W, int H, int Dloc, const float4 *g1_other,
-                       int d_begin, int cvc_mode, void *scratch, int *cnt, const uint8_t *p4_own, const uint8_t *p4_other, int sel, int step)
-{   // p4_own != NULL (cvc_mode 1 / 2 only): 8-bit char mode; cnt != NULL: dynamic slice distribution (npairs ints, zeroed here)
-    // Dloc = number of slices of this launch, (sel, step) = which ones (PcDyn)
-    const PcPlan pl = pc_plan(W, m.rows(H), Dloc, m.seg_rows, cnt ? 5 : 1);
-    const PcDyn dyn = {cnt, pl.NW, sel, step, 1};
-    if (cnt) (void)hipMemsetAsync(cnt, 0, sizeof(int) * pl.ngroups * pl.nsegs, s);
+                       int d_begin, int cvc_mode, void *scratch, unsigned long long *ts, const uint8_t *p4_own, const uint8_t *p4_other)
+{
+    const PcPlan pl = pc_plan(W, m.rows(H), Dloc, m.seg_rows, PC_PLANES);
+    const PcSel sel = {0, 1, pl.nxcd};
     float *kcost = (float *)scratch;                                           // nchunks * rec_per_chunk float4
     unsigned *kdisp = (unsigned *)(kcost + 4 * pl.rec_per_chunk * pl.nchunks);  // nchunks * rec_per_chunk uchar4
-    const int nblocks = 8 * ((pl.ngroups * pl.nsegs * pl.nchunks + 7) / 8);
-    const dim3 blk(64 * (PcLayout<1>::NA + PcLayout<1>::NB));
-#define PSM_LAUNCH_PC(CV)                                                                                                   \
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_cvf_pc<false, CV, 1>), dim3(nblocks), blk, 0, s, vin, (float *)nullptr, (const float4 *)gd.g1, \
+    const dim3 grid(pc_blocks(pl, pl.nchunks)), blk(64 * (PcLayout<1>::NA + PcLayout<1>::NB));
+#define PSM_LAUNCH_PC(CV, U8V, A0, A1)                                                                                      \
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_cvf_pc<false, CV, 1, U8V>), grid, blk, 0, s, A0, A1, (const float4 *)gd.g1,        \
                        (const float4 *)gd.g2, (const float4 *)gd.g3, (const float2 *)gd.g4, W, H, Dloc, pl.ngroups, pl.nsegs, \
-                       pl.seg_rows, m.y0(H), m.y1(H), g1_other, d_begin, pl.DC, kcost, kdisp, pl.nbmax, PcSide{}, dyn)
+                       pl.seg_rows, m.y0(H), m.y1(H), g1_other, d_begin, pl.DC, kcost, kdisp, pl.nbmax, PcSide{}, sel, ts)
     if (p4_own && cvc_mode != 0) {
-#define PSM_LAUNCH_PC8(CV)                                                                                                  \
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_cvf_pc<false, CV, 1, true>), dim3(nblocks), blk, 0, s, (const float *)p4_own, (float *)const_cast<uint8_t *>(p4_other), \
-                       (const float4 *)gd.g1, (const float4 *)gd.g2, (const float4 *)gd.g3, (const float2 *)gd.g4, W, H, Dloc, pl.ngroups, pl.nsegs, \
-                       pl.seg_rows, m.y0(H), m.y1(H), g1_other, d_begin, pl.DC, kcost, kdisp, pl.nbmax, PcSide{}, dyn)
-        if (cvc_mode == 1) PSM_LAUNCH_PC8(1); else PSM_LAUNCH_PC8(2);
-#undef PSM_LAUNCH_PC8
-    } else if (cvc_mode == 1) PSM_LAUNCH_PC(1); else if (cvc_mode == 2) PSM_LAUNCH_PC(2); else PSM_LAUNCH_PC(0);
+        if (cvc_mode == 1) PSM_LAUNCH_PC(1, true, (const float *)p4_own, (float *)const_cast<uint8_t *>(p4_other));
+        else PSM_LAUNCH_PC(2, true, (const float *)p4_own, (float *)const_cast<uint8_t *>(p4_other));
+    } else if (cvc_mode == 1) PSM_LAUNCH_PC(1, false, vin, (float *)nullptr);
+    else if (cvc_mode == 2) PSM_LAUNCH_PC(2, false, vin, (float *)nullptr);
+    else PSM_LAUNCH_PC(0, false, vin, (float *)nullptr);
 #undef PSM_LAUNCH_PC
 }
 
-// Select mode with a shared key plane (MODE 2): keys[H*W] of this volume receives the packed minima over the local slices.
-void launch_cvf_select_keys(hipStream_t s, March m, const float *vin, Guidance gd, int W, int H, int Dloc, const float4 *g1_other,
-                            int d_begin, int cvc_mode, long long *keys, const uint8_t *p4_own, const uint8_t *p4_other, int init, int sel, int step)
-{   // init: start from key(+inf, 0); otherwise continue from what `keys` holds (second phase of the two-phase selection)
-    const PcPlan pl = pc_plan(W, m.rows(H), Dloc, m.seg_rows, 3);
-    const size_t HW = (size_t)W * H;
-    if (init) hipLaunchKernelGGL(k_fill_keys, dim3((unsigned)((HW + 255) / 256)), dim3(256), 0, s, keys, HW);
-    const int nblocks = 8 * ((pl.ngroups * pl.nsegs * Dloc + 7) / 8);
-    const dim3 blk(64 * (PcLayout<2>::NA + PcLayout<2>::NB));
-#define PSM_LAUNCH_K(CV, U8V, A0, A1)                                                                                       \
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_cvf_pc<false, CV, 2, U8V>), dim3(nblocks), blk, 0, s, A0, A1, (const float4 *)gd.g1, \
-                       (const float4 *)gd.g2, (const float4 *)gd.g3, (const float2 *)gd.g4, W, H, Dloc, pl.ngroups, pl.nsegs, \
-                       pl.seg_rows, m.y0(H), m.y1(H), g1_other, d_begin, 1, (float *)keys, (unsigned *)nullptr, 0, PcSide{}, PcDyn{nullptr, 0, sel, step, 1})
-    if (p4_own && cvc_mode != 0) {
-        if (cvc_mode == 1) PSM_LAUNCH_K(1, true, (const float *)p4_own, (float *)const_cast<uint8_t *>(p4_other));
-        else PSM_LAUNCH_K(2, true, (const float *)p4_own, (float *)const_cast<uint8_t *>(p4_other));
-    } else if (cvc_mode == 1) PSM_LAUNCH_K(1, false, (const float *)nullptr, (float *)nullptr);
-    else if (cvc_mode == 2) PSM_LAUNCH_K(2, false, (const float *)nullptr, (float *)nullptr);
-    else PSM_LAUNCH_K(0, false, vin, (float *)nullptr);
-#undef PSM_LAUNCH_K
-}
-
-// ... both volumes in one launch: keys[2][H][W]
-void launch_cvf_select_keys2(hipStream_t s, March m, const Guidance *g, int W, int H, int Dloc, int d_begin, long long *keys,
-                             const uint8_t *const *p4, int init, int sel, int step, int unit)
+void launch_chunk_min(hipStream_t s, March m, int W, int H, int Dloc, void *scratch, long long *keys, uint8_t *map)
 {
-    const PcPlan pl = pc_plan(W, m.rows(H), Dloc, m.seg_rows, 4);
-    const size_t HW = (size_t)W * H;
-    if (init) hipLaunchKernelGGL(k_fill_keys, dim3((unsigned)((2 * HW + 255) / 256)), dim3(256), 0, s, keys, 2 * HW);
-    const int nblocks = 8 * ((pl.ngroups * pl.nsegs * Dloc + 7) / 8);
-    const dim3 blk(64 * (PcLayout<2>::NA + PcLayout<2>::NB));
-    const PcSide s1 = {(const float4 *)g[1].g1, (const float4 *)g[1].g2, (const float4 *)g[1].g3, (const float2 *)g[1].g4, (const float4 *)g[0].g1,
-                       (float *)(keys + HW), nullptr};
-    if (p4)
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_cvf_pc<false, 3, 2, true>), dim3(nblocks, 2), blk, 0, s, (const float *)p4[0], (float *)const_cast<uint8_t *>(p4[1]),
-                           (const float4 *)g[0].g1, (const float4 *)g[0].g2, (const float4 *)g[0].g3, (const float2 *)g[0].g4, W, H, Dloc, pl.ngroups,
-                           pl.nsegs, pl.seg_rows, m.y0(H), m.y1(H), (const float4 *)g[1].g1, d_begin, 1, (float *)keys, (unsigned *)nullptr, 0, s1, PcDyn{nullptr, 0, sel, step, unit});
-    else
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_cvf_pc<false, 3, 2, false>), dim3(nblocks, 2), blk, 0, s, (const float *)nullptr, (float *)nullptr,
-                           (const float4 *)g[0].g1, (const float4 *)g[0].g2, (const float4 *)g[0].g3, (const float2 *)g[0].g4, W, H, Dloc, pl.ngroups,
-                           pl.nsegs, pl.seg_rows, m.y0(H), m.y1(H), (const float4 *)g[1].g1, d_begin, 1, (float *)keys, (unsigned *)nullptr, 0, s1, PcDyn{nullptr, 0, sel, step, unit});
-}
-
-void launch_chunk_min(hipStream_t s, March m, int W, int H, int Dloc, void *scratch, long long *keys, uint8_t *map, int dynamic)
-{
-    const PcPlan pl = pc_plan(W, m.rows(H), Dloc, m.seg_rows, dynamic ? 5 : 1);
+    const PcPlan pl = pc_plan(W, m.rows(H), Dloc, m.seg_rows, PC_PLANES);
     const float *kcost = (const float *)scratch;
     const unsigned *kdisp = (const unsigned *)(kcost + 4 * pl.rec_per_chunk * pl.nchunks);
     hipLaunchKernelGGL(k_chunk_min, dim3((unsigned)((pl.rec_per_chunk + 255) / 256)), dim3(256), 0, s, (const float4 *)kcost, (const unsigned *)kdisp,
@@ -898,41 +744,62 @@ void launch_chunk_min(hipStream_t s, March m, int W, int H, int Dloc, void *scra
                        (const unsigned *)nullptr, m.y0(H), m.y1(H));
 }
 
-// Both volumes in one launch each (costs built on the fly): left volume = (g[0], other g[1].g1), right = (g[1], other g[0].g1);
-// scratch: 2 x pc_plan(...).scratch_bytes(); keys / map: [2][H][W].
-void launch_cvf_select2(hipStream_t s, March m, const Guidance *g, int W, int H, int Dloc, int d_begin, void *scratch, int *cnt,
-                        const uint8_t *const *p4, int sel, int step)
-{   // p4 != NULL: 8-bit char mode, p4[0] / p4[1] = byte planes {c0,c1,c2,grad} of the left / right image
-    // cnt != NULL: dynamic slice distribution (2 * npairs ints, zeroed here)
-    const PcPlan pl = pc_plan(W, m.rows(H), Dloc, m.seg_rows, cnt ? 6 : 2);
-    const PcDyn dyn = {cnt, pl.NW, sel, step, 1};
-    if (cnt) (void)hipMemsetAsync(cnt, 0, sizeof(int) * 2 * pl.ngroups * pl.nsegs, s);
+// Both volumes in one launch each (costs built on the fly): left volume = (g[0], other g[1].g1), right = (g[1], other g[0].g1).
+// Dloc = number of slices of this launch, (sel, step) = which ones (PcSel).  p4 != NULL: 8-bit char mode, p4[0] / p4[1] = byte
+// planes {c0,c1,c2,grad} of the left / right image.
+// ... plane form: scratch = 2 x pc_plan(..., PC_PLANES | PC_BOTH).scratch_bytes()
+void launch_cvf_select2(hipStream_t s, March m, const Guidance *g, int W, int H, int Dloc, int d_begin, void *scratch,
+                        unsigned long long *ts, const uint8_t *const *p4, int sel, int step)
+{
+    const PcPlan pl = pc_plan(W, m.rows(H), Dloc, m.seg_rows, PC_PLANES | PC_BOTH);
+    const PcSel ps = {sel, step, pl.nxcd};
     float *kcost0 = (float *)scratch;
     unsigned *kdisp0 = (unsigned *)(kcost0 + 4 * pl.rec_per_chunk * pl.nchunks);
     float *kcost1 = (float *)((char *)scratch + pl.scratch_bytes());
     unsigned *kdisp1 = (unsigned *)(kcost1 + 4 * pl.rec_per_chunk * pl.nchunks);
-    const int nblocks = 8 * ((pl.ngroups * pl.nsegs * pl.nchunks + 7) / 8);
-    const dim3 blk(64 * (PcLayout<1>::NA + PcLayout<1>::NB));
+    const dim3 grid(pc_blocks(pl, pl.nchunks), 2), blk(64 * (PcLayout<1>::NA + PcLayout<1>::NB));
     const PcSide s1 = {(const float4 *)g[1].g1, (const float4 *)g[1].g2, (const float4 *)g[1].g3, (const float2 *)g[1].g4, (const float4 *)g[0].g1, kcost1, kdisp1};
     if (p4)
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_cvf_pc<false, 3, 1, true>), dim3(nblocks, 2), blk, 0, s, (const float *)p4[0], (float *)const_cast<uint8_t *>(p4[1]),
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_cvf_pc<false, 3, 1, true>), grid, blk, 0, s, (const float *)p4[0], (float *)const_cast<uint8_t *>(p4[1]),
                            (const float4 *)g[0].g1, (const float4 *)g[0].g2, (const float4 *)g[0].g3, (const float2 *)g[0].g4, W, H, Dloc, pl.ngroups,
-                           pl.nsegs, pl.seg_rows, m.y0(H), m.y1(H), (const float4 *)g[1].g1, d_begin, pl.DC, kcost0, kdisp0, pl.nbmax, s1, dyn);
+                           pl.nsegs, pl.seg_rows, m.y0(H), m.y1(H), (const float4 *)g[1].g1, d_begin, pl.DC, kcost0, kdisp0, pl.nbmax, s1, ps, ts);
     else
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_cvf_pc<false, 3, 1>), dim3(nblocks, 2), blk, 0, s, (const float *)nullptr, (float *)nullptr, (const float4 *)g[0].g1,
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_cvf_pc<false, 3, 1>), grid, blk, 0, s, (const float *)nullptr, (float *)nullptr, (const float4 *)g[0].g1,
                            (const float4 *)g[0].g2, (const float4 *)g[0].g3, (const float2 *)g[0].g4, W, H, Dloc, pl.ngroups, pl.nsegs, pl.seg_rows, m.y0(H), m.y1(H),
-                           (const float4 *)g[1].g1, d_begin, pl.DC, kcost0, kdisp0, pl.nbmax, s1, dyn);
+                           (const float4 *)g[1].g1, d_begin, pl.DC, kcost0, kdisp0, pl.nbmax, s1, ps, ts);
 }
 
-void launch_chunk_min2sides(hipStream_t s, March m, int W, int H, int Dloc, void *scratch, long long *keys, uint8_t *map, int dynamic)
+void launch_chunk_min2sides(hipStream_t s, March m, int W, int H, int Dloc, void *scratch, long long *keys, uint8_t *map)
 {
-    const PcPlan pl = pc_plan(W, m.rows(H), Dloc, m.seg_rows, dynamic ? 6 : 2);
+    const PcPlan pl = pc_plan(W, m.rows(H), Dloc, m.seg_rows, PC_PLANES | PC_BOTH);
     const float *kcost0 = (const float *)scratch;
     const unsigned *kdisp0 = (const unsigned *)(kcost0 + 4 * pl.rec_per_chunk * pl.nchunks);
     const float *kcost1 = (const float *)((const char *)scratch + pl.scratch_bytes());
     const unsigned *kdisp1 = (const unsigned *)(kcost1 + 4 * pl.rec_per_chunk * pl.nchunks);
     hipLaunchKernelGGL(k_chunk_min, dim3((unsigned)((pl.rec_per_chunk + 255) / 256), 2), dim3(256), 0, s, (const float4 *)kcost0, kdisp0,
                        pl.nchunks, pl.ngroups * pl.nsegs, pl.nbmax, pl.ngroups, pl.seg_rows, W, H, keys, map, (const float4 *)kcost1, kdisp1, m.y0(H), m.y1(H));
+}
+
+// ... key form (MODE 2): keys[2][H][W] receives the packed minima (init: start from key(+inf, 0); otherwise continue from what
+// `keys` holds - the second phase of the two-phase selection)
+void launch_cvf_select_keys2(hipStream_t s, March m, const Guidance *g, int W, int H, int Dloc, int d_begin, long long *keys,
+                             unsigned long long *ts, const uint8_t *const *p4, int init, int sel, int step)
+{
+    const PcPlan pl = pc_plan(W, m.rows(H), Dloc, m.seg_rows, PC_KEYS | PC_BOTH);
+    const PcSel ps = {sel, step, pl.nxcd};
+    const size_t HW = (size_t)W * H;
+    if (init) hipLaunchKernelGGL(k_fill_keys, dim3((unsigned)((2 * HW + 255) / 256)), dim3(256), 0, s, keys, 2 * HW);
+    const dim3 grid(pc_blocks(pl, Dloc), 2), blk(64 * (PcLayout<2>::NA + PcLayout<2>::NB));
+    const PcSide s1 = {(const float4 *)g[1].g1, (const float4 *)g[1].g2, (const float4 *)g[1].g3, (const float2 *)g[1].g4, (const float4 *)g[0].g1,
+                       (float *)(keys + HW), nullptr};
+    if (p4)
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_cvf_pc<false, 3, 2, true>), grid, blk, 0, s, (const float *)p4[0], (float *)const_cast<uint8_t *>(p4[1]),
+                           (const float4 *)g[0].g1, (const float4 *)g[0].g2, (const float4 *)g[0].g3, (const float2 *)g[0].g4, W, H, Dloc, pl.ngroups,
+                           pl.nsegs, pl.seg_rows, m.y0(H), m.y1(H), (const float4 *)g[1].g1, d_begin, 1, (float *)keys, (unsigned *)nullptr, 0, s1, ps, ts);
+    else
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_cvf_pc<false, 3, 2, false>), grid, blk, 0, s, (const float *)nullptr, (float *)nullptr,
+                           (const float4 *)g[0].g1, (const float4 *)g[0].g2, (const float4 *)g[0].g3, (const float2 *)g[0].g4, W, H, Dloc, pl.ngroups,
+                           pl.nsegs, pl.seg_rows, m.y0(H), m.y1(H), (const float4 *)g[1].g1, d_begin, 1, (float *)keys, (unsigned *)nullptr, 0, s1, ps, ts);
 }
 
 }  // namespace psm

@@ -213,10 +213,6 @@ class DispEst:
                                               _ptr(self.rDisMap) if download else None, self.wid),
                  "DispSelect_merge_ctx")
 
-    def seed_stride(self) -> int:
-        """Stride of the seeding phase the in-place tuner settled on (0: still measuring / two-phase selection not in use)."""
-        return int(self._lib.psm_debug_seed_stride(self._h))
-
     def set_rows(self, y_begin: int = 0, y_end: int = 0):
         """Row stripe: CostFilter_GPU / DispSelect* compute output rows [y_begin, y_end) of the whole image only (all
         slices, both volumes, identical values); (0, 0): whole image.  Call before CostFilter_GPU."""
@@ -243,6 +239,34 @@ class DispEst:
         self._ck(self._lib.psm_download_maps(self._h, _ptr(self.lDisMap), _ptr(self.rDisMap), self.wid),
                  "download_maps")
         return self.lDisMap, self.rDisMap
+
+    # ---- frame loop: the PCIe legs next to the kernels (src/main.cpp:64-73) ----
+    def setInputImages_async(self, l, r) -> int:
+        """The NEXT frame's pair: staged and copied on the copy stream while the current frame computes; the next
+        CostConst_GPU adopts it."""
+        l = np.ascontiguousarray(l)
+        r = np.ascontiguousarray(r)
+        if l.shape != (self.hei, self.wid, 3) or r.shape != l.shape or l.dtype != r.dtype:
+            raise ValueError("setInputImages_async: image size / type differs from the one DispEst was built for")
+        depth = capi.PSM_IMG_U8 if l.dtype == np.uint8 else capi.PSM_IMG_F32
+        self._ck(self._lib.psm_upload_pair_async(self._h, _ptr(l), _ptr(r), 3, l.strides[0], depth), "setInputImages_async")
+        return 0
+
+    def download_maps_async(self):
+        self._ck(self._lib.psm_download_maps_async(self._h), "download_maps_async")
+
+    def download_maps_wait(self):
+        self._ck(self._lib.psm_download_maps_wait(self._h, _ptr(self.lDisMap), _ptr(self.rDisMap), self.wid), "download_maps_wait")
+        return self.lDisMap, self.rDisMap
+
+    def filter_launch_times(self, max_launches: int = 4096):
+        """PSM_OPT_PROFILE 2: [(ms, form)] of every launch of the fused filter kernel since the last call (form 1 = minima
+        planes, 2 = key plane, 0 = storing), from time stamps the kernel takes itself; resets the record."""
+        ms = (C.c_double * max_launches)()
+        form = (C.c_int * max_launches)()
+        n = C.c_int()
+        self._ck(self._lib.psm_filter_launch_times(self._h, ms, form, max_launches, C.byref(n)), "filter_launch_times")
+        return [(ms[i], form[i]) for i in range(n.value)]
 
     def _vdtype(self):
         return np.uint8 if self._dtype == capi.PSM_U8 else np.float32

@@ -33,11 +33,18 @@ DispEst::DispEst(Mat l, Mat r, const int d, int t, bool ocl, int ndev, int dtype
     if (ndev > have && !share) ndev = have;
     if (ndev > hei) ndev = hei;
     // several devices: one context per device on a stripe of the image rows - all disparities of both volumes, so the WTA
-    // finishes on the device and only finished map rows are gathered (psm_gather_rows_ctx)
+    // finishes on the device and only finished map rows are gathered (psm_gather_rows_ctx).  Stripes of R = ceil(H / ndev)
+    // rows, aligned at multiples of R (the same bounds as the rank-per-GPU host, primestereomatch_amd/stripes.py: a gathered
+    // [ndev][2][R][W] buffer is the image); devices past the last non-empty stripe stay unused.
+    const int R = (hei + ndev - 1) / ndev;
+    while (ndev > 1 && (ndev - 1) * R >= hei) --ndev;
     for (int g = 0; g < ndev; ++g) {
         psm_ctx *c = nullptr;
+        const int ya = g * R, yb = ya + R < hei ? ya + R : hei;
+        y0s.push_back(ya);
+        y1s.push_back(yb);
         if (api.create_shard(&c, wid, hei, maxDis, 0, maxDis, dtype, g % have) != 0 ||
-            (ndev > 1 && api.set_rows(c, (int)((long)hei * g / ndev), (int)((long)hei * (g + 1) / ndev)) != 0)) {
+            (ndev > 1 && api.set_rows(c, ya, yb) != 0)) {
             fprintf(stderr, "DispEst: %s\n", api.last_error(c));
             if (c) api.destroy(c);
             for (psm_ctx *p : ctx) api.destroy(p);
@@ -88,6 +95,8 @@ int DispEst::CostFilter_GPU()
 {
     if (ctx.empty()) return 1;
     int rc = 0;
+    if (whole_on_first && ctx.size() > 1) rc |= hipUtil::api().set_rows(ctx[0], y0s[0], y1s[0]);   // back to stripes
+    whole_on_first = false;
     for (psm_ctx *c : ctx) rc |= hipUtil::api().cost_filter(c);
     return rc;
 }
@@ -95,8 +104,12 @@ int DispEst::CostFilter_GPU()
 int DispEst::CostFilter_FGF_GPU()
 {
     if (ctx.empty()) return 1;
+    // the Fast Guided Filter path has no row stripes (its low-resolution models would need their own halo arithmetic, and
+    // it is 3x cheaper than the full filter anyway): the first device filters the whole image, the others sit this frame out
     int rc = 0;
-    for (psm_ctx *c : ctx) rc |= hipUtil::api().cost_filter_fgf(c, (int)subsample_rate);
+    if (ctx.size() > 1) rc |= hipUtil::api().set_rows(ctx[0], 0, 0);
+    whole_on_first = ctx.size() > 1;
+    rc |= hipUtil::api().cost_filter_fgf(ctx[0], (int)subsample_rate);
     return rc;
 }
 
@@ -104,7 +117,7 @@ int DispEst::DispSelect_GPU()
 {
     if (ctx.empty()) return 1;
     const HipApi &api = hipUtil::api();
-    if (ctx.size() == 1) return api.disp_select(ctx[0], lDisMap.data, rDisMap.data, lDisMap.step);
+    if (ctx.size() == 1 || whole_on_first) return api.disp_select(ctx[0], lDisMap.data, rDisMap.data, lDisMap.step);
     int rc = 0;
     for (psm_ctx *c : ctx) rc |= api.disp_select(c, nullptr, nullptr, 0);
     rc |= api.gather_rows_ctx(ctx[0], ctx.data(), (int)ctx.size(), lDisMap.data, rDisMap.data, lDisMap.step);

@@ -49,8 +49,9 @@ class DispEst {
 public:
     // l, r: H x W x 3 images, cv::imread channel order, CV_8U or CV_32F (already scaled by
     // 1/255.0f, src/StereoMatch.cpp:193-198).  d: maxDis; t: host threads (interface parity);
-    // ocl: accelerator available (the reference's gotOCLDev).  ndev > 1 shards the disparity
-    // range over the first ndev devices of this process.
+    // ocl: accelerator available (the reference's gotOCLDev).  ndev > 1: the first ndev devices of this process each
+    // take a stripe of ceil(H / ndev) output rows of both maps (all disparities of both volumes: the WTA finishes on the
+    // device, only finished map rows are gathered - psm_set_rows / psm_gather_rows_ctx).
     DispEst(Mat l, Mat r, const int d, int t, bool ocl, int ndev = 1, int dtype = PSM_F32);
     ~DispEst(void);
 
@@ -85,7 +86,9 @@ private:
     int hei, wid, maxDis, threads;
     bool useOCL;
     unsigned int subsample_rate = 4;
-    std::vector<psm_ctx *> ctx;  // one per device (disparity shards)
+    std::vector<psm_ctx *> ctx;  // one per device (row stripes of ceil(H / ndev) rows)
+    std::vector<int> y0s, y1s;   // their stripes
+    bool whole_on_first = false; // the last filter ran on ctx[0] over the whole image (Fast Guided Filter path: no stripes)
 };
 
 }  // namespace psm

@@ -32,6 +32,18 @@ def test_bench_line_live_small_config():
     assert j["cpu_baseline"]["kind"] == "port" and j["cpu_baseline"]["value"] > 0
     assert j["verified_vs_single_gpu"] is True
     assert j["median_ms_per_step"] > 0 and j["pcie"]["h2d_ms"] > 0 and j["pcie"]["d2h_ms"] > 0
+    # the fused kernel's time comes from the timed region itself (in-kernel stamps): it fits inside the step it describes
+    k = j["kernels"]["cvf_fused"]
+    assert "timed region" in k["source"] and k["avg_ms"] * k["launches_per_step"] <= j["ms_per_step"]
+    assert j["pcie"]["frame_loop"]["maps_equal_timed_path"] is True and j["pcie"]["frame_loop"]["ms_per_frame"] > 0
+
+
+def test_bench_line_oracle_checks_the_timed_maps():
+    """The oracle run that provides cpu_baseline also checks the maps the TIMED path left on the device (whole D)."""
+    j = _bench("--config", "c3", "--steps", "3", "--warmup", "1", "--pp")
+    assert j["oracle_maps_equal"] is True and j["oracle_map_mismatches"] == [0, 0]
+    assert j["kernels_sum_ms_per_step"] <= 1.03 * j["ms_per_step"]      # (the small kernels come from a perturbed event pass)
+    assert j["pp"]["verified_vs_oracle"] is True and j["pp"]["wgt_median_ms"] > 0
 
 
 @pytest.mark.parametrize("shard,exchange,extra", [("rows", "allreduce", ()), ("rows", "allreduce", ("--no-frame-pipeline",)),
@@ -43,6 +55,9 @@ def test_distributed_path_world1_verified(shard, exchange, extra):
     j = _bench("--gpus", "1", "--force-dist", "--shard", shard, "--exchange", exchange, "--config", "c3", "--steps", "3", "--warmup", "1",
                "--no-cpu-baseline", *extra)
     assert j["verified_vs_single_gpu"] is True and j["scaling"] == "strong" and j["config"]["shard"] == shard
+    # one invocation times both axes: the other one sits in alt_shard, verified the same way
+    a = j["alt_shard"]
+    assert a["shard"] == ("disp" if shard == "rows" else "rows") and a["verified_vs_single_gpu"] is True and a["ms_per_step"] > 0
 
 
 @pytest.mark.parametrize("shard", ["rows", "disp"])
@@ -51,7 +66,8 @@ def test_distributed_path_world2_rccl_when_two_gpus(shard):
     if capi.device_count() < 2:
         pytest.skip("needs 2 GPUs (the driver's multi-GPU bench covers N > 1 on an 8-GPU node)")
     j = _bench("--gpus", "2", "--shard", shard, "--config", "c3", "--steps", "3", "--warmup", "1", "--no-cpu-baseline")   # bare command: self-launch
-    assert j["n_gpus"] == 2 and j["verified_vs_single_gpu"] is True
+    assert j["n_gpus"] == 2 and j["verified_vs_single_gpu"] is True and j["oracle_maps_equal"] is True
+    assert j["alt_shard"]["verified_vs_single_gpu"] is True and j["alt_shard"]["oracle_maps_equal"] is True
 
 
 @pytest.mark.parametrize("parts", [2, 8])

@@ -39,7 +39,7 @@ def test_random_geometry_full_path(psm, oracle, W, H, D, seed):
         l[: H // 2, : W // 2] = 90
         r[: H // 2, : W // 2] = 90
     ref = oracle.pipeline_f32(l, r, D, threads=4, want_volumes=True)
-    flags = int(rng.choice([0, 0, 0, 512, 128, 16]))
+    flags = int(rng.choice([0, 0, 0, 8192, 128, 8192 + 128]))
     with psm.DispEst(l, r, D) as de:
         de.set_option(capi.PSM_OPT_FLAGS, flags)
         if rng.random() < 0.5:
@@ -117,7 +117,7 @@ def test_random_geometry_two_phase_and_stripes(psm, oracle, W, H, D, seed):
         l[H // 3:, W // 3:] = 200
         r[H // 3:, W // 3:] = 200
     ref = (oracle.pipeline_u8 if dtype == "u8" else oracle.pipeline_f32)(l, r, D, threads=4)
-    flags = 1048576 | int(rng.choice([0, 0, 65536 * 0, 128 if dtype == "f32" else 0]))
+    flags = 1048576 | int(rng.choice([0, 0, 128 if dtype == "f32" else 0]))
     with psm.DispEst(l, r, D, dtype=dtype) as de:
         de.set_option(capi.PSM_OPT_FLAGS, flags)
         if rng.random() < 0.5:

@@ -474,10 +474,9 @@ def test_cpp_dispest_demo(psm, oracle, golden, tmp_path, mode, float_input):
     assert np.array_equal(lpp, exp)
 
 
-@pytest.mark.parametrize("flags", [0, 256, 128, 128 + 64, 16, 16 + 1, 16 + 2, 16 + 4, 512, 512 + 128, 4096, 8192, 8192 + 128, 16384, 16384 + 128, 65536, 262144, 262144 + 65536, 524288, 524288 + 65536,
-                                   1048576, 1048576 + 128, 2097152])
+@pytest.mark.parametrize("flags", [0, 128, 4096, 8192, 8192 + 128, 1048576, 1048576 + 128, 2097152])
 def test_tuning_flags_do_not_change_results(psm, oracle, flags):
-    """PSM_OPT_FLAGS only changes store policy / block traversal / CVC store width."""
+    """PSM_OPT_FLAGS picks which volumes are materialised and which select form runs - never a result."""
     from primestereomatch_amd import capi, synth
     H, W, D = 150, 260, 12          # 5 strips, 2 y-segments, W % 4 == 0
     l, r, _ = synth.make_pair(W, H, D, 5)
@@ -606,29 +605,3 @@ def test_two_phase_selection_on_shards(psm, oracle):
     finally:
         for s in shards:
             s.close()
-
-
-def test_seed_stride_tuner(psm, oracle):
-    """PSM_OPT_FLAGS 16777216: the stride of the seeding phase is tuned in place over the first frames of a geometry
-    (candidates 5, 4, 6, two frames each after three untimed ones): every frame gives the same maps, the tuner settles, a new
-    geometry (row stripe) starts it over; without the flag nothing is tuned."""
-    from primestereomatch_amd import capi, synth
-    W, H, D = 160, 40, 120
-    l, r, _ = synth.make_pair(W, H, D, seed=3)
-    ref = oracle.pipeline_f32(l, r, D, threads=8)
-    with psm.DispEst(l, r, D) as de:
-        de.set_option(capi.PSM_OPT_FLAGS, 16777216)
-        seen = []
-        for f in range(12):
-            de.CostConst_GPU(); de.CostFilter_GPU(); de.DispSelect_GPU()
-            assert np.array_equal(de.lDisMap, ref["ldisp"]) and np.array_equal(de.rDisMap, ref["rdisp"]), f
-            seen.append(de.seed_stride())
-        assert seen[0] == 0 and seen[-1] in (4, 5, 6), seen
-        de.set_rows(8, 30)                      # another geometry: measured again
-        de.CostConst_GPU(); de.CostFilter_GPU(); de.DispSelect_GPU()
-        assert de.seed_stride() == 0
-        assert np.array_equal(de.lDisMap[8:30], ref["ldisp"][8:30])
-    with psm.DispEst(l, r, D) as de:
-        for f in range(6):
-            de.CostConst_GPU(); de.CostFilter_GPU(); de.DispSelect_GPU()
-        assert de.seed_stride() == 0 and np.array_equal(de.lDisMap, ref["ldisp"])

@@ -28,7 +28,7 @@ def _full(psm, oracle, l, r, D, dtype):
 
 @pytest.mark.parametrize("W,H,D,dtype,flags,G", [(260, 150, 12, "f32", 0, 3), (200, 97, 20, "f32", 1048576, 4), (107, 20, 9, "f32", 0, 7),
                                                  (230, 64, 33, "u8", 0, 2), (214, 40, 19, "u8", 1048576, 5), (260, 40, 200, "f32", 0, 2),
-                                                 (330, 135, 16, "f32", 524288, 3), (120, 33, 8, "f32", 262144, 2),
+                                                 (330, 135, 16, "f32", 2097152, 3), (120, 33, 8, "f32", 1048576, 2),
                                                  (100, 12, 42, "u8", 0, 12), (100, 12, 42, "f32", 1048576, 12)])   # one row per stripe
 def test_row_stripes_equal_the_whole_image(psm, oracle, W, H, D, dtype, flags, G):
     from primestereomatch_amd import capi, synth
@@ -205,3 +205,28 @@ def test_cpp_host_mirror_row_stripes(psm, oracle, golden, tmp_path, ndev, mode):
     assert np.array_equal(lv, oracle.lr_check(ld, rd)[0])
     lpp = np.fromfile(tmp_path / "o_ldisp_pp.raw", np.uint8).reshape(H, W)
     assert np.array_equal(lpp, oracle.wgt_median(oracle.u8_to_f32(pair["l_bgr"]), oracle.fill_inv(ld, lv), lv, 64, right=False))
+
+
+def test_cpp_host_mirror_fgf_on_a_striped_host(psm, oracle, golden, tmp_path):
+    """The C++ DispEst mirror with several (logical) devices and the Fast Guided Filter: the FGF path has no stripes - the
+    first device filters the whole image (round-2 advisor finding: every device filtered the full image and the gather then
+    saw stripe bookkeeping that did not match) - and the maps equal the one-context FGF run."""
+    import os
+    import subprocess
+    from conftest import ROOT
+    demo = os.path.join(ROOT, "primestereomatch_amd", "lib", "psm_demo")
+    subprocess.run(["make", "-C", os.path.join(ROOT, "primestereomatch_amd", "host")], check=True, capture_output=True)
+    pair = golden("teddy_pair.npz")
+    H, W, _ = pair["l_bgr"].shape
+    pair["l_bgr"].tofile(tmp_path / "l.raw")
+    pair["r_bgr"].tofile(tmp_path / "r.raw")
+    env = dict(os.environ, PRIMESM_HIP_LIB=psm.capi.LIB_PATH, PSM_HOST_LOGICAL_STRIPES="1")
+    p = subprocess.run([demo, str(tmp_path / "l.raw"), str(tmp_path / "r.raw"), str(W), str(H), "64",
+                        str(tmp_path / "o"), "3", "f32", "0", "4", "1"], env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr
+    ref = oracle.pipeline_fgf(pair["l_bgr"], pair["r_bgr"], 64, s=4)
+    ld = np.fromfile(tmp_path / "o_ldisp.raw", np.uint8).reshape(H, W)
+    rd = np.fromfile(tmp_path / "o_rdisp.raw", np.uint8).reshape(H, W)
+    assert np.array_equal(ld, ref["ldisp"]) and np.array_equal(rd, ref["rdisp"])
+    lv = np.fromfile(tmp_path / "o_lvalid.raw", np.uint8).reshape(H, W)
+    assert np.array_equal(lv, oracle.lr_check(ld, rd)[0])
