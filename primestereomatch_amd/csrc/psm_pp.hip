@@ -30,6 +30,7 @@ namespace psm {
 constexpr int WM_R = 9;                 // MED_SZ / 2, include/PP.h:12
 constexpr int WM_K = 2 * WM_R + 1;      // 19
 constexpr int WM_TAPS = WM_K * WM_K;    // 361
+constexpr int WM_LANE_MIN = 8192;       // active pixels from which a sweep evaluates one pixel per LANE (k_wm_eval) instead of per wave
 
 // nxt[y][x] (x = 0..W) = smallest x' >= x with valid[y][x'] == 0, W if there is none; prog[y] = nxt[y][0]
 __global__ __launch_bounds__(64) void k_wm_next(const uint8_t *__restrict__ valid, int W, int *__restrict__ nxt, int *__restrict__ prog)
@@ -234,13 +235,14 @@ __global__ __launch_bounds__(256) void k_wm_seed(const uint8_t *__restrict__ val
 // stay in a register; the LDS column is touched only when the disparity changes.  Then the threshold scan over the bins in
 // ascending d (adding an empty bin is the identity).  LDS: maxDis x 256 bytes per wave (64 KB at D = 256: two waves per CU).
 template <bool RIGHT>
-__global__ __launch_bounds__(64) void k_wm_eval(const uint8_t *__restrict__ cur, const uint8_t *__restrict__ orig,
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2))) void k_wm_eval(const uint8_t *__restrict__ cur, const uint8_t *__restrict__ orig,
                                                const float4 *__restrict__ g1, const int *__restrict__ list, const int *n_act,
                                                uint8_t *__restrict__ newv, int *__restrict__ chg, int *n_chg, int W, int H, int maxDis)
 {
     extern __shared__ float hist[];          // [maxDis][64]
     const int lane = threadIdx.x;
     const int n = *n_act;
+    if (n < WM_LANE_MIN) return;               // short lists: k_wm_eval_w (latency of one evaluation instead of a batch's)
     for (int i0 = blockIdx.x * 64; i0 < n; i0 += gridDim.x * 64) {
         const bool live = i0 + lane < n;
         const int pix = list[live ? i0 + lane : i0];
@@ -250,18 +252,35 @@ __global__ __launch_bounds__(64) void k_wm_eval(const uint8_t *__restrict__ cur,
         float tot = 0.0f;
         int run_d = 0;                        // disparity of the current run (0: none) and its bin's sum so far
         float run_s = 0.0f;
-        for (int wy = -WM_R; wy <= WM_R; ++wy) {
+        // One window row at a time: its 19 + 19 loads (every lane its own pixel: uncoalesced, latency bound) are all issued
+        // before the first weight is formed, and the next row's are in flight while this row is accumulated.
+        float4 gq[2][WM_K];
+        int dq[2][WM_K];
+        auto issue_row = [&](int slot, int wy) __attribute__((always_inline)) {
             int qy = y + wy;
             qy = qy < 0 ? qy + H : (qy >= H ? qy - H : qy);
             const int rowo = qy * W;
-            for (int wx = -WM_R; wx <= WM_R; ++wx) {
-                int qx = x + wx;
+#pragma unroll
+            for (int k = 0; k < WM_K; ++k) {
+                int qx = x + k - WM_R;
                 qx = qx < 0 ? qx + W : (qx >= W ? qx - W : qx);
                 const int off = rowo + qx;
                 // raster order is index order: an earlier pixel shows its current iterate (= the input where it is valid),
                 // a later one - and the pixel itself - the input (src/PP.cpp:164-166 reads the map in place)
-                const int dep = off < pix ? cur[off] : orig[off];
-                const float w = wm_weight<RIGHT>(p, g1[off], wx, wy);
+                dq[slot][k] = off < pix ? cur[off] : orig[off];
+                gq[slot][k] = g1[off];
+            }
+        };
+        auto take_row = [&](int slot, int wy) __attribute__((always_inline)) {
+            // (the 19 weights first: independent double-precision chains - division, exp - the scheduler can interleave; with
+            // one or two waves per SIMD a single chain would run at its own latency)
+            float wk[WM_K];
+#pragma unroll
+            for (int k = 0; k < WM_K; ++k) wk[k] = wm_weight<RIGHT>(p, gq[slot][k], k - WM_R, wy);
+#pragma unroll
+            for (int k = 0; k < WM_K; ++k) {
+                const int dep = dq[slot][k];
+                const float w = wk[k];
                 if (dep != 0) tot = __fadd_rn(tot, w);
                 if (dep != 0 && dep < maxDis) {            // (dep >= maxDis cannot come out of a WTA over maxDis slices: no bin)
                     if (dep != run_d) {
@@ -272,7 +291,15 @@ __global__ __launch_bounds__(64) void k_wm_eval(const uint8_t *__restrict__ cur,
                     run_s = __fadd_rn(run_s, w);
                 }
             }
+        };
+        issue_row(0, -WM_R);
+        for (int wy = -WM_R; wy < WM_R; wy += 2) {     // rows wy (slot 0) and wy + 1 (slot 1); the last row after the loop
+            issue_row(1, wy + 1);
+            take_row(0, wy);
+            issue_row(0, wy + 2);
+            take_row(1, wy + 1);
         }
+        take_row(0, WM_R);
         if (run_d != 0) hist[run_d * 64 + lane] = run_s;
         // ---- threshold scan over the non-empty bins, ascending d (src/PP.cpp:184-192) ----
         const float half = __fdiv_rn(tot, 2.0f);
@@ -293,6 +320,125 @@ __global__ __launch_bounds__(64) void k_wm_eval(const uint8_t *__restrict__ cur,
             newv[pix] = (uint8_t)filterDep;
             chg[slot] = pix;
         }
+    }
+}
+
+// Short active lists (the tail sweeps: a few hundred pixels whose evaluation latency is what the sweep costs): one WAVE per
+// pixel - the 361 weights of a pixel are evaluated by the 64 lanes in parallel, the histogram bins and the total are then
+// accumulated in window raster order (lane l owns bins l, l+64, ..: every lane scans the (disparity, weight) pairs from LDS
+// and adds the ones that fall into its bins).  ~10 us per evaluation instead of ~80 us for a batch of 64, at 30x the
+// instructions per evaluation.
+template <bool RIGHT, int NB>
+__global__ __launch_bounds__(64) void k_wm_eval_w(const uint8_t *__restrict__ cur, const uint8_t *__restrict__ orig,
+                                               const float4 *__restrict__ g1, const int *__restrict__ list, const int *n_act,
+                                               uint8_t *__restrict__ newv, int *__restrict__ chg, int *n_chg, int W, int H, int maxDis)
+{
+    // NB == 1: taps in window raster order.  NB > 1: the voting taps stably partitioned by dep / 64 (bucket j holds, in raster
+    // order, the taps of the bins lane + 64 j, buckets back to back), so a lane walks every tap once instead of NB times;
+    // wsum[] keeps the raster order for the total.
+    __shared__ float2 taps[WM_TAPS + 3];
+    __shared__ float wsum[NB == 1 ? 1 : WM_TAPS + 3];
+    __shared__ float hist[64 * NB];
+    const int lane = threadIdx.x;
+    const int n = *n_act;
+    if (n >= WM_LANE_MIN) return;              // long lists: k_wm_eval
+    constexpr int WM_ROUNDS = (WM_TAPS + 63) / 64;
+    const unsigned long long below = (1ull << lane) - 1ull;
+    for (int i = blockIdx.x; i < n; i += gridDim.x) {
+        const int pix = list[i];
+        const int y = pix / W, x = pix - y * W;
+        const float4 p = g1[pix];
+        int cntj[NB], basej[NB];
+#pragma unroll
+        for (int j = 0; j < NB; ++j) cntj[j] = 0;
+        int dep[WM_ROUNDS], off[WM_ROUNDS];
+#pragma unroll
+        for (int k = 0; k < WM_ROUNDS; ++k) {
+            const int t = min(lane + 64 * k, WM_TAPS - 1);
+            const int wy = t / WM_K - WM_R, wx = t % WM_K - WM_R;
+            const int qy = (y + wy + H) % H, qx = (x + wx + W) % W;
+            off[k] = qy * W + qx;
+            // raster order is index order: an earlier pixel shows its current iterate (= the input where it is valid),
+            // a later one - and the pixel itself - the input (src/PP.cpp:164-166 reads the map in place)
+            dep[k] = off[k] < pix ? cur[off[k]] : orig[off[k]];
+            if (NB > 1) {
+#pragma unroll
+                for (int j = 0; j < NB; ++j)
+                    cntj[j] += __builtin_popcountll(__builtin_amdgcn_ballot_w64(lane + 64 * k < WM_TAPS && dep[k] != 0 && (dep[k] >> 6) == j));
+            }
+        }
+        if (NB > 1) {
+            int b = 0;
+#pragma unroll
+            for (int j = 0; j < NB; ++j) { basej[j] = b; b += cntj[j]; }
+        }
+        int fill[NB];
+#pragma unroll
+        for (int j = 0; j < NB; ++j) fill[j] = 0;
+#pragma unroll
+        for (int k = 0; k < WM_ROUNDS; ++k) {
+            const int t = min(lane + 64 * k, WM_TAPS - 1);
+            const int wy = t / WM_K - WM_R, wx = t % WM_K - WM_R;
+            const float w = wm_weight<RIGHT>(p, g1[off[k]], wx, wy);
+            const bool live = lane + 64 * k < WM_TAPS;
+            if (NB == 1) {
+                if (live) taps[t] = make_float2(__int_as_float(dep[k]), dep[k] != 0 ? w : 0.0f);
+            } else {
+                if (live) wsum[t] = dep[k] != 0 ? w : 0.0f;
+#pragma unroll
+                for (int j = 0; j < NB; ++j) {
+                    const bool mine = live && dep[k] != 0 && (dep[k] >> 6) == j;
+                    const unsigned long long m = __builtin_amdgcn_ballot_w64(mine);
+                    if (mine) taps[basej[j] + fill[j] + __builtin_popcountll(m & below)] = make_float2(__int_as_float(dep[k] & 63), w);
+                    fill[j] += __builtin_popcountll(m);
+                }
+            }
+        }
+        __syncthreads();
+        float acc[NB];
+#pragma unroll
+        for (int j = 0; j < NB; ++j) acc[j] = 0.0f;
+        float tot = 0.0f;
+        if (NB == 1) {
+#pragma unroll 19
+            for (int t = 0; t < WM_TAPS; ++t) {
+                const float2 tw = taps[t];
+                tot = __fadd_rn(tot, tw.y);
+                acc[0] = __fadd_rn(acc[0], __float_as_int(tw.x) == lane ? tw.y : 0.0f);
+            }
+        } else {
+#pragma unroll 19
+            for (int t = 0; t < WM_TAPS; ++t) tot = __fadd_rn(tot, wsum[t]);     // adding 0.0f for "does not vote" is the identity
+#pragma unroll
+            for (int j = 0; j < NB; ++j)
+                for (int t = 0; t < cntj[j]; ++t) {
+                    const float2 tw = taps[basej[j] + t];
+                    acc[j] = __fadd_rn(acc[j], __float_as_int(tw.x) == lane ? tw.y : 0.0f);
+                }
+        }
+#pragma unroll
+        for (int j = 0; j < NB; ++j) hist[lane + 64 * j] = acc[j];
+        __syncthreads();
+        const float half = __fdiv_rn(tot, 2.0f);
+        float run = 0.0f;
+        int filterDep = 0;
+        bool found = false;
+        if (run >= half) { filterDep = 0; found = true; }
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            unsigned long long m = __builtin_amdgcn_ballot_w64(acc[j] != 0.0f && lane + 64 * j < maxDis);
+            while (m && !found) {
+                const int b = __builtin_ctzll(m);
+                m &= m - 1;
+                run = __fadd_rn(run, hist[b + 64 * j]);
+                if (run >= half) { filterDep = b + 64 * j; found = true; }
+            }
+        }
+        if (lane == 0 && filterDep != (int)cur[pix]) {
+            newv[pix] = (uint8_t)filterDep;
+            chg[atomicAdd(n_chg, 1)] = pix;
+        }
+        __syncthreads();
     }
 }
 
@@ -346,6 +492,17 @@ void launch_wm_sweep(hipStream_t s, uint8_t *cur, const uint8_t *orig, const uin
     const dim3 ge(dev.nxcd * dev.cus_per_xcd * (per_cu < 1 ? 1 : per_cu));
     if (right) hipLaunchKernelGGL(k_wm_eval<true>, ge, dim3(64), lds, s, (const uint8_t *)cur, orig, g1, act, n_act, newv, chg, n_chg, W, H, maxDis);
     else hipLaunchKernelGGL(k_wm_eval<false>, ge, dim3(64), lds, s, (const uint8_t *)cur, orig, g1, act, n_act, newv, chg, n_chg, W, H, maxDis);
+    // ... and the one-wave-per-pixel form for short lists (either kernel returns at once when the list is not its size)
+    const int nb = (maxDis + 63) / 64;
+    const dim3 gw(8192);
+#define PSM_LAUNCH_WE(R, NBV) \
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_wm_eval_w<R, NBV>), gw, dim3(64), 0, s, (const uint8_t *)cur, orig, g1, act, n_act, newv, chg, n_chg, W, H, maxDis)
+    if (right) {
+        if (nb <= 1) PSM_LAUNCH_WE(true, 1); else if (nb == 2) PSM_LAUNCH_WE(true, 2); else if (nb == 3) PSM_LAUNCH_WE(true, 3); else PSM_LAUNCH_WE(true, 4);
+    } else {
+        if (nb <= 1) PSM_LAUNCH_WE(false, 1); else if (nb == 2) PSM_LAUNCH_WE(false, 2); else if (nb == 3) PSM_LAUNCH_WE(false, 3); else PSM_LAUNCH_WE(false, 4);
+    }
+#undef PSM_LAUNCH_WE
     hipLaunchKernelGGL(k_wm_apply, ga, dim3(64), 0, s, cur, (const uint8_t *)newv, valid, (const int *)chg, (const int *)n_chg, stamp, mark, next, n_next, W, H);
 }
 
