@@ -136,9 +136,25 @@ struct PcSide {
 struct PcSel {
     int sel, step;
     int nxcd;      // XCDs of the device (blocks are dispatched round-robin over them)
+    int spread;    // key form: dispatch the slices of a pair in `spread` interleaved passes (0 / 1: ascending)
+    int n;         // ... over n slices
 };
 __device__ __forceinline__ int pc_slice(const PcSel &o, int i)
 {
+    // Key form: the workgroups of one (column group, segment) pair that run at the same time would be CONSECUTIVE slices - the
+    // ones most likely to tie or nearly tie for a pixel's minimum, each deciding on a snapshot of the key that predates the
+    // others' updates (redundant atomics; with quantised 8-bit costs exact ties are the rule).  Dispatch position i -> slice
+    // index in `spread` passes (0, s, 2s, .. | 1, s+1, .. | ..): concurrent slices are s apart, a slice's lower neighbour has
+    // long finished when it starts - and a later tie loses against the lower d without an atomic.
+    if (o.spread > 1) {
+        int r = 0, base = 0;
+        for (; r < o.spread; ++r) {
+            const int cnt = (o.n - r + o.spread - 1) / o.spread;     // slices with index % spread == r
+            if (i < base + cnt) break;
+            base += cnt;
+        }
+        i = (i - base) * o.spread + r;
+    }
     return o.sel == 1 ? i * o.step : (o.sel == 2 ? (i / (o.step - 1)) * o.step + i % (o.step - 1) + 1 : i);
 }
 
@@ -298,10 +314,13 @@ void k_cvf_pc(
         if (CVC == 0) p = pin[K & 1];                                                               \
         else if (U8) {                                                                              \
             const unsigned b_ = inb ? po[K & 1] : 0xffffffffu;        /* border: the other image reads as 255 */ \
-            const unsigned clr_ = __builtin_amdgcn_sad_u8(pu[K & 1] & 0xffffffu, b_ & 0xffffffu, 0u); \
-            const int gd_ = (int)(pu[K & 1] >> 24) - (int)(b_ >> 24);                               \
-            const float f_ = __fadd_rn(__fmul_rn(0.9f, (float)(clr_ / 3u)), __fmul_rn(__fsub_rn(1.0f, 0.9f), (float)(gd_ < 0 ? -gd_ : gd_))); \
-            p = __fmul_rn((float)(unsigned)(unsigned char)f_, 1 / 255.0f);                          \
+            /* |gradient difference| and colour sum from two SADs (all four bytes, then the gradient byte alone); clr / 3 as a   \
+               24-bit multiply (clr <= 765: floor(clr * 21846 / 65536) == clr / 3); the truncating cast to uchar of a value in    \
+               [0, 256) as v_trunc_f32 - integer arithmetic and exact conversions only, same bits as oracle cost_u8 */           \
+            const unsigned grd_ = __builtin_amdgcn_sad_u8(pu[K & 1] & 0xff000000u, b_ & 0xff000000u, 0u); \
+            const unsigned clr_ = __builtin_amdgcn_sad_u8(pu[K & 1], b_, 0u) - grd_;                \
+            const float f_ = __fadd_rn(__fmul_rn(0.9f, (float)(__umul24(clr_, 21846u) >> 16)), __fmul_rn(__fsub_rn(1.0f, 0.9f), (float)grd_)); \
+            p = __fmul_rn(__builtin_truncf(f_), 1 / 255.0f);                                        \
         } else {                                                                                    \
             p = cost_pair(gin[K & 1], oth[LEANA ? 0 : (K & 1)]);                                    \
             if (LEANA) oth[0] = pc_load4(rGo, vcp, r101c(mstart - 5 + (S) + 1, H) * W * 16);   /* partner pixels of the next step: the current ones are dead now */ \
@@ -466,7 +485,7 @@ void k_cvf_pc(
                                     __fmul_rn(PSM_BOX(n1), o1y[LEANB ? (K & 1) : K])), __fmul_rn(PSM_BOX(n2), o1z[LEANB ? (K & 1) : K])); \
         if (U8) {   /* q8 = sat_u8(rintf(q * 255)), NaN -> 0 (oracle: quant_u8); kept as a float: the selection is unchanged */ \
             const float r_ = rintf(__fmul_rn(qv[K], 255.0f * QSCALE));   /* (255 * 2^-12 is exact: one rounding, as q * 255) */ \
-            qv[K] = !(r_ > 0.0f) ? 0.0f : (r_ > 255.0f ? 255.0f : r_);                              \
+            qv[K] = __builtin_amdgcn_fmed3f(r_, 0.0f, 255.0f);   /* saturate; a NaN input makes v_med3_f32 return min3 = 0 */ \
         } else if (SCALED) qv[K] = __fmul_rn(qv[K], QSCALE);                                        \
         if (LEANB) {                                                                                \
             PSM_ISSUE_PB(K & 1, j0 + K + 2)                                                         \
@@ -663,7 +682,11 @@ PcPlan pc_plan(int W, int rows, int Dloc, int seg_rows_opt, int form)
         const int nch = (Dloc + dc - 1) / dc;
         const long per_xcd = ((long)sides * pl.ngroups * kk * nch + dev.nxcd - 1) / dev.nxcd;
         const long rounds2 = 2 * ((per_xcd + slots - 1) / slots) + 1;   // 2 x (rounds + 1/2)
-        return rounds2 * dc * ((rows + kk - 1) / kk + 14) / 2 + (planes ? 2L * sides * nch : 0);
+        long c = rounds2 * dc * ((rows + kk - 1) / kk + 14) / 2 + (planes ? 2L * sides * nch : 0);
+        // one slice per plane rewrites every record (a chunk's later slices only the improved ones): +6 % once the planes of
+        // an image no longer sit in the L2s (measured at 1080p, 32 local slices: DC 1 / 2 = 1.28 / 1.17 ms; at 450 x 375 DC 1 wins)
+        if (planes && dc == 1) c += (long)(0.06 * c * ((double)W * rows >= 2097152.0 ? 1.0 : (double)W * rows / 2097152.0));
+        return c;
     };
     auto allowed = [&](int dc, int kk) { return (dc == dcs[0] || dc <= Dloc) && (seg_rows_opt <= 0 || kk == (rows + seg_rows_opt - 1) / seg_rows_opt); };
     long best = -1;
@@ -685,6 +708,8 @@ PcPlan pc_plan(int W, int rows, int Dloc, int seg_rows_opt, int form)
     return pl;
 }
 
+constexpr int PC_KEY_SPREAD = 4;    // passes of the key form's slice order (pc_slice; measured 1 / 2 / 4 / 8 / 16: f32 5.12 / 5.07 / 5.06 / 5.08 / 5.10 ms, 8-bit 5.94 / 5.82 / 5.80 / 5.81 / 5.83)
+
 int pc_seed_stride(int W, int H)
 {   // every S-th slice goes through the minima planes and seeds the key plane: 5, 4 from 4 Mpixel up
     const int e = pc_env("PSM_PC_S");
@@ -703,7 +728,7 @@ void launch_cvf_fused(hipStream_t s, March m, const float *vin, float *vout, Gui
 #define PSM_LAUNCH_PC(V4, CV)                                                                                              \
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_cvf_pc<V4, CV, 0>), grid, blk, 0, s, vin, vout, (const float4 *)gd.g1,            \
                        (const float4 *)gd.g2, (const float4 *)gd.g3, (const float2 *)gd.g4, W, H, Dloc, pl.ngroups, pl.nsegs, \
-                       pl.seg_rows, ybeg, yend, g1_other, d_begin, 1, (float *)nullptr, (unsigned *)nullptr, 0, PcSide{}, PcSel{0, 1, pl.nxcd}, (unsigned long long *)nullptr)
+                       pl.seg_rows, ybeg, yend, g1_other, d_begin, 1, (float *)nullptr, (unsigned *)nullptr, 0, PcSide{}, PcSel{0, 1, pl.nxcd, 0, Dloc}, (unsigned long long *)nullptr)
     const bool v4 = (W & 3) == 0;
     if (cvc_mode == 1) { if (v4) PSM_LAUNCH_PC(true, 1); else PSM_LAUNCH_PC(false, 1); }
     else if (cvc_mode == 2) { if (v4) PSM_LAUNCH_PC(true, 2); else PSM_LAUNCH_PC(false, 2); }
@@ -717,7 +742,7 @@ void launch_cvf_select(hipStream_t s, March m, const float *vin, Guidance gd, in
                        int d_begin, int cvc_mode, void *scratch, unsigned long long *ts, const uint8_t *p4_own, const uint8_t *p4_other)
 {
     const PcPlan pl = pc_plan(W, m.rows(H), Dloc, m.seg_rows, PC_PLANES);
-    const PcSel sel = {0, 1, pl.nxcd};
+    const PcSel sel = {0, 1, pl.nxcd, 0, Dloc};
     float *kcost = (float *)scratch;                                           // nchunks * rec_per_chunk float4
     unsigned *kdisp = (unsigned *)(kcost + 4 * pl.rec_per_chunk * pl.nchunks);  // nchunks * rec_per_chunk uchar4
     const dim3 grid(pc_blocks(pl, pl.nchunks)), blk(64 * (PcLayout<1>::NA + PcLayout<1>::NB));
@@ -752,7 +777,7 @@ void launch_cvf_select2(hipStream_t s, March m, const Guidance *g, int W, int H,
                         unsigned long long *ts, const uint8_t *const *p4, int sel, int step)
 {
     const PcPlan pl = pc_plan(W, m.rows(H), Dloc, m.seg_rows, PC_PLANES | PC_BOTH);
-    const PcSel ps = {sel, step, pl.nxcd};
+    const PcSel ps = {sel, step, pl.nxcd, 0, Dloc};
     float *kcost0 = (float *)scratch;
     unsigned *kdisp0 = (unsigned *)(kcost0 + 4 * pl.rec_per_chunk * pl.nchunks);
     float *kcost1 = (float *)((char *)scratch + pl.scratch_bytes());
@@ -786,7 +811,7 @@ void launch_cvf_select_keys2(hipStream_t s, March m, const Guidance *g, int W, i
                              unsigned long long *ts, const uint8_t *const *p4, int init, int sel, int step)
 {
     const PcPlan pl = pc_plan(W, m.rows(H), Dloc, m.seg_rows, PC_KEYS | PC_BOTH);
-    const PcSel ps = {sel, step, pl.nxcd};
+    const PcSel ps = {sel, step, pl.nxcd, pc_env("PSM_PC_SPREAD") > 0 ? pc_env("PSM_PC_SPREAD") : PC_KEY_SPREAD, Dloc};
     const size_t HW = (size_t)W * H;
     if (init) hipLaunchKernelGGL(k_fill_keys, dim3((unsigned)((2 * HW + 255) / 256)), dim3(256), 0, s, keys, 2 * HW);
     const dim3 grid(pc_blocks(pl, Dloc), 2), blk(64 * (PcLayout<2>::NA + PcLayout<2>::NB));

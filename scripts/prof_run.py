@@ -12,7 +12,7 @@ from primestereomatch_amd import capi, synth  # noqa: E402
 cfg = {"c4": (1920, 1080, 256), "c3": (1280, 720, 128), "c2": (450, 375, 64)}[sys.argv[1] if len(sys.argv) > 1 else "c4"]
 W, H, D = cfg
 l, r, _ = synth.make_pair(W, H, D, seed=0)
-de = P.DispEst(l, r, D)
+de = P.DispEst(l, r, D, dtype=os.environ.get("PSM_DTYPE", "f32"))
 if len(sys.argv) > 2:
     de.set_option(capi.PSM_OPT_SEG_ROWS, int(sys.argv[2]))
 if len(sys.argv) > 3:
@@ -21,7 +21,7 @@ if os.environ.get("PSM_FLAGS"):
     de.set_option(capi.PSM_OPT_FLAGS, int(os.environ["PSM_FLAGS"]))
 for _ in range(2):
     de.CostConst_GPU()
-    if not os.environ.get("PSM_FLAGS"):
+    if os.environ.get("PSM_BOX"):
         de.box8_volume(0, download=False)
     de.CostFilter_GPU()
     de.DispSelect_device()
