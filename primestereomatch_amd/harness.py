@@ -30,10 +30,13 @@ def error_vs_ground_truth(lDisMap, gt, mask, maxDis, scale_factor, error_thresho
 
 
 def compute(l_bgr, r_bgr, maxDis=64, gt=None, mask=None, scale_factor=4, error_threshold=4, threads=8,
-            dtype="f32", post_process=True, verbose=False, subsample_rate=0):
+            dtype="f32", post_process=True, verbose=False, subsample_rate=0, process_dm=False):
     """One frame of STEREO_GIF on the accelerator path.  l_bgr/r_bgr: H x W x 3 uint8 (imread order).
     subsample_rate 0: full guided filter (CostFilter_GPU, the reference's 'm' branch); 2/4/8: the Fast Guided
-    Filter variant (CostFilter_FGF, the snapshot's live branch, src/StereoMatch.cpp:213) on the device."""
+    Filter variant (CostFilter_FGF, the snapshot's live branch, src/StereoMatch.cpp:213) on the device.
+    process_dm: after the L-R check run the rest of PP::processDM's plain sequence on the device - fillInv, then wgtMedian
+    on the pixels the check rejected (src/PP.cpp:405-410; lrCheck and fillInv are commented out in the snapshot's live
+    processDM, wgtMedian is its dead-code predecessor of JointWMF) - the maps before it stay in lDisMap_raw / rDisMap_raw."""
     out = {}
     lFrame = np.ascontiguousarray(l_bgr)
     rFrame = np.ascontiguousarray(r_bgr)
@@ -51,15 +54,18 @@ def compute(l_bgr, r_bgr, maxDis=64, gt=None, mask=None, scale_factor=4, error_t
         else:
             SMDE.CostFilter_GPU()
         SMDE.DispSelect_GPU()
-        if post_process:
+        if post_process or process_dm:
             SMDE.LRCheck_GPU()
+            out["lValid"], out["rValid"] = SMDE.lValid.copy(), SMDE.rValid.copy()
+        if process_dm:
+            out["lDisMap_raw"], out["rDisMap_raw"] = SMDE.lDisMap.copy(), SMDE.rDisMap.copy()
+            SMDE.FillInv_GPU()
+            SMDE.WgtMedian_GPU()
         out["cvc_ms"] = SMDE.stage_time_us(capi.PSM_STAGE_CVC) / 1000
         out["cvf_ms"] = SMDE.stage_time_us(capi.PSM_STAGE_CVF) / 1000
         out["dispsel_ms"] = SMDE.stage_time_us(capi.PSM_STAGE_DISPSEL) / 1000
         out["pp_ms"] = SMDE.stage_time_us(capi.PSM_STAGE_PP) / 1000
         out["lDisMap"], out["rDisMap"] = SMDE.lDisMap.copy(), SMDE.rDisMap.copy()
-        if post_process:
-            out["lValid"], out["rValid"] = SMDE.lValid.copy(), SMDE.rValid.copy()
     out["lDispMap"] = np.clip(out["lDisMap"].astype(np.int32) * scale_factor, 0, 255).astype(np.uint8)
     if gt is not None:
         bp, avg, bad, emap = error_vs_ground_truth(out["lDisMap"], gt, mask, maxDis, scale_factor, error_threshold)

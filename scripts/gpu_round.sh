@@ -1,76 +1,74 @@
 #!/bin/bash
-# One full GPU-box session of a round: parity tests, smoke, benches of every config / variant, the torch.distributed path on
-# one GPU, rocprofv3 kernel trace + PMC passes (each in its own run).  Usage (via gpurun): bash scripts/gpu_round.sh r02
-TAG=${1:-r02}
+# One full GPU-box session of a round: parity tests, smoke, benches of every config, the torch.distributed path on
+# one GPU, rocprofv3 kernel trace + PMC passes (each in its own run).  Usage (via gpurun): bash scripts/gpu_round.sh r03
+TAG=${1:-r03}
 OUT=$GRAFT_REPO_ROOT/gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
-python -c "import __graft_entry__ as g; g.build()" > $OUT/build.log 2>&1 || echo "BUILD FAILED"
-rocminfo 2>/dev/null | grep -E "Marketing Name|gfx" | head -4 > $OUT/device.txt
-nproc >> $OUT/device.txt; grep -m1 "model name" /proc/cpuinfo >> $OUT/device.txt
+rocminfo 2>/dev/null | grep -E "Marketing Name|gfx" | head -4 | tr -s ' ' > $OUT/device.txt
+echo "host cores $(nproc)" >> $OUT/device.txt; grep -m1 "model name" /proc/cpuinfo >> $OUT/device.txt; date -u +%Y-%m-%dT%H:%MZ >> $OUT/device.txt; hostname >> $OUT/device.txt
 echo "== smoke"; timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2 | tee $OUT/smoke.log
 echo "== pytest -m gpu"
-timeout 1800 python -m pytest tests -m gpu -q -s -p no:cacheprovider --timeout=900 > $OUT/pytest_gpu.log 2>&1
+timeout 2400 python -m pytest tests -m gpu -q -s -p no:cacheprovider --timeout=1200 > $OUT/pytest_gpu.log 2>&1
 tail -3 $OUT/pytest_gpu.log
 grep -E "^\.?\[wmf\]|^\.?\[ocv-order\]" $OUT/pytest_gpu.log > $OUT/pytest_gpu_reports.txt
-echo "== bench (default: c4, N=1)"
-timeout 900 python bench.py --box-bench --verify > $OUT/bench_c4_n1.json 2> $OUT/bench_c4.err; cat $OUT/bench_c4_n1.json; tail -2 $OUT/bench_c4.err
+echo "== PMC passes first (own runs; kernel trace only): the headline line below then carries THIS session's traffic figure"
+cd /tmp
+for dt in f32 u8; do
+  pre=pmc_; [ $dt = u8 ] && pre=pmc_u8_
+  for pass in "rd:TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum" "wr:WRITE_SIZE TCC_EA0_WRREQ_sum" "sq:SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY"; do
+    n=${pass%%:*}; c=${pass#*:}
+    PSM_DTYPE=$dt timeout 300 rocprofv3 --kernel-trace --pmc $c -d $OUT/${pre}$n -o $n -- python $GRAFT_REPO_ROOT/scripts/prof_run.py c4 > $OUT/${pre}$n.log 2>&1 || echo "pmc pass $dt $n failed"
+    fdb=$(find $OUT/${pre}$n -name "*.db" | head -1); [ -n "$fdb" ] && python $GRAFT_REPO_ROOT/scripts/rocpd_summary.py $fdb > $OUT/${pre}$n.summary.txt 2>&1
+  done
+done
+for pass in "ft:FETCH_SIZE" "sqb:SQ_INSTS_SALU SQ_INSTS_VMEM SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_SCA" "lds:SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_LDS_ADDR_CONFLICT GRBM_GUI_ACTIVE" "tcc:TCC_ATOMIC_sum TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum"; do
+  n=${pass%%:*}; c=${pass#*:}
+  timeout 300 rocprofv3 --kernel-trace --pmc $c -d $OUT/pmc_$n -o $n -- python $GRAFT_REPO_ROOT/scripts/prof_run.py c4 > $OUT/pmc_$n.log 2>&1 || echo "pmc pass $n failed"
+  fdb=$(find $OUT/pmc_$n -name "*.db" | head -1); [ -n "$fdb" ] && python $GRAFT_REPO_ROOT/scripts/rocpd_summary.py $fdb > $OUT/pmc_$n.summary.txt 2>&1
+done
+cd $GRAFT_REPO_ROOT
+python scripts/make_traffic.py $OUT $TAG > $OUT/traffic.log 2>&1; tail -12 $OUT/traffic.log
+cp profiles/traffic.json $OUT/traffic.json
+echo "== bench (default: c4, N=1) - the headline line"
+timeout 900 python bench.py --box-bench --verify --pp > $OUT/bench_c4_n1.json 2> $OUT/bench_c4.err; cat $OUT/bench_c4_n1.json; tail -2 $OUT/bench_c4.err
 B="timeout 600 python bench.py"
-$B --config c3 --verify > $OUT/bench_c3_n1.json 2>> $OUT/bench_var.err
-$B --config c2 --steps 30 --verify > $OUT/bench_c2_n1.json 2>> $OUT/bench_var.err
+$B --config c3 --verify --pp > $OUT/bench_c3_n1.json 2>> $OUT/bench_var.err
+$B --config c2 --steps 30 --verify --pp > $OUT/bench_c2_n1.json 2>> $OUT/bench_var.err
 $B --config c5 --steps 4 --warmup 1 --verify > $OUT/bench_c5_n1.json 2>> $OUT/bench_var.err
 $B --config c1 --steps 30 --verify > $OUT/bench_c1_u8_n1.json 2>> $OUT/bench_var.err
 $B --config c1x --steps 30 --verify > $OUT/bench_c1x_u8_n1.json 2>> $OUT/bench_var.err
-$B --config c4 --dtype u8 --no-cpu-baseline --verify > $OUT/bench_c4_u8_n1.json 2>> $OUT/bench_var.err
+$B --config c4 --dtype u8 --verify > $OUT/bench_c4_u8_n1.json 2>> $OUT/bench_var.err
 $B --flags 2097152 --no-cpu-baseline --verify > $OUT/bench_c4_single_phase_n1.json 2>> $OUT/bench_var.err
 $B --flags 8192 --no-cpu-baseline --verify > $OUT/bench_c4_store_mode_n1.json 2>> $OUT/bench_var.err
-$B --flags 65536 --no-cpu-baseline --verify > $OUT/bench_c4_one_side_per_launch_n1.json 2>> $OUT/bench_var.err
-$B --flags 16384 --no-cpu-baseline --verify > $OUT/bench_c4_q2_variant_n1.json 2>> $OUT/bench_var.err
-$B --flags 16 --no-cpu-baseline > $OUT/bench_c4_twostage_n1.json 2>> $OUT/bench_var.err
 for s in 2 4 8; do $B --fgf $s --no-cpu-baseline > $OUT/bench_c4_fgf_s${s}_n1.json 2>> $OUT/bench_var.err; done
 for g in 2 4 8; do $B --shard-sim $g --steps 40 --no-cpu-baseline > $OUT/bench_c4_shardsim_1of$g.json 2>> $OUT/bench_var.err; done
 for g in 2 4 8; do $B --shard-sim $g --shard disp --steps 40 --no-cpu-baseline > $OUT/bench_c4_shardsim_disp_1of$g.json 2>> $OUT/bench_var.err; done
 $B --config c5 --shard-sim 8 --steps 6 --warmup 2 --no-cpu-baseline > $OUT/bench_c5_shardsim_1of8.json 2>> $OUT/bench_var.err
-echo "== weighted median timing (sweeps form / dataflow form)"
+echo "== weighted median timing (hybrid sweeps form / dataflow form)"
 timeout 300 python scripts/dbg_wmf.py big > $OUT/wmf_timing.txt 2>&1; WM_FLAGS=4194304 timeout 300 python scripts/dbg_wmf.py >> $OUT/wmf_timing.txt 2>&1; tail -22 $OUT/wmf_timing.txt
-echo "== torch.distributed path on 1 GPU (RCCL, world_size 1)"
+echo "== torch.distributed path on 1 GPU (RCCL, world_size 1): both sharding axes per invocation"
 D="timeout 600 python bench.py --gpus 1 --force-dist --steps 10 --warmup 3 --no-cpu-baseline"
 $D > $OUT/bench_c4_dist_world1.json 2> $OUT/bench_dist1.err
 $D --shard disp > $OUT/bench_c4_dist_world1_disp.json 2>> $OUT/bench_dist1.err
-$D --shard disp --exchange allgather > $OUT/bench_c4_dist_world1_allgather.json 2>> $OUT/bench_dist1.err
 $D --no-frame-pipeline > $OUT/bench_c4_dist_world1_nopipeline.json 2>> $OUT/bench_dist1.err
 python - <<PY
 import json,glob
 for f in sorted(glob.glob("$OUT/bench_*.json")):
     try:
         j=json.loads([ln for ln in open(f).read().strip().splitlines() if ln.startswith("{")][-1])
-        print(f.split('/')[-1], "%.3e vox/s"%j["value"], "%.3f ms"%j["ms_per_step"], {k:v["avg_ms"] for k,v in j["kernels"].items()}, "frac", j["roofline"]["frac"], "verified", j.get("verified_vs_single_gpu"), "cpu", (j.get("cpu_baseline") or {}).get("value"))
+        print(f.split('/')[-1], "%.3e vox/s"%j["value"], "%.3f ms"%j["ms_per_step"], {k:v["avg_ms"] for k,v in j["kernels"].items()}, "frac", j["roofline"]["frac"], "verified", j.get("verified_vs_single_gpu"), "oracle", j.get("oracle_maps_equal"), "cpu", (j.get("cpu_baseline") or {}).get("value"), "alt", (j.get("alt_shard") or {}).get("ms_per_step"))
     except Exception as e:
         print(f, "ERR", e)
 PY
 echo "== rocprofv3 kernel trace (same command as the bench)"
 cd /tmp
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -o trace -- python $GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 3 --no-cpu-baseline > $OUT/rocprof_stdout.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -o trace -- python $GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 3 --no-cpu-baseline --frame-loop 0 > $OUT/rocprof_stdout.log 2>&1
 f=$(find $OUT/prof -name "*kernel_trace.csv" | head -1); [ -n "$f" ] && python $GRAFT_REPO_ROOT/scripts/trace_gaps.py $f 20 > $OUT/trace_gaps_c4.txt 2>&1
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_s8 -o trace -- python $GRAFT_REPO_ROOT/bench.py --shard-sim 8 --steps 40 --warmup 3 --no-cpu-baseline > $OUT/rocprof_s8_stdout.log 2>&1
 f=$(find $OUT/prof_s8 -name "*kernel_trace.csv" | head -1); [ -n "$f" ] && python $GRAFT_REPO_ROOT/scripts/trace_gaps.py $f 20 > $OUT/trace_gaps_shard8.txt 2>&1
-echo "== rocprofv3 PMC passes (own runs; kernel trace only)"
-for pass in "rd:TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum" "wr:WRITE_SIZE TCC_EA0_WRREQ_sum" "ft:FETCH_SIZE" "sq:SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY" "sqb:SQ_INSTS_SALU SQ_INSTS_VMEM SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_SCA" "lds:SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_LDS_ADDR_CONFLICT GRBM_GUI_ACTIVE"; do
-  n=${pass%%:*}; c=${pass#*:}
-  PSM_FLAGS=0 timeout 300 rocprofv3 --kernel-trace --pmc $c -d $OUT/pmc_$n -o $n -- python $GRAFT_REPO_ROOT/scripts/prof_run.py c4 0 > $OUT/pmc_$n.log 2>&1 || echo "pmc pass $n failed"
-  fdb=$(find $OUT/pmc_$n -name "*.db" | head -1); [ -n "$fdb" ] && python $GRAFT_REPO_ROOT/scripts/rocpd_summary.py $fdb > $OUT/pmc_$n.summary.txt 2>&1
-done
-for pass in "sq:SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY" "lds:SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_LDS_ADDR_CONFLICT GRBM_GUI_ACTIVE"; do
-  n=${pass%%:*}; c=${pass#*:}
-  PSM_FLAGS=16384 timeout 300 rocprofv3 --kernel-trace --pmc $c -d $OUT/pmcq2_$n -o $n -- python $GRAFT_REPO_ROOT/scripts/prof_run.py c4 0 > $OUT/pmcq2_$n.log 2>&1 || echo "pmc pass q2 $n failed"
-  fdb=$(find $OUT/pmcq2_$n -name "*.db" | head -1); [ -n "$fdb" ] && python $GRAFT_REPO_ROOT/scripts/rocpd_summary.py $fdb > $OUT/pmcq2_$n.summary.txt 2>&1
-done
 cd $GRAFT_REPO_ROOT
-python scripts/make_traffic.py $OUT "k_cvf_pc<false, 3, 1|k_cvf_pc<false, 3, 2" "profiles/$TAG/rocprofv3_pmc_{rd,wr}.summary.txt" > $OUT/traffic.log 2>&1; tail -8 $OUT/traffic.log
-cp profiles/traffic.json $OUT/traffic.json
-echo "== headline line again, carrying this session's traffic figure"
-timeout 900 python bench.py --box-bench --verify > $OUT/bench_c4_n1.json 2> $OUT/bench_c4.err; python -c "import json;j=json.load(open('$OUT/bench_c4_n1.json'));print(j['value'],j['ms_per_step'],j['roofline'])"
 echo "== per-role cycle counters (debug build, if present)"
 if [ -f primestereomatch_amd/lib/libprimesm_hip_dbg.so ]; then PRIMESM_HIP_LIB=$GRAFT_REPO_ROOT/primestereomatch_amd/lib/libprimesm_hip_dbg.so python scripts/dbg_pc_timing.py > $OUT/role_cycles.txt 2>&1; cat $OUT/role_cycles.txt; fi
 find $OUT -name "*.db" -delete; find $OUT -name "*kernel_trace.csv" -size +3M -delete

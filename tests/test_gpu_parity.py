@@ -507,6 +507,21 @@ def test_harness_reproduces_reference_metric(psm, oracle, golden, name):
     assert out["cvf_ms"] > 0 and out["dispsel_ms"] > 0
 
 
+def test_harness_process_dm_sequence(psm, oracle, golden):
+    """harness.compute(process_dm=True): lrCheck -> fillInv -> wgtMedian on the device (the plain sequence of PP::processDM,
+    src/PP.cpp:405-410) - every stage equal to the oracle's, end to end on the Cones pair."""
+    from primestereomatch_amd import harness
+    pair = golden("cones_pair.npz")
+    out = harness.compute(pair["l_bgr"], pair["r_bgr"], 64, gt=pair["gt_l"], mask=pair["occl"], scale_factor=4, process_dm=True)
+    lv, rv = oracle.lr_check(out["lDisMap_raw"], out["rDisMap_raw"])
+    assert np.array_equal(out["lValid"], lv) and np.array_equal(out["rValid"], rv)
+    lf, rf = oracle.u8_to_f32(pair["l_bgr"]), oracle.u8_to_f32(pair["r_bgr"])
+    el = oracle.wgt_median(lf, oracle.fill_inv(out["lDisMap_raw"], lv), lv, 64, right=False)
+    er = oracle.wgt_median(rf, oracle.fill_inv(out["rDisMap_raw"], rv), rv, 64, right=True)
+    assert np.array_equal(out["lDisMap"], el) and np.array_equal(out["rDisMap"], er)
+    assert out["pp_ms"] > 0 and out["bp_percent"] > 0
+
+
 def test_fill_invalid_synthetic_width(psm, oracle):
     from primestereomatch_amd import synth
     l, r, _ = synth.make_pair(300, 40, 24, 9)
