@@ -142,6 +142,28 @@ int DispEst::WgtMedian_GPU()
     return hipUtil::api().wgt_median(ctx[0], lDisMap.data, rDisMap.data, lDisMap.step);
 }
 
+int DispEst::computeFrame(const Mat *nextL, const Mat *nextR, bool have_prev)
+{
+    if (ctx.size() != 1) return 1;           // (a multi-device host gathers stripes: use the stage calls)
+    const HipApi &api = hipUtil::api();
+    psm_ctx *c = ctx[0];
+    int rc = api.cost_construct(c);
+    if (nextL && nextR)
+        rc |= api.upload_pair_async(c, nextL->data, nextR->data, nextL->channels, nextL->step,
+                                    nextL->depth == PSM_32F ? PSM_IMG_F32 : PSM_IMG_U8);
+    rc |= api.cost_filter(c);
+    rc |= api.disp_select(c, nullptr, nullptr, 0);
+    if (have_prev) rc |= api.download_maps_wait(c, lDisMap.data, rDisMap.data, lDisMap.step);
+    rc |= api.download_maps_async(c);
+    return rc;
+}
+
+int DispEst::finishFrames()
+{
+    if (ctx.size() != 1) return 1;
+    return hipUtil::api().download_maps_wait(ctx[0], lDisMap.data, rDisMap.data, lDisMap.step);
+}
+
 double DispEst::stageTimeUs(int stage) const
 {
     double us = 0;

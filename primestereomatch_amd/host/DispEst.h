@@ -78,6 +78,13 @@ public:
     // pixels PostProcess_GPU marked invalid; same result as the reference's sequential in-place form
     int WgtMedian_GPU();
 
+    // Frame loop (src/main.cpp:64-73) with the PCIe legs next to the kernels (single-device hosts): one call per frame -
+    // CostConst (adopts the pair staged by the previous call), stages `next` pair (may be NULL at the end of the stream: its
+    // Mats are free again on return), CostFilter, DispSelect on the device, hands over the PREVIOUS frame's maps in
+    // lDisMap / rDisMap (have_prev: there was one) and starts this frame's download.  finishFrames() returns the last maps.
+    int computeFrame(const Mat *nextL, const Mat *nextR, bool have_prev);
+    int finishFrames();
+
     bool ok() const { return !ctx.empty(); }
     double stageTimeUs(int stage) const;
 

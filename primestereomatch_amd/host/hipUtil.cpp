@@ -40,6 +40,8 @@ bool hipUtil::load(const char *path)
     bool ok = bind(g_api.device_count, "psm_device_count") && bind(g_api.create_shard, "psm_create_shard") &&
               bind(g_api.destroy, "psm_destroy") && bind(g_api.last_error, "psm_last_error") &&
               bind(g_api.set_option, "psm_set_option") && bind(g_api.upload_pair, "psm_upload_pair") &&
+              bind(g_api.upload_pair_async, "psm_upload_pair_async") && bind(g_api.download_maps_async, "psm_download_maps_async") &&
+              bind(g_api.download_maps_wait, "psm_download_maps_wait") &&
               bind(g_api.cost_construct, "psm_cost_construct") && bind(g_api.cost_filter, "psm_cost_filter") &&
               bind(g_api.cost_filter_fgf, "psm_cost_filter_fgf") &&
               bind(g_api.disp_select, "psm_disp_select") && bind(g_api.disp_select_partial, "psm_disp_select_partial") &&

@@ -19,6 +19,9 @@ struct HipApi {
     const char *(*last_error)(const psm_ctx *) = nullptr;
     int (*set_option)(psm_ctx *, int, int) = nullptr;
     int (*upload_pair)(psm_ctx *, const void *, const void *, int, size_t, int) = nullptr;
+    int (*upload_pair_async)(psm_ctx *, const void *, const void *, int, size_t, int) = nullptr;
+    int (*download_maps_async)(psm_ctx *) = nullptr;
+    int (*download_maps_wait)(psm_ctx *, uint8_t *, uint8_t *, size_t) = nullptr;
     int (*cost_construct)(psm_ctx *) = nullptr;
     int (*cost_filter)(psm_ctx *) = nullptr;
     int (*cost_filter_fgf)(psm_ctx *, int) = nullptr;

@@ -1,9 +1,13 @@
 // psm_demo - headless counterpart of the reference's StereoMatch::compute accelerator branch
 // (src/StereoMatch.cpp:193-262): raw B,G,R uint8 pair in, four timed stages, raw uint8 maps out.
-//   psm_demo <left.raw> <right.raw> <W> <H> <maxDis> <out_prefix> [ndev] [f32|u8] [float_input] [fgf_rate] [pp]
+//   psm_demo <left.raw> <right.raw> <W> <H> <maxDis> <out_prefix> [ndev] [f32|u8] [float_input] [fgf_rate] [pp] [frames]
+// frames > 0: additionally run that many frames of the pair through DispEst::computeFrame (asynchronous upload of the next
+// pair / download of the previous maps: the frame loop of src/main.cpp:64-73), dump its last maps as <out>_ldisp_loop.raw and
+// print the time per frame
 // fgf_rate 0 (default): CostFilter_GPU; 2/4/8: CostFilter_FGF_GPU with that subsample rate
 // pp 1: after the left-right check also fillInv + wgtMedian (the stages of PP::processDM, src/PP.cpp:405-410); the
 //       post-processed maps go to <out_prefix>_ldisp_pp.raw / _rdisp_pp.raw
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -32,7 +36,7 @@ static bool dump(const std::string &path, const unsigned char *p, size_t n)
 int main(int argc, char **argv)
 {
     if (argc < 7) {
-        fprintf(stderr, "usage: %s left.raw right.raw W H maxDis out_prefix [ndev] [f32|u8] [float_input] [fgf_rate] [pp]\n", argv[0]);
+        fprintf(stderr, "usage: %s left.raw right.raw W H maxDis out_prefix [ndev] [f32|u8] [float_input] [fgf_rate] [pp] [frames]\n", argv[0]);
         return 2;
     }
     const int W = atoi(argv[3]), H = atoi(argv[4]), D = atoi(argv[5]);
@@ -42,6 +46,7 @@ int main(int argc, char **argv)
     const bool float_input = argc > 9 && atoi(argv[9]) != 0;
     const int fgf_rate = argc > 10 ? atoi(argv[10]) : 0;
     const bool pp = argc > 11 && atoi(argv[11]) != 0;
+    const int frames = argc > 12 ? atoi(argv[12]) : 0;
     std::vector<unsigned char> lraw, rraw;
     if (!slurp(argv[1], lraw, (size_t)W * H * 3) || !slurp(argv[2], rraw, (size_t)W * H * 3)) {
         fprintf(stderr, "psm_demo: cannot read the input pair\n");
@@ -84,6 +89,16 @@ int main(int argc, char **argv)
     if (ok && pp) {
         if (SMDE.FillInvalid_GPU() || SMDE.WgtMedian_GPU()) return 5;
         ok = dump(out + "_ldisp_pp.raw", SMDE.lDisMap.data, (size_t)W * H) && dump(out + "_rdisp_pp.raw", SMDE.rDisMap.data, (size_t)W * H);
+    }
+    if (ok && frames > 0 && ndev == 1 && !fgf_rate) {
+        SMDE.setInputImages(l, r);
+        const auto t0 = std::chrono::steady_clock::now();
+        for (int i = 0; i < frames; ++i)
+            if (SMDE.computeFrame(i + 1 < frames ? &l : nullptr, i + 1 < frames ? &r : nullptr, i > 0)) return 5;
+        if (SMDE.finishFrames()) return 5;
+        const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        printf("Frame loop:	 %d frames, %4.3f ms per frame (H2D of every pair and D2H of every pair of maps included)\n", frames, ms / frames);
+        ok = dump(out + "_ldisp_loop.raw", SMDE.lDisMap.data, (size_t)W * H) && dump(out + "_rdisp_loop.raw", SMDE.rDisMap.data, (size_t)W * H);
     }
     return ok ? 0 : 6;
 }

@@ -6,8 +6,9 @@ OUT=$GRAFT_REPO_ROOT/gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
-rocminfo 2>/dev/null | grep -E "Marketing Name|gfx" | head -4 | tr -s ' ' > $OUT/device.txt
-echo "host cores $(nproc)" >> $OUT/device.txt; grep -m1 "model name" /proc/cpuinfo >> $OUT/device.txt; date -u +%Y-%m-%dT%H:%MZ >> $OUT/device.txt; hostname >> $OUT/device.txt
+GFX=$(rocminfo 2>/dev/null | grep -m1 -oE "gfx9[0-9a-f]+")
+CPU=$(grep -m1 "model name" /proc/cpuinfo | sed 's/.*: //')
+echo "$TAG $(date -u +%Y-%m-%dT%H:%MZ): $GFX (MI355X), host $CPU, $(nproc) cores, box $(hostname)" > $OUT/device.txt
 echo "== smoke"; timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2 | tee $OUT/smoke.log
 echo "== pytest -m gpu"
 timeout 2400 python -m pytest tests -m gpu -q -s -p no:cacheprovider --timeout=1200 > $OUT/pytest_gpu.log 2>&1

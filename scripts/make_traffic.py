@@ -44,7 +44,7 @@ def main():
                     "avg_launch_ms; *_valu_insts = SQ_INSTS_VALU per launch (same mean), *_four_cycle_share = share of 4-cycle "
                     "VALU ops in the loop bodies (scripts/isa_mix.py), weighted by the two launches' instruction counts.",
         "_source": f"profiles/{tag}/rocprofv3_pmc_{{rd,wr,sq}}*.summary.txt",
-        "_session": f"{tag}: {session}",
+        "_session": session,
     }
     for dt, u8 in (("f32", "false"), ("u8", "true")):
         pre = "pmc_" if dt == "f32" else "pmc_u8_"

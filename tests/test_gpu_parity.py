@@ -459,9 +459,9 @@ def test_cpp_dispest_demo(psm, oracle, golden, tmp_path, mode, float_input):
     pair["r_bgr"].tofile(tmp_path / "r.raw")
     env = dict(os.environ, PRIMESM_HIP_LIB=psm.capi.LIB_PATH)
     p = subprocess.run([demo, str(tmp_path / "l.raw"), str(tmp_path / "r.raw"), str(W), str(H), "64",
-                        str(tmp_path / "o"), "1", mode, str(float_input), "0", "1"], env=env, capture_output=True, text=True, timeout=300)
+                        str(tmp_path / "o"), "1", mode, str(float_input), "0", "1", "5"], env=env, capture_output=True, text=True, timeout=300)
     assert p.returncode == 0, p.stderr
-    assert "CVF Time" in p.stdout
+    assert "CVF Time" in p.stdout and "Frame loop" in p.stdout
     ld = np.fromfile(tmp_path / "o_ldisp.raw", np.uint8).reshape(H, W)
     rd = np.fromfile(tmp_path / "o_rdisp.raw", np.uint8).reshape(H, W)
     key = ("ldisp", "rdisp") if mode == "f32" else ("ldisp_u8mode", "rdisp_u8mode")
@@ -472,6 +472,10 @@ def test_cpp_dispest_demo(psm, oracle, golden, tmp_path, mode, float_input):
     lpp = np.fromfile(tmp_path / "o_ldisp_pp.raw", np.uint8).reshape(H, W)
     exp = oracle.wgt_median(oracle.u8_to_f32(pair["l_bgr"]), oracle.fill_inv(ld, lv), lv, 64, right=False)
     assert np.array_equal(lpp, exp)
+    # frames = 5: DispEst::computeFrame (asynchronous upload of the next pair / download of the previous maps): same maps
+    ll = np.fromfile(tmp_path / "o_ldisp_loop.raw", np.uint8).reshape(H, W)
+    rl = np.fromfile(tmp_path / "o_rdisp_loop.raw", np.uint8).reshape(H, W)
+    assert np.array_equal(ll, gold[key[0]]) and np.array_equal(rl, gold[key[1]])
 
 
 @pytest.mark.parametrize("flags", [0, 128, 4096, 8192, 8192 + 128, 1048576, 1048576 + 128, 2097152])
