@@ -15,8 +15,8 @@ import primestereomatch_amd as P          # noqa: E402
 from primestereomatch_amd import capi, synth   # noqa: E402
 import psm_oracle_py as O                 # noqa: E402
 
-SAFE_FLAGS = [0, 0, 0, 1048576, 2097152, 262144, 524288, 16777216, 1048576 | 16777216]     # compatible with row stripes
-ANY_FLAGS = SAFE_FLAGS + [128, 256, 65536, 8192]
+SAFE_FLAGS = [0, 0, 0, 1048576, 2097152]     # compatible with row stripes
+ANY_FLAGS = SAFE_FLAGS + [128, 8192, 8192 | 128]
 
 
 def episode(rng, idx):
@@ -27,14 +27,19 @@ def episode(rng, idx):
     pipe = O.pipeline_u8 if dtype == "u8" else O.pipeline_f32
     refs = [pipe(l, r, D, threads=8, want_volumes=(dtype == "f32" and D <= 16)) for l, r in pairs]
     log = [f"episode {idx}: {W}x{H} D={D} {dtype}"]
-    cur = 0
+    cur, pend = 0, None
     y0, y1 = 0, H
     with P.DispEst(pairs[0][0], pairs[0][1], D, dtype=dtype) as de:
         for step in range(int(rng.integers(4, 12))):
-            op = rng.choice(["frame", "frame", "frame", "images", "rows", "flags", "volume", "pp"])
+            op = rng.choice(["frame", "frame", "frame", "images", "images_async", "rows", "flags", "volume", "pp", "frame_async"])
             if op == "images":
                 cur = int(rng.integers(0, 3))
+                pend = None                     # a blocking upload supersedes a staged pair
                 de.setInputImages(*pairs[cur]); log.append(f"images {cur}")
+                continue
+            if op == "images_async":            # staged for the NEXT CostConst (psm_upload_pair_async)
+                pend = int(rng.integers(0, 3))
+                de.setInputImages_async(*pairs[pend]); log.append(f"images_async {pend}")
                 continue
             if op == "rows":
                 if rng.random() < 0.4:
@@ -51,7 +56,13 @@ def episode(rng, idx):
                     fl = 0
                 de.set_option(capi.PSM_OPT_FLAGS, fl); log.append(f"flags {fl}")
                 continue
-            de.CostConst_GPU(); de.CostFilter_GPU(); de.DispSelect_GPU()
+            if pend is not None:                # CostConst adopts the staged pair
+                cur, pend = pend, None
+            if op == "frame_async":             # maps through psm_download_maps_async / _wait
+                de.CostConst_GPU(); de.CostFilter_GPU(); de.DispSelect_device()
+                de.download_maps_async(); de.download_maps_wait()
+            else:
+                de.CostConst_GPU(); de.CostFilter_GPU(); de.DispSelect_GPU()
             ref = refs[cur]
             log.append(f"frame pair {cur} rows {y0},{y1}")
             if not (np.array_equal(de.lDisMap[y0:y1], ref["ldisp"][y0:y1]) and np.array_equal(de.rDisMap[y0:y1], ref["rdisp"][y0:y1])):
