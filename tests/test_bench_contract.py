@@ -112,3 +112,40 @@ def test_bare_multi_gpu_command_becomes_its_own_launcher(monkeypatch):
     monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "400", "--config", "c2"])
     with pytest.raises(SystemExit):
         bench.main()
+
+
+def test_round3_lines():
+    """profiles/r03: the line is self-consistent (kernel times from the timed region sum to the step), checks its own maps
+    against the oracle, and carries the physical rates next to the algorithmic one."""
+    j = _line_r("r03", "bench_c4_n1.json")
+    W, H, D = j["config"]["W"], j["config"]["H"], j["config"]["D"]
+    assert (W, H, D) == (1920, 1080, 256) and j["dtype"] == "f32" and j["n_gpus"] == 1 and j["vs_baseline"] is None
+    assert abs(j["value"] - 2.0 * W * H * D / (j["ms_per_step"] * 1e-3)) / j["value"] < 1e-6
+    assert j["oracle_maps_equal"] is True and j["oracle_map_mismatches"] == [0, 0] and j["verified_vs_single_gpu"] is True
+    r = j["roofline"]
+    assert r["bound"] == "hbm" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    assert abs(r["achieved"] - r["alg_bytes_per_launch"] / (r["avg_launch_ms"] * 1e-3) / 1e9) / r["achieved"] < 1e-3
+    k = j["kernels"]["cvf_fused"]
+    assert "timed region" in k["source"] and set(k["by_form"]) == {"planes", "keys"}
+    lps = round(k["launches_per_step"])
+    assert lps == 2 and r["alg_bytes_per_launch"] * lps == 48.0 * 2 * W * H * D
+    # per-kernel times describe the step they were taken in: they sum to it (2 % slack for the four small kernels' event pass)
+    assert j["kernels_sum_ms_per_step"] <= 1.02 * j["ms_per_step"]
+    assert k["avg_ms"] * k["launches_per_step"] <= j["ms_per_step"]
+    # physical rates beside the algorithmic one, all from this session
+    assert 0 < r["traffic"] < r["alg_bytes_per_launch"] and 0 < r["traffic_frac"] < 0.2 and r["traffic_session"].startswith("r03")
+    v = r["valu"]
+    assert 0.5 < v["four_cycle_share"] < 0.8 and 0.7 < v["frac_of_valu_bound"] <= 1.0
+    fl = j["pcie"]["frame_loop"]
+    assert fl["maps_equal_timed_path"] is True and fl["ms_per_frame"] < j["ms_per_step"] + j["pcie"]["h2d_ms"]   # overlapped
+    assert j["pp"]["verified_vs_oracle"] is True
+    c = j["cpu_baseline"]
+    assert c["kind"] == "port" and c["cores"] == 8 and c["unit"] == j["unit"] and c["value"] > 0
+    for name, dt in (("bench_c3_n1.json", "f32"), ("bench_c2_n1.json", "f32"), ("bench_c1_u8_n1.json", "u8"), ("bench_c1x_u8_n1.json", "u8"),
+                     ("bench_c4_u8_n1.json", "u8")):
+        q = _line_r("r03", name)
+        assert q["dtype"] == dt and q["cpu_baseline"]["value"] > 0 and q["verified_vs_single_gpu"] is True and q["oracle_maps_equal"] is True, name
+    for name in ("bench_c4_dist_world1.json", "bench_c4_dist_world1_disp.json", "bench_c4_dist_world1_nopipeline.json"):
+        q = _line_r("r03", name)
+        assert q["verified_vs_single_gpu"] is True and q["scaling"] == "strong", name
+        assert q["alt_shard"]["verified_vs_single_gpu"] is True and q["alt_shard"]["shard"] != q["config"]["shard"], name
