@@ -398,13 +398,16 @@ def main():
         timed_maps = [m.copy() for m in de.download_maps()]
 
     # ---- PCIe legs the reference's stage timers include (src/StereoMatch.cpp:227-237), never part of `value` ----
+    # (N > 1: step() contains the frame's collective - EVERY rank runs the same sequence of steps here and below; only the
+    # measuring and the downloads are rank 0's)
     pcie = None
-    if rank == 0 and args.shard_sim <= 1:
+    if args.shard_sim <= 1:
         sync()
         ts = time.perf_counter()
         de.setInputImages(l, r)              # H2D of the u8 pair (blocking)
         h2d = 1e3 * (time.perf_counter() - ts)
         step(); sync()                       # maps of this pair on the device again
+    if rank == 0 and args.shard_sim <= 1:
         de.download_maps()                   # (first call allocates the library's page-locked bounce buffer)
         ts = time.perf_counter()
         de.download_maps()                   # D2H of the two u8 maps (blocking)

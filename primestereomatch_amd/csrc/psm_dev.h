@@ -120,10 +120,11 @@ __device__ __forceinline__ float recombine(float ma0, float ma1, float ma2, floa
 __device__ __forceinline__ long long pack_key_f32(float cost, int d)
 {
     cost = __fadd_rn(cost, 0.0f);  // -0 -> +0 so that equal costs compare equal
-    unsigned u = __float_as_uint(cost);
-    u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);  // monotone map float -> uint
-    unsigned long long k = ((unsigned long long)u << 32) | (unsigned)d;
-    return (long long)(k ^ 0x8000000000000000ull);   // signed-comparable
+    // monotone map float -> signed int: non-negative floats keep their bits, negative ones get their magnitude bits flipped
+    // (the same 64 bits as ((b < 0 ? ~b : b | 0x80000000) << 32 | d) ^ (1 << 63), in three integer ops instead of five)
+    const int b = __float_as_int(cost);
+    const int hi = b ^ ((b >> 31) & 0x7fffffff);
+    return (long long)(((unsigned long long)(unsigned)hi << 32) | (unsigned)d);
 }
 
 }  // namespace psm
