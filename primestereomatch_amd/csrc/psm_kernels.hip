@@ -103,26 +103,30 @@ __device__ __forceinline__ void guide_finish(const float *m, float4 &g2, float4 
     g4 = make_float2(A12, A22);
 }
 
-__global__ __launch_bounds__(64) void k_guide_march(const float4 *g1, int W, int H, int nstrips, int seg_rows,
-                                                   float4 *g2, float4 *g3, float2 *g4, Guidance second, int ybeg, int yend)
+// Three waves per (strip, segment): wave w marches three of the nine channels (its own sliding trees: 42 tree registers
+// instead of 126, so six and more waves per SIMD instead of two) and parks the three means of every output pixel in LDS;
+// after each batch of four rows all 192 threads share the per-pixel finish (variances, adjugate, 1/DET) of the batch's
+// 4 x 56 pixels.  Round 2 ran one wave per (strip, segment) with all nine trees: one resident round of two waves per SIMD,
+// i.e. the kernel took as long as ONE wave's serial march (54 us at 1080p, 19 us at 450 x 375).  Same arithmetic, same bits.
+__global__ __launch_bounds__(192) void k_guide_march(const float4 *g1, int W, int H, int nstrips, int seg_rows,
+                                                    float4 *g2, float4 *g3, float2 *g4, Guidance second, int ybeg, int yend)
 {
+    __shared__ float ms[2][4][9][64];            // [batch parity][row of the batch][channel][lane]
     if (blockIdx.y == 1) { g1 = second.g1; g2 = second.g2; g3 = second.g3; g4 = second.g4; }   // second image of a two-image launch
     const int strip = blockIdx.x % nstrips, seg = blockIdx.x / nstrips;
-    const int lane = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int x0 = strip * 56;
-    const int cs = r101c(x0 - 4 + lane, W), xo = x0 + lane;
-    const bool ovalid = lane < 56 && xo < W;
+    const int cs = r101c(x0 - 4 + lane, W);
     const int y0 = ybeg + seg * seg_rows, y1 = min(yend, y0 + seg_rows);   // output rows [y0, y1) of the rows [ybeg, yend) asked for
     const int n = (y1 - y0) + 7, ybase = y0 - 4;
     const int i1 = ((lane + 1) & 63) << 2, i2 = ((lane + 2) & 63) << 2, i4 = ((lane + 4) & 63) << 2;
     (void)i1;
-    VTree t[9] = {};
-    // the image rows of the next batch of four steps are in flight while this batch computes: one step is ~400 cycles of
-    // VALU work, less than the load latency, so a one-row lookahead left every step waiting for memory
+    VTree t[3] = {};
+    // the image rows of the next batch of four steps are in flight while this batch computes
     float4 gq[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) gq[k] = g1[(size_t)r101c(ybase + k, H) * W + cs];
-    for (int i = 0; i < n; i += 4) {
+    for (int i = 0, b = 0; i < n; i += 4, ++b) {
         float4 gc[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) gc[k] = gq[k];
@@ -131,20 +135,31 @@ __global__ __launch_bounds__(64) void k_guide_march(const float4 *g1, int W, int
 #define PSM_STEP_G(K)                                                                              \
     {                                                                                              \
         const float4 g = gc[K];                                                                    \
-        float v[9] = {g.x, g.y, g.z, __fmul_rn(g.x, g.x), __fmul_rn(g.x, g.y), __fmul_rn(g.x, g.z), \
-                      __fmul_rn(g.y, g.y), __fmul_rn(g.y, g.z), __fmul_rn(g.z, g.z)};              \
-        float m[9];                                                                                \
-        _Pragma("unroll") for (int c = 0; c < 9; ++c) m[c] = box_out(vstep<K>(t[c], hsum8(v[c], i1, i2, i4))); \
-        const int step = i + K;                                                                    \
-        if (step >= 7 && step < n && ovalid) {                                                     \
-            float4 r2, r3; float2 r4;                                                              \
-            guide_finish(m, r2, r3, r4);                                                           \
-            const size_t o = (size_t)(ybase + step - 3) * W + xo;                                  \
-            g2[o] = r2; g3[o] = r3; g4[o] = r4;                                                    \
-        }                                                                                          \
+        /* channels I0,I1,I2 | I0I0,I0I1,I0I2 | I1I1,I1I2,I2I2: wave w takes the w-th triple */      \
+        const float v0 = wave == 0 ? g.x : (wave == 1 ? __fmul_rn(g.x, g.x) : __fmul_rn(g.y, g.y)); \
+        const float v1 = wave == 0 ? g.y : (wave == 1 ? __fmul_rn(g.x, g.y) : __fmul_rn(g.y, g.z)); \
+        const float v2 = wave == 0 ? g.z : (wave == 1 ? __fmul_rn(g.x, g.z) : __fmul_rn(g.z, g.z)); \
+        ms[b & 1][K][3 * wave + 0][lane] = box_out(vstep<K>(t[0], hsum8(v0, i1, i2, i4)));        \
+        ms[b & 1][K][3 * wave + 1][lane] = box_out(vstep<K>(t[1], hsum8(v1, i1, i2, i4)));        \
+        ms[b & 1][K][3 * wave + 2][lane] = box_out(vstep<K>(t[2], hsum8(v2, i1, i2, i4)));        \
     }
         PSM_STEP_G(0) PSM_STEP_G(1) PSM_STEP_G(2) PSM_STEP_G(3)
 #undef PSM_STEP_G
+        __syncthreads();     // (one barrier per batch: the other parity's buffer is rewritten only after the NEXT barrier)
+        // finish the batch's pixels: 4 rows x 56 columns over 192 threads
+        for (int q = threadIdx.x; q < 4 * 56; q += 192) {
+            const int k = q / 56, col = q - k * 56;
+            const int step = i + k, xo = x0 + col;
+            if (step >= 7 && step < n && xo < W) {
+                float m[9];
+#pragma unroll
+                for (int c = 0; c < 9; ++c) m[c] = ms[b & 1][k][c][col];
+                float4 r2, r3; float2 r4;
+                guide_finish(m, r2, r3, r4);
+                const size_t o = (size_t)(ybase + step - 3) * W + xo;
+                g2[o] = r2; g3[o] = r3; g4[o] = r4;
+            }
+        }
     }
 }
 
@@ -153,13 +168,15 @@ void launch_guidance(hipStream_t s, Guidance g, int W, int H, const Guidance *se
     // to produce - a row stripe of the filter needs its own rows + 4 either side
     if (yend <= ybeg) { ybeg = 0; yend = H; }
     const int rows = yend - ybeg;
-    // one wave per (strip, segment): ~2048 waves over both images = one resident round (two per SIMD at 199 VGPRs), 8..64 rows each
+    // one workgroup of three waves per (strip, segment); segments as short as still fill ~2 workgroups per SIMD-quad of the
+    // chip in one resident round (8..64 rows each: 7 halo rows per segment)
     const int nstrips = (W + 55) / 56;
-    const int waves = 8 * pc_dev().nxcd * pc_dev().cus_per_xcd / (second ? 2 : 1);   // per image
-    int seg_rows = 8;                                        // shortest segment whose waves fit one round
-    while (seg_rows < 64 && nstrips * ((rows + seg_rows - 1) / seg_rows) > waves) ++seg_rows;
+    const PcDev dev = pc_dev();
+    const int wgs = 6 * dev.nxcd * dev.cus_per_xcd / (second ? 2 : 1);   // per image (87 VGPRs, 18 KB of LDS: ~6 resident workgroups per CU)
+    int seg_rows = 8;
+    while (seg_rows < 64 && nstrips * ((rows + seg_rows - 1) / seg_rows) > wgs) ++seg_rows;
     const int nsegs = (rows + seg_rows - 1) / seg_rows;
-    hipLaunchKernelGGL(k_guide_march, dim3(nstrips * nsegs, second ? 2 : 1), dim3(64), 0, s, (const float4 *)g.g1, W, H, nstrips, seg_rows, g.g2, g.g3, g.g4,
+    hipLaunchKernelGGL(k_guide_march, dim3(nstrips * nsegs, second ? 2 : 1), dim3(192), 0, s, (const float4 *)g.g1, W, H, nstrips, seg_rows, g.g2, g.g3, g.g4,
                        second ? *second : Guidance{}, ybeg, yend);
 }
 
