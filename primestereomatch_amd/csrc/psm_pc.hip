@@ -47,6 +47,12 @@ namespace psm {
 
 #if PSM_PC_TIMING
 __device__ unsigned long long g_pc_dbg[8];   // work cycles of waves A0, A1, B0, B1, then their barrier-wait cycles
+// per workgroup of the LAST launch (scripts/dbg_pc_trace.py, dbg_pc_clock.py): start and end on the constant 100 MHz counter and
+// on the shader-clock counter, the hardware id (XCC, SE, CU), and the SIMD each of its four waves runs on
+constexpr int PC_TRACE_N = 1 << 16;
+__device__ unsigned long long g_pc_trace[3 * PC_TRACE_N];
+__device__ unsigned long long g_pc_clk[2 * PC_TRACE_N];
+__device__ unsigned char g_pc_simd[4 * PC_TRACE_N];
 #define PC_SYNC()                                                                \
     {                                                                            \
         const unsigned long long a_ = __builtin_readcyclecounter();              \
@@ -242,6 +248,15 @@ void k_cvf_pc(
 
 #if PSM_PC_TIMING
     unsigned long long q_work = 0, q_wait = 0, q_mark = __builtin_readcyclecounter();
+    const unsigned trace_id = blockIdx.y * gridDim.x + blockIdx.x;
+    if ((threadIdx.x & 63) == 0 && trace_id < PC_TRACE_N)
+        g_pc_simd[4 * trace_id + (threadIdx.x >> 6)] = (unsigned char)__builtin_amdgcn_s_getreg((4 << 0) | (4 << 6) | (1 << 11));   // HW_ID.SIMD_ID
+    if (threadIdx.x == 0 && trace_id < PC_TRACE_N) {
+        g_pc_trace[3 * trace_id] = wall_clock64();
+        g_pc_clk[2 * trace_id] = __builtin_readcyclecounter();
+        g_pc_trace[3 * trace_id + 2] = ((unsigned long long)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11)) << 32) |   // XCC_ID[3:0]
+                                       __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));                                // HW_ID
+    }
 #endif
     const int nds = MODE == 1 ? DC : 1;               // MODE 0 / 2 always run with DC == 1 (one slice per workgroup)
     bool first = true;                                // no slice processed yet: the plane holds nothing
@@ -551,6 +566,7 @@ void k_cvf_pc(
     if (ts != nullptr && threadIdx.x == 0)            // ... and when did the last one end (all waves have passed the last barrier)
         (void)__hip_atomic_fetch_max(ts + PC_TS_SLOTS, (unsigned long long)wall_clock64(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #if PSM_PC_TIMING
+    if (threadIdx.x == 0 && trace_id < PC_TRACE_N) { g_pc_trace[3 * trace_id + 1] = wall_clock64(); g_pc_clk[2 * trace_id + 1] = __builtin_readcyclecounter(); }
     if (lane == 0 && MODE == 1) {
         atomicAdd(&g_pc_dbg[wave], q_work);
         atomicAdd(&g_pc_dbg[4 + wave], q_wait);
@@ -620,6 +636,26 @@ extern "C" int psm_debug_pc_cycles(unsigned long long *out8)
     if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(psm::g_pc_dbg), 8 * sizeof(unsigned long long)) != hipSuccess) return 1;
     unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     if (hipMemcpyToSymbol(HIP_SYMBOL(psm::g_pc_dbg), z, sizeof z) != hipSuccess) return 1;
+#endif
+    return 0;
+}
+
+// debug: the per-workgroup trace of the last k_cvf_pc launch - out3: (start, end, hardware id) x n, clk2: shader-clock counter at
+// start and end x n, simd4: SIMD of the four waves x n; any pointer may be null (all zero unless built with -DPSM_PC_TIMING=1)
+extern "C" int psm_debug_pc_trace(unsigned long long *out3, unsigned long long *clk2, unsigned char *simd4, int n)
+{
+    for (int i = 0; i < n; ++i) {
+        if (out3) out3[3 * i] = out3[3 * i + 1] = out3[3 * i + 2] = 0;
+        if (clk2) clk2[2 * i] = clk2[2 * i + 1] = 0;
+        if (simd4) simd4[4 * i] = simd4[4 * i + 1] = simd4[4 * i + 2] = simd4[4 * i + 3] = 255;
+    }
+#if PSM_PC_TIMING
+    if (n > psm::PC_TRACE_N) n = psm::PC_TRACE_N;
+    if (out3 && hipMemcpyFromSymbol(out3, HIP_SYMBOL(psm::g_pc_trace), 3 * (size_t)n * sizeof(unsigned long long)) != hipSuccess) return 1;
+    if (clk2 && hipMemcpyFromSymbol(clk2, HIP_SYMBOL(psm::g_pc_clk), 2 * (size_t)n * sizeof(unsigned long long)) != hipSuccess) return 1;
+    if (simd4 && hipMemcpyFromSymbol(simd4, HIP_SYMBOL(psm::g_pc_simd), 4 * (size_t)n) != hipSuccess) return 1;
+    void *sym = nullptr;                                   // clear the start stamps: a smaller launch must not show stale workgroups
+    if (hipGetSymbolAddress(&sym, HIP_SYMBOL(psm::g_pc_trace)) == hipSuccess) (void)hipMemset(sym, 0, 3 * (size_t)psm::PC_TRACE_N * sizeof(unsigned long long));
 #endif
     return 0;
 }

@@ -12,7 +12,8 @@ from primestereomatch_amd import capi, synth  # noqa: E402
 cfg = {"c4": (1920, 1080, 256), "c3": (1280, 720, 128), "c2": (450, 375, 64)}[sys.argv[1] if len(sys.argv) > 1 else "c4"]
 W, H, D = cfg
 l, r, _ = synth.make_pair(W, H, D, seed=0)
-de = P.DispEst(l, r, D, dtype=os.environ.get("PSM_DTYPE", "f32"))
+dr = tuple(int(v) for v in os.environ["PSM_DRANGE"].split(",")) if os.environ.get("PSM_DRANGE") else None   # disparity shard
+de = P.DispEst(l, r, D, dtype=os.environ.get("PSM_DTYPE", "f32"), d_range=dr)
 if len(sys.argv) > 2:
     de.set_option(capi.PSM_OPT_SEG_ROWS, int(sys.argv[2]))
 if len(sys.argv) > 3:
@@ -24,6 +25,7 @@ for _ in range(2):
     if os.environ.get("PSM_BOX"):
         de.box8_volume(0, download=False)
     de.CostFilter_GPU()
-    de.DispSelect_device()
+    if dr is None:
+        de.DispSelect_device()
 de.synchronize()
 de.close()
