@@ -1,8 +1,11 @@
 """Static VALU instruction mix of k_cvf_pc's loop bodies (no GPU needed): compiles psm_pc.hip to gfx950 assembly and counts,
 per producer / consumer batch loop of the product instantiations, the wave-instructions of the part's two VALU rate classes
 
-    four-cycle  : fp64 adds / moves, fp64 <-> fp32 conversions, DPP moves (and packed fp32) - 4 cycles per wave64
-    two-cycle   : everything else in the VALU (fp32 / integer / compares)
+    four-cycle  : fp64 adds / moves, fp64 <-> fp32 conversions, DPP moves, packed fp32 - and, measured in round 3
+                  (scripts/exp/clock.hip: 0.54-0.56 G wave-instructions/s per SIMD against 0.84-0.92 for the two-cycle
+                  class): v_sad_u8, v_mul_u32_u24, integer <-> fp32 conversions, v_trunc / v_rndne_f32, v_med3_f32
+                  (the 8-bit cost and re-quantisation); 64-bit integer ops are counted here too (not measured)
+    two-cycle   : everything else in the VALU (fp32 add / mul / fma, 32-bit integer and bit ops, compares)
 
 plus LDS, VMEM and scalar instructions.  The rarely executed border-cost block of the producer (columns x < d) is left
 out.  bench.py's roofline.valu uses `four_cycle_share` together with the measured SQ_INSTS_VALU (rocprofv3 PMC pass) to
@@ -29,7 +32,9 @@ KERNELS = {"planes_f32": "k_cvf_pcILb0ELi3ELi1ELb0EEE", "keys_f32": "k_cvf_pcILb
 
 def classify(op, rest):
     if op.startswith("v_"):
-        if re.search(r"_f64|f64_f32|f32_f64|_b64", op) or op.startswith("v_pk_") or "dpp" in op:
+        if re.search(r"_f64|f64_f32|f32_f64|_b64|_u64|_i64", op) or op.startswith("v_pk_") or "dpp" in op:
+            return "V4"
+        if re.match(r"v_(sad_u8|mul_u32_u24|mul_i32_i24|cvt_f32_[ui]32|cvt_[ui]32_f32|cvt_f32_ubyte\d|trunc_f32|rndne_f32|med3_f32)", op):
             return "V4"
         if "row_" in rest or "wave_" in rest or "quad_perm" in rest:
             return "V4"
