@@ -87,6 +87,7 @@ void adopt_new_pair(psm_ctx *c, int depth)
     c->raw_rows[0] = c->raw_rows[1] = psm_ctx::RAW_ALL;   // nothing virtual survives a new pair
     c->fgf_virtual[0] = c->fgf_virtual[1] = 0;
     c->gf_virtual[0] = c->gf_virtual[1] = false;
+    c->maps_early = nullptr;
 }
 
 }  // namespace psm
@@ -383,6 +384,7 @@ int psm_upload_volume(psm_ctx *c, int side, int d0, int d1, const void *host)
     // after a striped psm_cost_construct, which leaves have_g1 false -, packed minima, FGF models) becomes real data first
     if (c->have_cost && (c->raw_rows[side] != psm_ctx::RAW_ALL || c->gf_virtual[side] || c->fgf_virtual[side]) && materialize(c, side)) return 1;
     c->gf_virtual[side] = false;
+    c->maps_early = nullptr;
     if (ensure_vol(c, side)) return 1;
     const size_t S = (size_t)c->W * c->H * velem(c);
     PSM_HIP(c, hipMemcpyAsync((char *)c->vol[side] + (size_t)(d0 - c->d0) * S, host, (size_t)(d1 - d0) * S, hipMemcpyHostToDevice, c->stream));

@@ -208,6 +208,7 @@ namespace {
 // form, the direct variant and for stage A alone.
 int filter_side(psm_ctx *c, int side, bool stage_b)
 {
+    c->maps_early = nullptr;
     const size_t V = (size_t)c->W * c->H * c->Dloc;
     const int W = c->W, H = c->H;
     if (!c->have_g1 && run_prep(c)) return 1;  // volume came from psm_upload_volume
@@ -302,6 +303,7 @@ bool can_filter_both(const psm_ctx *c)
 
 int filter_both(psm_ctx *c)
 {
+    c->maps_early = nullptr;
     const bool striped = c->march.yend > c->march.ybeg;
     {   // g1 rows this launch reads: everything, or the stripe's rows - 8 .. + 8
         const int ya = striped ? (c->march.ybeg - 8 > 0 ? c->march.ybeg - 8 : 0) : 0;
@@ -357,8 +359,13 @@ int filter_both(psm_ctx *c)
         launch_cvf_select2(c->stream, c->march, c->g, c->W, c->H, c->Dloc, c->d0, c->gf_scratch, next_pc_stamp(c), p4);
     }
     {
+        // The reduction of the planes is the last thing that touches the keys: when the context holds every slice it writes the
+        // maps (the low byte of each key) in the same pass, and psm_disp_select has no kernel left to launch.
+        uint8_t *const early = c->Dloc == c->D ? c->maps : nullptr;
+        if (early && c->ev_down) PSM_HIP(c, hipStreamWaitEvent(c->stream, c->ev_down, 0));   // (still the source of the last frame's download?)
         Prof p(c, PSM_K_WTA);
-        launch_chunk_min2sides(c->stream, c->march, c->W, c->H, c->Dloc, c->gf_scratch, c->keys_cur, nullptr);
+        launch_chunk_min2sides(c->stream, c->march, c->W, c->H, c->Dloc, c->gf_scratch, c->keys_cur, early);
+        c->maps_early = early;
     }
     c->gf_virtual[0] = c->gf_virtual[1] = true;
     return check_launch(c, "cvf (fused, select mode, both volumes)");
@@ -394,6 +401,7 @@ int psm_cost_construct(psm_ctx *c)
     if (c->ev_free) PSM_HIP(c, hipEventRecord(c->ev_free, c->stream));   // the staged images have been read: their slot may be refilled
     c->fgf_virtual[0] = c->fgf_virtual[1] = 0;   // a new cost volume replaces whatever was pending
     c->gf_virtual[0] = c->gf_virtual[1] = false;
+    c->maps_early = nullptr;
     for (int s = 0; s < 2; ++s) {
         if (lazy) {
             c->raw_rows[s] = psm_ctx::RAW_NONE;
@@ -470,6 +478,7 @@ int psm_cost_filter_fgf(psm_ctx *c, int sub)
     const int ws = c->W / sub, hs = c->H / sub, rad = 8 / sub;
     if (ws <= rad || hs <= rad) return fail(c, "psm_cost_filter_fgf: %dx%d too small for subsample_rate %d", c->W, c->H, sub);
     if (bind(c)) return 1;
+    c->maps_early = nullptr;
     const double t0 = now_us();
     if (!c->have_g1 && run_prep(c)) return 1;
     // small planes: ism, msm, v1 (float4), v2 (float2) per pixel; ab (scratch) and one mab per side (float4) per small voxel
@@ -518,6 +527,7 @@ int psm_filter_stage_a(psm_ctx *c, int side)
     if (side != PSM_LEFT && side != PSM_RIGHT) return fail(c, "psm_filter_stage_a: bad side %d", side);
     if (!c->have_cost || !c->have_images) return fail(c, "psm_filter_stage_a: needs images and a cost volume");
     if (bind(c)) return 1;
+    c->maps_early = nullptr;
     if (filter_side(c, side, false)) return 1;
     PSM_HIP(c, hipStreamSynchronize(c->stream));
     return 0;

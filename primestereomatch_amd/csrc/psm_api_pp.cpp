@@ -162,6 +162,7 @@ int psm_upload_maps(psm_ctx *c, const uint8_t *lmap, const uint8_t *rmap, const 
     if (stride == 0) stride = c->W;
     if (stride < (size_t)c->W) return fail(c, "psm_upload_maps: stride %zu < width %d", stride, c->W);
     if (bind(c)) return 1;
+    c->maps_early = nullptr;
     const size_t HW = (size_t)c->W * c->H;
     const uint8_t *src[4] = {lmap, rmap, lvalid, rvalid};
     uint8_t *dst[4] = {c->maps, c->maps + HW, c->valid, c->valid + HW};

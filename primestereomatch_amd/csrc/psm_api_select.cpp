@@ -77,6 +77,9 @@ int wta_launch(psm_ctx *c, long long *keys, uint8_t *maps)
     // a side that is not the select filter's packed minima was selected from a whole volume: its map is whole
     if (!(c->gf_virtual[0] && c->gf_virtual[1])) { c->have_rows = false; c->rows_y0 = 0; c->rows_y1 = c->H; }
     if (c->gf_virtual[0] && c->gf_virtual[1] && !keys && maps) {   // both sides already reduced to keys: one launch for both maps
+        const bool done = c->maps_early == maps;                    // ... unless the filter's reduction wrote them already
+        c->maps_early = nullptr;                                    // (once: post-processing rewrites the maps in place)
+        if (done) return 0;
         Prof p(c, PSM_K_WTA);
         launch_merge(c->stream, c->keys_cur, 2 * HW, 1, (int)(2 * HW), maps);
         return check_launch(c, "wta");
@@ -164,6 +167,7 @@ int psm_set_map_buffer(psm_ctx *c, void *dev_maps, int whole)
     if (!c) return 1;
     uint8_t *m = dev_maps ? (uint8_t *)dev_maps : c->maps_own;
     if (m != c->maps) { c->have_maps = false; c->have_valid = false; }
+    c->maps_early = nullptr;
     c->maps = m;
     if (whole) {    // the caller filled the buffer with both complete maps of the current frame (e.g. gathered row stripes)
         c->have_maps = true;

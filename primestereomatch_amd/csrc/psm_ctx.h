@@ -49,6 +49,7 @@ struct psm_ctx {
     int gather_ranks = 0;
     uint8_t *maps = nullptr;            // [2][H][W]: maps_own, or the caller's buffer (psm_set_map_buffer)
     uint8_t *maps_own = nullptr;
+    uint8_t *maps_early = nullptr;      // the map buffer the single-phase filter already filled from its final keys (k_chunk_min), or null
     // The maps / minima of the current frame cover the rows [rows_y0, rows_y1) only (a psm_set_rows stripe was in force when
     // psm_cost_filter produced them); have_rows false: whole image.  Recorded at filter time - psm_set_rows itself only
     // affects the NEXT filter - and cleared by everything that writes whole maps.

@@ -109,6 +109,34 @@ def test_frame_loop_async_upload_and_download(psm, oracle):
         assert np.array_equal(de.lDisMap, refs[2]["ldisp"])
 
 
+def test_single_phase_filter_writes_the_maps_once(psm, oracle):
+    """Below 112 slices the filter's plane reduction writes the maps itself (psm_disp_select launches nothing): a second select
+    after post-processing rewrote the maps in place must extract the raw WTA maps from the keys again, and a one-side filter or
+    a new pair in between must not leave a stale early map behind."""
+    from primestereomatch_amd import synth
+    W, H, D = 180, 70, 20
+    pa, pb = (synth.make_pair(W, H, D, seed=s)[:2] for s in (11, 12))
+    ra, rb = (oracle.pipeline_f32(l, r, D, threads=4) for l, r in (pa, pb))
+    with psm.DispEst(*pa, D) as de:
+        de.CostConst_GPU(); de.CostFilter_GPU(); de.DispSelect_GPU()
+        assert np.array_equal(de.lDisMap, ra["ldisp"]) and np.array_equal(de.rDisMap, ra["rdisp"])
+        de.LRCheck_GPU(); de.FillInv_GPU()                                  # rewrites the maps in place
+        lv, rv = oracle.lr_check(ra["ldisp"], ra["rdisp"])
+        assert np.array_equal(de.lDisMap, oracle.fill_inv(ra["ldisp"], lv))
+        de.DispSelect_GPU()                                                # the raw maps again, from the keys
+        assert np.array_equal(de.lDisMap, ra["ldisp"]) and np.array_equal(de.rDisMap, ra["rdisp"])
+        # filter, then a new pair, then the full sequence: nothing of pair a survives
+        de.CostConst_GPU(); de.CostFilter_GPU()
+        de.setInputImages(*pb)
+        de.CostConst_GPU(); de.CostFilter_GPU(); de.DispSelect_GPU()
+        assert np.array_equal(de.lDisMap, rb["ldisp"]) and np.array_equal(de.rDisMap, rb["rdisp"])
+        # both sides filtered together (early maps), then fresh costs filtered side by side (keys rewritten): the select must not skip
+        de.CostConst_GPU(); de.CostFilter_GPU()
+        de.CostConst_GPU(); de.CostFilter_side(0); de.CostFilter_side(1)
+        de.DispSelect_GPU()
+        assert np.array_equal(de.lDisMap, rb["ldisp"]) and np.array_equal(de.rDisMap, rb["rdisp"])
+
+
 def test_filter_launch_time_stamps(psm):
     """PSM_OPT_PROFILE 2: the fused filter kernel stamps its own start / end; two launches per frame at 120 slices (planes
     phase, key phase), durations positive and below the frame's wall time; results unchanged."""
