@@ -176,6 +176,28 @@ int check_slices(psm_ctx *c, const char *who, int side, int d0, int d1)
 
 }  // namespace
 
+namespace psm {
+
+// Host rows -> packed device rows on the context's stream.  hipMemcpy2D takes a row-by-row path when the row length is not a
+// multiple of 4 bytes (measured: 6.5 ms for a 450 x 375 x 3 pair, 18.9 ms for 1919 x 1080 x 3, against 0.05 / 0.25 ms): contiguous
+// images go as one linear copy, odd-length rows with a pitch are packed on the host first.
+int h2d_rows(psm_ctx *c, void *dst, const void *src, size_t row, size_t stride, int rows)
+{
+    if (stride == row) {
+        PSM_HIP(c, hipMemcpyAsync(dst, src, row * rows, hipMemcpyHostToDevice, c->stream));
+    } else if (row % 4 == 0 && stride % 4 == 0) {
+        PSM_HIP(c, hipMemcpy2DAsync(dst, row, src, stride, row, rows, hipMemcpyHostToDevice, c->stream));
+    } else {
+        std::vector<uint8_t> packed(row * rows);
+        for (int y = 0; y < rows; ++y) memcpy(packed.data() + (size_t)y * row, (const uint8_t *)src + (size_t)y * stride, row);
+        PSM_HIP(c, hipMemcpyAsync(dst, packed.data(), row * rows, hipMemcpyHostToDevice, c->stream));
+        PSM_HIP(c, hipStreamSynchronize(c->stream));      // (the packed copy lives only here)
+    }
+    return 0;
+}
+
+}  // namespace psm
+
 extern "C" {
 
 int psm_device_count(void)
@@ -317,7 +339,7 @@ int psm_upload_pair(psm_ctx *c, const void *l, const void *r, int channels, size
     if (bind(c)) return 1;
     const void *src[2] = {l, r};
     for (int s = 0; s < 2; ++s)
-        PSM_HIP(c, hipMemcpy2DAsync(c->raw[s], row, src[s], stride_bytes, row, c->H, hipMemcpyHostToDevice, c->stream));
+        if (h2d_rows(c, c->raw[s], src[s], row, stride_bytes, c->H)) return 1;
     // the copy reads caller memory: always complete it before returning (CVC_cl::buildCV copies
     // out of the cv::Mats synchronously, src/CVC_cl.cpp:113-160)
     PSM_HIP(c, hipStreamSynchronize(c->stream));

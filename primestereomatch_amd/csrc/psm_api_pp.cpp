@@ -167,7 +167,7 @@ int psm_upload_maps(psm_ctx *c, const uint8_t *lmap, const uint8_t *rmap, const 
     const uint8_t *src[4] = {lmap, rmap, lvalid, rvalid};
     uint8_t *dst[4] = {c->maps, c->maps + HW, c->valid, c->valid + HW};
     for (int i = 0; i < 4; ++i)
-        if (src[i]) PSM_HIP(c, hipMemcpy2DAsync(dst[i], c->W, src[i], stride, c->W, c->H, hipMemcpyHostToDevice, c->stream));
+        if (src[i] && h2d_rows(c, dst[i], src[i], (size_t)c->W, stride, c->H)) return 1;
     PSM_HIP(c, hipStreamSynchronize(c->stream));
     if (lmap && rmap) { c->have_maps = true; c->have_valid = false; c->have_rows = false; c->rows_y0 = 0; c->rows_y1 = c->H; }   // whole maps
     if (lvalid && rvalid && c->have_maps) c->have_valid = true;

@@ -145,6 +145,8 @@ struct Prof {
     }
 };
 
+// psm_api_core.cpp
+int h2d_rows(psm_ctx *c, void *dst, const void *src, size_t row, size_t stride, int rows);   // host rows -> packed device rows
 // psm_api_filter.cpp
 int run_prep(psm_ctx *c, int ya = 0, int yb = 0);
 int ensure_vol(psm_ctx *c, int side);
