@@ -89,21 +89,49 @@ int psm_wgt_median(psm_ctx *c, uint8_t *lmap, uint8_t *rmap, size_t stride)
     if (!dataflow_only) {
         // parallel form: sweeps to the fixed point of the in-place recursion (psm_pp.hip), both maps side by side
         const size_t nb = (HW + 255) / 256 * 256, ncnt = 2 * (size_t)(96 + 2);
-        const size_t per_side = 2 * nb + (4 * nb + ncnt) * sizeof(int);
+        const size_t per_side = 4 * nb + (6 * nb + ncnt) * sizeof(int);
         if (!c->wm_par) PSM_HIP(c, hipMalloc((void **)&c->wm_par, 2 * per_side));
-        uint8_t *orig[2], *newv[2];
-        int *stamp[2], *list[2][2], *chg[2], *cnt[2];
+        uint8_t *orig[2], *newv[2], *chgb[2], *rowany[2];
+        int *stamp[2], *list[2][2], *chg[2], *cnt[2], *slot_of[2], *inv[2];
         for (int s = 0; s < 2; ++s) {
             uint8_t *b = c->wm_par + s * per_side;
-            orig[s] = b; newv[s] = b + nb;
-            int *ip = reinterpret_cast<int *>(b + 2 * nb);
-            stamp[s] = ip; list[s][0] = ip + nb; list[s][1] = ip + 2 * nb; chg[s] = ip + 3 * nb; cnt[s] = ip + 4 * nb;
+            orig[s] = b; newv[s] = b + nb; chgb[s] = b + 2 * nb; rowany[s] = b + 3 * nb;
+            int *ip = reinterpret_cast<int *>(b + 4 * nb);
+            stamp[s] = ip; list[s][0] = ip + nb; list[s][1] = ip + 2 * nb; chg[s] = ip + 3 * nb; slot_of[s] = ip + 4 * nb; inv[s] = ip + 5 * nb; cnt[s] = ip + 6 * nb;
             PSM_HIP(c, hipMemcpyAsync(orig[s], c->maps + s * HW, HW, hipMemcpyDeviceToDevice, c->stream));
-            PSM_HIP(c, hipMemsetAsync(stamp[s], 0, nb * sizeof(int), c->stream));
+            PSM_HIP(c, hipMemsetAsync(chgb[s], 0, 2 * nb + nb * sizeof(int), c->stream));      // chgb, rowany, stamp (contiguous)
             PSM_HIP(c, hipMemsetAsync(cnt[s], 0, ncnt * sizeof(int), c->stream));
-            launch_wm_seed(c->stream, c->valid + s * HW, c->W, c->H, list[s][0], cnt[s]);
+            launch_wm_seed(c->stream, c->valid + s * HW, c->W, c->H, inv[s], cnt[s]);     // all invalid pixels = the first sweep's list
         }
         std::vector<int> hc(2 * ncnt);
+        // Weight cache: the 19 x 19 weights of an invalid pixel depend on the image only, and the sweeps evaluate it ~5 times.
+        // For sides with at least WM_LANE_MIN invalid pixels one pass forms them all (1.5 KB per invalid pixel; beyond
+        // WM_CACHE_MAX bytes for the pair the evaluations form their weights themselves, as they do for short lists).
+        float *wts[2] = {nullptr, nullptr};
+        {
+            constexpr size_t WM_CACHE_MAX = (size_t)12 << 30;
+            int n0[2];
+            for (int s = 0; s < 2; ++s) PSM_HIP(c, hipMemcpyAsync(&n0[s], cnt[s], sizeof(int), hipMemcpyDeviceToHost, c->stream));
+            PSM_HIP(c, hipStreamSynchronize(c->stream));
+            size_t need[2], tot = 0;
+            for (int s = 0; s < 2; ++s) { need[s] = n0[s] >= WM_LANE_MIN ? (size_t)n0[s] * WM_WPIX : 0; tot += need[s]; }
+            if (tot && tot * sizeof(float) <= WM_CACHE_MAX) {
+                if (c->wm_wts_n < tot) {
+                    (void)hipFree(c->wm_wts);
+                    c->wm_wts = nullptr;
+                    c->wm_wts_n = 0;
+                    if (hipMalloc((void **)&c->wm_wts, tot * sizeof(float)) == hipSuccess) c->wm_wts_n = tot;
+                    else (void)hipGetLastError();           // no memory for it: recompute, as without the cache
+                }
+                if (c->wm_wts_n >= tot) {
+                    if (need[0]) wts[0] = c->wm_wts;
+                    if (need[1]) wts[1] = c->wm_wts + need[0];
+                    Prof p(c, PSM_K_WMF);
+                    for (int s = 0; s < 2; ++s)
+                        if (wts[s]) launch_wm_weights(c->stream, c->g[s].g1, c->W, c->H, s, inv[s], cnt[s], n0[s], wts[s], slot_of[s]);
+                }
+            }
+        }
         int sw = 0;
         while (sw < CAP && !(done[0] && done[1])) {
             const int upto = sw + CHK < CAP ? sw + CHK : CAP;
@@ -113,8 +141,8 @@ int psm_wgt_median(psm_ctx *c, uint8_t *lmap, uint8_t *rmap, size_t stride)
                     for (int s = 0; s < 2; ++s)
                         if (!done[s])
                             launch_wm_sweep(c->stream, c->maps + s * HW, orig[s], c->valid + s * HW, c->g[s].g1, c->W, c->H, c->D, s,
-                                            list[s][sw & 1], cnt[s] + 2 * sw, newv[s], chg[s], cnt[s] + 2 * sw + 1, stamp[s], sw + 1,
-                                            list[s][(sw + 1) & 1], cnt[s] + 2 * (sw + 1));
+                                            sw == 0 ? inv[s] : list[s][(sw + 1) & 1], cnt[s] + 2 * sw, newv[s], chg[s], cnt[s] + 2 * sw + 1, stamp[s], sw + 1,
+                                            list[s][sw & 1], cnt[s] + 2 * (sw + 1), wts[s], slot_of[s], inv[s], cnt[s], chgb[s], rowany[s]);
             }
             if (check_launch(c, "wgt_median (sweeps)")) return 1;
             for (int s = 0; s < 2; ++s)

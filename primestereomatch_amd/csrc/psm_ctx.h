@@ -59,8 +59,9 @@ struct psm_ctx {
     uint8_t *pinned = nullptr;          // [2][H][W] page-locked bounce buffer for map / mask downloads (on first use)
     uint8_t *pinned2 = nullptr;         // second bounce buffer: psm_download_maps_async of frame i while frame i-1 is being read
     int *wm = nullptr;                  // psm_wgt_median scratch: nxt[H][W+1], prog[H], err[1]; allocated on first use
-    uint8_t *wm_par = nullptr;          // scratch of its parallel (sweep) form, per side: orig, newv (bytes), stamp, 2 active lists, changed list, counters
-    float *wm_wts = nullptr;            // ... cached window weights of the pixels that are re-evaluated (on first use)
+    uint8_t *wm_par = nullptr;          // scratch of its parallel (sweep) form, per side: orig, newv, chgb, rowany (bytes), stamp, 2 active lists, changed list,
+                                        // slot_of, the list of all invalid pixels, counters
+    float *wm_wts = nullptr;            // ... the 19 x 19 window weights of every invalid pixel (formed once per call, read by every evaluation)
     size_t wm_wts_n = 0;
     int wm_sweeps[2] = {0, 0};          // last call: sweeps until the fixed point (-1: dataflow form), evaluations
     long long wm_evals[2] = {0, 0};

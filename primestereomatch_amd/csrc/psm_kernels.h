@@ -96,10 +96,14 @@ void launch_fill_inv(hipStream_t s, uint8_t *dis, const uint8_t *valid, int W, i
 void launch_wgt_median(hipStream_t s, uint8_t *dis, const uint8_t *valid, const float4 *g1, int W, int H, int maxDis, int right,
                        int *nxt, int *prog, int *err);
 // parallel form (sweeps to the fixed point of the in-place recursion; psm_pp.hip)
+constexpr int WM_LANE_MIN = 8192;       // active pixels from which a sweep evaluates one pixel per LANE (k_wm_eval) instead of per wave
+constexpr int WM_WROW = 20;             // floats per window row of the weight cache (19 weights + 1 pad: five float4)
+constexpr int WM_WPIX = 19 * WM_WROW;   // floats per cached pixel
 void launch_wm_seed(hipStream_t s, const uint8_t *valid, int W, int H, int *list, int *cnt);
 void launch_wm_sweep(hipStream_t s, uint8_t *cur, const uint8_t *orig, const uint8_t *valid, const float4 *g1, int W, int H, int maxDis,
                      int right, const int *act, const int *n_act, uint8_t *newv, int *chg, int *n_chg, int *stamp, int mark,
-                     int *next, int *n_next);
+                     int *next, int *n_next, const float *wts, const int *slot_of, const int *inv, const int *n_inv, uint8_t *chgb, uint8_t *rowany);
+void launch_wm_weights(hipStream_t s, const float4 *g1, int W, int H, int right, const int *inv, const int *n_inv, int n, float *wts, int *slot_of);
 
 // ---- Fast Guided Filter variant (psm_fgf.hip); sub = subsample rate, small planes are (H/sub) x (W/sub) ----
 // g1 -> subsampled guidance ism, its means msm and the inverse covariance planes v1 = {irr,irg,irb,igg}, v2 = {igb,ibb}

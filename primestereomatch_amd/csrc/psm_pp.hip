@@ -30,7 +30,6 @@ namespace psm {
 constexpr int WM_R = 9;                 // MED_SZ / 2, include/PP.h:12
 constexpr int WM_K = 2 * WM_R + 1;      // 19
 constexpr int WM_TAPS = WM_K * WM_K;    // 361
-constexpr int WM_LANE_MIN = 8192;       // active pixels from which a sweep evaluates one pixel per LANE (k_wm_eval) instead of per wave
 
 // nxt[y][x] (x = 0..W) = smallest x' >= x with valid[y][x'] == 0, W if there is none; prog[y] = nxt[y][0]
 __global__ __launch_bounds__(64) void k_wm_next(const uint8_t *__restrict__ valid, int W, int *__restrict__ nxt, int *__restrict__ prog)
@@ -219,77 +218,172 @@ __device__ __forceinline__ int wm_append(int *cnt, bool want)
     return base + before;
 }
 
+// the invalid pixels of a map as a list (any order): 16 pixels per thread, one atomic per wave
+constexpr int WM_SEED_PER = 16;
 __global__ __launch_bounds__(256) void k_wm_seed(const uint8_t *__restrict__ valid, int HW, int *__restrict__ list, int *cnt)
 {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    const bool inv = i < HW && valid[i] == 0;
-    const int slot = wm_append(cnt, inv);
-    if (inv) list[slot] = i;
+    const int lane = threadIdx.x & 63;
+    const int base = (blockIdx.x * blockDim.x + threadIdx.x) * WM_SEED_PER;
+    unsigned m = 0;                                   // bit k: pixel base + k is invalid
+#pragma unroll
+    for (int k = 0; k < WM_SEED_PER; ++k)
+        if (base + k < HW && valid[base + k] == 0) m |= 1u << k;
+    const int c = __builtin_popcount(m);
+    int incl = c;                                     // inclusive prefix sum over the wave
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int t = __shfl_up(incl, o);
+        if (lane >= o) incl += t;
+    }
+    const int total = __shfl(incl, 63);
+    if (total == 0) return;
+    int wbase = 0;
+    if (lane == 63) wbase = atomicAdd(cnt, total);
+    wbase = __shfl(wbase, 63);
+    int slot = wbase + incl - c;
+    while (m) {
+        const int k = __builtin_ctz(m);
+        m &= m - 1;
+        list[slot++] = base + k;
+    }
 }
 
 // One evaluation of f per LANE (round 3; round 2 spent a whole wave per pixel: every lane scanned all 361 taps for "its"
 // bins - 361 x 64 lane-steps for 722 useful additions).  A lane walks the 361 taps of its own pixel in window raster order:
-// weight (fp32 colour distance op for op, double exp narrowed to float), tot += w, hist[dep] += w in a private column of an
-// LDS histogram laid out [bin][lane] (bank = lane: conflict free) - every float sum is formed in exactly the reference's order
-// (src/PP.cpp:164-192), a bin sees its taps in raster order.  Runs of equal disparities (the common case in a disparity map)
-// stay in a register; the LDS column is touched only when the disparity changes.  Then the threshold scan over the bins in
-// ascending d (adding an empty bin is the identity).  LDS: maxDis x 256 bytes per wave (64 KB at D = 256: two waves per CU).
+// weight (fp32 colour distance op for op, double exp narrowed to float - or read from the cache below), tot += w,
+// hist[dep] += w in a private column of an LDS histogram laid out [bin][lane] (bank = lane: conflict free) - every float sum is
+// formed in exactly the reference's order (src/PP.cpp:164-192), a bin sees its taps in raster order.  Then the threshold scan
+// over the bins some lane touched, in ascending d (adding an empty bin is the identity), which also zeroes them again.
+// LDS: maxDis x 256 bytes per wave (64 KB at D = 256: two waves per CU) - the kernel runs at the pace ONE wave issues
+// instructions, so what counts is the length of its instruction stream: no data-dependent branches per tap, window rows read
+// as five dwords, the scan four bins at a time (1080p, 20 % invalid, random disparities: 24.9 -> 9.6 ms for both maps).
+// The weights of a pixel depend on the image only, and the sweeps evaluate an invalid pixel ~5 times: k_wm_weights forms the
+// 19 x 19 weights of every invalid pixel once, at full occupancy (this kernel runs two waves per CU at D = 256: its LDS
+// histograms) - rows of 20 floats, pixel-major, slot = position in the list of invalid pixels, slot_of[pix] remembers it -
+// and every evaluation (CACHED) loads them: five float4 per window row instead of 19 g1 loads, 19 colour distances,
+// divisions and double-precision exps.  !CACHED: weights formed here (few invalid pixels, or the cache would not fit).
 template <bool RIGHT>
+__global__ __launch_bounds__(256) void k_wm_weights(const float4 *__restrict__ g1, const int *__restrict__ inv, const int *n_inv,
+                                                   float4 *__restrict__ wts, int *__restrict__ slot_of, int W, int H)
+{   // one thread per (invalid pixel, window row): consecutive threads write consecutive 80-byte rows
+    const long long total = (long long)*n_inv * WM_K;
+    for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long long)gridDim.x * blockDim.x) {
+        const int slot = (int)(t / WM_K), r = (int)(t - (long long)slot * WM_K), wy = r - WM_R;
+        const int pix = inv[slot];
+        const int y = pix / W, x = pix - y * W;
+        if (r == 0) slot_of[pix] = slot;
+        const float4 p = g1[pix];
+        int qy = y + wy;
+        qy = qy < 0 ? qy + H : (qy >= H ? qy - H : qy);
+        float wk[WM_WROW];
+#pragma unroll
+        for (int k = 0; k < WM_K; ++k) {
+            int qx = x + k - WM_R;
+            qx = qx < 0 ? qx + W : (qx >= W ? qx - W : qx);
+            wk[k] = wm_weight<RIGHT>(p, g1[qy * W + qx], k - WM_R, wy);
+        }
+        wk[WM_WROW - 1] = 0.0f;
+#pragma unroll
+        for (int k = 0; k < WM_WROW / 4; ++k) wts[t * (WM_WROW / 4) + k] = make_float4(wk[4 * k], wk[4 * k + 1], wk[4 * k + 2], wk[4 * k + 3]);
+    }
+}
+
+template <bool RIGHT, bool CACHED>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2))) void k_wm_eval(const uint8_t *__restrict__ cur, const uint8_t *__restrict__ orig,
                                                const float4 *__restrict__ g1, const int *__restrict__ list, const int *n_act,
-                                               uint8_t *__restrict__ newv, int *__restrict__ chg, int *n_chg, int W, int H, int maxDis)
+                                               uint8_t *__restrict__ newv, int *__restrict__ chg, int *n_chg, int W, int H, int maxDis,
+                                               const float4 *__restrict__ wts, const int *__restrict__ slot_of)
 {
-    extern __shared__ float hist[];          // [maxDis][64]
+    extern __shared__ float hist[];          // [maxDis][64], all zero between two evaluations
     const int lane = threadIdx.x;
     const int n = *n_act;
     if (n < WM_LANE_MIN) return;               // short lists: k_wm_eval_w (latency of one evaluation instead of a batch's)
+    for (int d = 0; d < maxDis; ++d) hist[d * 64 + lane] = 0.0f;
     for (int i0 = blockIdx.x * 64; i0 < n; i0 += gridDim.x * 64) {
         const bool live = i0 + lane < n;
         const int pix = list[live ? i0 + lane : i0];
         const int y = pix / W, x = pix - y * W;
         const float4 p = g1[pix];
-        for (int d = 0; d < maxDis; ++d) hist[d * 64 + lane] = 0.0f;
+        // this pixel's row of the weight cache (WM_WROW / 4 float4 per window row)
+        const float4 *wrow = nullptr;
+        if constexpr (CACHED) wrow = wts + (size_t)slot_of[pix] * (WM_WPIX / 4);
+        unsigned dlo = (unsigned)maxDis, dhi = 0u;   // range of the bins this evaluation touches: dlo + 1 .. dhi (zeroed again after the scan)
         float tot = 0.0f;
-        int run_d = 0;                        // disparity of the current run (0: none) and its bin's sum so far
-        float run_s = 0.0f;
         // One window row at a time: its 19 + 19 loads (every lane its own pixel: uncoalesced, latency bound) are all issued
         // before the first weight is formed, and the next row's are in flight while this row is accumulated.
-        float4 gq[2][WM_K];
-        int dq[2][WM_K];
+        float4 gq[2][CACHED ? WM_WROW / 4 : WM_K];     // CACHED: the row's weights instead of its g1 values
+        // the 19 disparities of a window row, packed four to a dword.  A row is 19 consecutive bytes of one plane (the current
+        // iterate for an earlier row, the input for a later one; the pixel's own row: left of it / from it on) unless the window
+        // wraps around the image's left or right edge: five unaligned dword loads instead of 19 byte loads - every lane reads
+        // its own pixel's window, so each load instruction walks 64 cache lines whatever its width.
+        typedef unsigned wm_u32 __attribute__((aligned(1)));
+        unsigned dq[2][5];
+        const bool inner = x - WM_R >= 0 && x + WM_R + 1 < W;     // (the fifth dword's last byte is still inside the row)
         auto issue_row = [&](int slot, int wy) __attribute__((always_inline)) {
             int qy = y + wy;
             qy = qy < 0 ? qy + H : (qy >= H ? qy - H : qy);
             const int rowo = qy * W;
+            // raster order is index order: an earlier pixel shows its current iterate (= the input where it is valid),
+            // a later one - and the pixel itself - the input (src/PP.cpp:164-166 reads the map in place)
+            if (inner) {
+                const int b0 = rowo + x - WM_R;
+                const wm_u32 *pa = reinterpret_cast<const wm_u32 *>((qy <= y ? cur : orig) + b0);    // taps 0 .. 8 of the own row: current
+                const wm_u32 *pb = reinterpret_cast<const wm_u32 *>((qy < y ? cur : orig) + b0);     // taps 9 .. 18 of the own row: input
+                dq[slot][0] = pa[0]; dq[slot][1] = pa[1];
+                dq[slot][2] = (pa[2] & 0xffu) | (pb[2] & 0xffffff00u);
+                dq[slot][3] = pb[3]; dq[slot][4] = pb[4];
+            } else {
 #pragma unroll
-            for (int k = 0; k < WM_K; ++k) {
-                int qx = x + k - WM_R;
-                qx = qx < 0 ? qx + W : (qx >= W ? qx - W : qx);
-                const int off = rowo + qx;
-                // raster order is index order: an earlier pixel shows its current iterate (= the input where it is valid),
-                // a later one - and the pixel itself - the input (src/PP.cpp:164-166 reads the map in place)
-                dq[slot][k] = off < pix ? cur[off] : orig[off];
-                gq[slot][k] = g1[off];
+                for (int j = 0; j < 5; ++j) dq[slot][j] = 0;
+#pragma unroll
+                for (int k = 0; k < WM_K; ++k) {
+                    int qx = x + k - WM_R;
+                    qx = qx < 0 ? qx + W : (qx >= W ? qx - W : qx);
+                    const int off = rowo + qx;
+                    dq[slot][k >> 2] |= (unsigned)(off < pix ? cur[off] : orig[off]) << (8 * (k & 3));
+                }
+            }
+            if constexpr (!CACHED) {
+#pragma unroll
+                for (int k = 0; k < WM_K; ++k) {
+                    int qx = x + k - WM_R;
+                    qx = qx < 0 ? qx + W : (qx >= W ? qx - W : qx);
+                    gq[slot][k] = g1[rowo + qx];
+                }
+            }
+            if constexpr (CACHED) {
+#pragma unroll
+                for (int k = 0; k < WM_WROW / 4; ++k) gq[slot][k] = wrow[(wy + WM_R) * (WM_WROW / 4) + k];
             }
         };
         auto take_row = [&](int slot, int wy) __attribute__((always_inline)) {
             // (the 19 weights first: independent double-precision chains - division, exp - the scheduler can interleave; with
             // one or two waves per SIMD a single chain would run at its own latency)
-            float wk[WM_K];
+            float wk[WM_WROW];
+            if constexpr (CACHED) {
 #pragma unroll
-            for (int k = 0; k < WM_K; ++k) wk[k] = wm_weight<RIGHT>(p, gq[slot][k], k - WM_R, wy);
+                for (int k = 0; k < WM_WROW / 4; ++k) { wk[4 * k] = gq[slot][k].x; wk[4 * k + 1] = gq[slot][k].y; wk[4 * k + 2] = gq[slot][k].z; wk[4 * k + 3] = gq[slot][k].w; }
+            } else {
+#pragma unroll
+                for (int k = 0; k < WM_K; ++k) wk[k] = wm_weight<RIGHT>(p, gq[slot][k], k - WM_R, wy);
+            }
+            // Branch free: one wave per SIMD at best (the LDS histograms), so the kernel runs at the pace one wave issues
+            // instructions, and the exec-mask bookkeeping of three data-dependent branches per tap (a run-length shortcut for
+            // equal neighbours among them) was 2/3 of its instruction stream (PMC: 39 VALU + 39 scalar + 10 branch instructions per
+            // tap).  A tap that does not vote (dep == 0, or dep >= maxDis: cannot come out of a WTA over maxDis slices) adds its
+            // weight to bin 0, which nothing reads; adding +0.0f to the non-negative total is the identity.
 #pragma unroll
             for (int k = 0; k < WM_K; ++k) {
-                const int dep = dq[slot][k];
+                const unsigned dep = (dq[slot][k >> 2] >> (8 * (k & 3))) & 0xffu;
                 const float w = wk[k];
-                if (dep != 0) tot = __fadd_rn(tot, w);
-                if (dep != 0 && dep < maxDis) {            // (dep >= maxDis cannot come out of a WTA over maxDis slices: no bin)
-                    if (dep != run_d) {
-                        if (run_d != 0) hist[run_d * 64 + lane] = run_s;
-                        run_s = hist[dep * 64 + lane];
-                        run_d = dep;
-                    }
-                    run_s = __fadd_rn(run_s, w);
-                }
+                tot = __fadd_rn(tot, dep != 0u ? w : 0.0f);
+                const unsigned bin = dep < (unsigned)maxDis ? dep : 0u;
+                // (ds_add_f32 gives the same bits and needs no read, but measured 40 % slower: the LDS processes a 64-lane float
+                // atomic far below the rate of a read and a write)
+                float *hp = &hist[bin * 64u + lane];
+                *hp = __fadd_rn(*hp, w);
+                dlo = min(dlo, bin - 1u);              // (bin 0: 0xffffffff, no effect)
+                dhi = max(dhi, bin);
             }
         };
         issue_row(0, -WM_R);
@@ -300,17 +394,28 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2))) void
             take_row(1, wy + 1);
         }
         take_row(0, WM_R);
-        if (run_d != 0) hist[run_d * 64 + lane] = run_s;
         // ---- threshold scan over the non-empty bins, ascending d (src/PP.cpp:184-192) ----
         const float half = __fdiv_rn(tot, 2.0f);
         float run = 0.0f;
         int filterDep = 0;
         bool found = run >= half;             // d = 0: sumWgt(0) >= halfWgt only when nobody voted
-        for (int d = 1; d < maxDis; ++d) {
-            const float h = hist[d * 64 + lane];
-            if (!found && h != 0.0f) {
-                run = __fadd_rn(run, h);
-                if (run >= half) { filterDep = d; found = true; }
+        // (only the bins some lane of the wave touched: the others are zero, and adding an empty bin is the identity)
+        int wlo = (int)dlo + 1, whi = (int)dhi;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { wlo = min(wlo, __shfl_xor(wlo, o)); whi = max(whi, __shfl_xor(whi, o)); }
+        // (branch free, four bins per iteration with their loads issued together: while !found, run < half, so an empty bin -
+        // adding +0.0f - can neither change run nor end the scan)
+        for (int d0 = wlo; d0 <= whi; d0 += 4) {
+            float h[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) h[j] = d0 + j <= whi ? hist[(d0 + j) * 64 + lane] : 0.0f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (d0 + j <= whi) hist[(d0 + j) * 64 + lane] = 0.0f;
+                run = __fadd_rn(run, h[j]);
+                const bool hit = !found && run >= half;
+                filterDep = hit ? d0 + j : filterDep;
+                found = found || hit;
             }
         }
         // (not found: the running sum never reaches half - only possible with NaN weights - filterDep stays 0 as in the reference)
@@ -328,10 +433,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2))) void
 // accumulated in window raster order (lane l owns bins l, l+64, ..: every lane scans the (disparity, weight) pairs from LDS
 // and adds the ones that fall into its bins).  ~10 us per evaluation instead of ~80 us for a batch of 64, at 30x the
 // instructions per evaluation.
-template <bool RIGHT, int NB>
+template <bool RIGHT, int NB, bool CACHED>
 __global__ __launch_bounds__(64) void k_wm_eval_w(const uint8_t *__restrict__ cur, const uint8_t *__restrict__ orig,
                                                const float4 *__restrict__ g1, const int *__restrict__ list, const int *n_act,
-                                               uint8_t *__restrict__ newv, int *__restrict__ chg, int *n_chg, int W, int H, int maxDis)
+                                               uint8_t *__restrict__ newv, int *__restrict__ chg, int *n_chg, int W, int H, int maxDis,
+                                               const float *__restrict__ wts, const int *__restrict__ slot_of)
 {
     // NB == 1: taps in window raster order.  NB > 1: the voting taps stably partitioned by dep / 64 (bucket j holds, in raster
     // order, the taps of the bins lane + 64 j, buckets back to back), so a lane walks every tap once instead of NB times;
@@ -379,7 +485,9 @@ __global__ __launch_bounds__(64) void k_wm_eval_w(const uint8_t *__restrict__ cu
         for (int k = 0; k < WM_ROUNDS; ++k) {
             const int t = min(lane + 64 * k, WM_TAPS - 1);
             const int wy = t / WM_K - WM_R, wx = t % WM_K - WM_R;
-            const float w = wm_weight<RIGHT>(p, g1[off[k]], wx, wy);
+            float w;
+            if constexpr (CACHED) w = wts[(size_t)slot_of[pix] * WM_WPIX + (wy + WM_R) * WM_WROW + wx + WM_R];   // (the first sweep stored it)
+            else w = wm_weight<RIGHT>(p, g1[off[k]], wx, wy);
             const bool live = lane + 64 * k < WM_TAPS;
             if (NB == 1) {
                 if (live) taps[t] = make_float2(__int_as_float(dep[k]), dep[k] != 0 ? w : 0.0f);
@@ -442,14 +550,61 @@ __global__ __launch_bounds__(64) void k_wm_eval_w(const uint8_t *__restrict__ cu
     }
 }
 
+// Which pixels does the next sweep evaluate?  Every invalid pixel that has a pixel changed by this sweep among the EARLIER taps
+// of its window.  Two forms, chosen on the device from the counts:
+//   scatter (k_wm_apply, short change lists - the tail sweeps): one wave per changed pixel stamps its later invalid window
+//     neighbours (an atomic exchange each: once per pixel and sweep);
+//   gather (k_wm_apply marks, k_wm_gather collects; long change lists - the first sweeps, where scatter spent 36 atomics per changed pixel:
+//     7.7 of 19 ms at 1080p / 20 % invalid): the changed pixels mark themselves and the 19 columns around them in their own
+//     row (rowany[y][x] = "row y changed within x +- 9", plain byte stores of the sweep's mark), then every invalid pixel looks
+//     at rowany of the earlier rows of its window at its own column and at the earlier taps of its own row: <= 36 byte loads.
+// (measured at 1080p: the gather pass costs ~0.09 ms whatever changed, the scatter pass ~3 ns per changed pixel)
+__device__ __forceinline__ bool wm_gather_form(int n_chg, int n_inv) { return n_inv >= 4096 && (long long)n_chg * 16 >= n_inv; }
+
+__global__ __launch_bounds__(256) void k_wm_gather(const int *__restrict__ inv, const int *n_inv, const int *n_chg,
+                                                  const uint8_t *__restrict__ chgb, const uint8_t *__restrict__ rowany, int mark,
+                                                  int *__restrict__ next, int *n_next, int W, int H)
+{
+    const int ninv = *n_inv;
+    if (!wm_gather_form(*n_chg, ninv)) return;
+    const int lane = threadIdx.x & 63;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i - lane < ninv; i += gridDim.x * blockDim.x) {   // (whole waves: wm_append)
+        const bool live = i < ninv;
+        const int pix = inv[live ? i : 0];
+        const int y = pix / W, x = pix - y * W;
+        bool want = false;
+#pragma unroll
+        for (int w = -WM_R; w <= WM_R; ++w) {
+            if (w == 0) continue;
+            const int qy = ((y + w) % H + H) % H, qx = ((x + w) % W + W) % W;
+            if (qy < y) want |= rowany[qy * W + x] == (uint8_t)mark;      // an earlier row of the window (also through the wrap)
+            if (qx < x) want |= chgb[y * W + qx] == (uint8_t)mark;        // an earlier tap of the pixel's own row
+        }
+        want = want && live;
+        const int slot = wm_append(n_next, want);
+        if (want) next[slot] = pix;
+    }
+}
+
 // the changed pixels take their new value; every invalid pixel LATER in raster order that has one of them in its window
 // is evaluated again in the next sweep (stamp: once)
 __global__ __launch_bounds__(64) void k_wm_apply(uint8_t *__restrict__ cur, const uint8_t *__restrict__ newv, const uint8_t *__restrict__ valid,
-                                                const int *__restrict__ chg, const int *n_chg, int *__restrict__ stamp, int mark,
-                                                int *__restrict__ next, int *n_next, int W, int H)
+                                                const int *__restrict__ chg, const int *n_chg, const int *n_inv, int *__restrict__ stamp, int mark,
+                                                int *__restrict__ next, int *n_next, int W, int H, uint8_t *__restrict__ chgb, uint8_t *__restrict__ rowany)
 {
     const int lane = threadIdx.x;
     const int n = *n_chg;
+    if (wm_gather_form(n, *n_inv)) {   // gather form: only mark (one thread per changed pixel); k_wm_gather builds the next list
+        for (int i = blockIdx.x * 64 + lane; i < n; i += gridDim.x * 64) {
+            const int pix = chg[i];
+            const int y = pix / W, x = pix - y * W;
+            cur[pix] = newv[pix];
+            chgb[pix] = (uint8_t)mark;
+#pragma unroll
+            for (int wx = -WM_R; wx <= WM_R; ++wx) rowany[y * W + ((x + wx) % W + W) % W] = (uint8_t)mark;
+        }
+        return;
+    }
     constexpr int WM_ROUNDS = (WM_TAPS + 63) / 64;
     for (int i = blockIdx.x; i < n; i += gridDim.x) {
         const int pix = chg[i];
@@ -473,37 +628,54 @@ __global__ __launch_bounds__(64) void k_wm_apply(uint8_t *__restrict__ cur, cons
     }
 }
 
+// the 19 x 19 weights of the n_inv invalid pixels of `inv` (n = an upper bound of *n_inv, for the grid) -> wts, slot_of
+void launch_wm_weights(hipStream_t s, const float4 *g1, int W, int H, int right, const int *inv, const int *n_inv, int n, float *wts, int *slot_of)
+{
+    const long long threads = (long long)n * WM_K;
+    const int blocks = (int)((threads + 255) / 256 < 65536 ? (threads + 255) / 256 : 65536);
+    if (right) hipLaunchKernelGGL(k_wm_weights<true>, dim3(blocks), dim3(256), 0, s, g1, inv, n_inv, (float4 *)wts, slot_of, W, H);
+    else hipLaunchKernelGGL(k_wm_weights<false>, dim3(blocks), dim3(256), 0, s, g1, inv, n_inv, (float4 *)wts, slot_of, W, H);
+}
+
 void launch_wm_seed(hipStream_t s, const uint8_t *valid, int W, int H, int *list, int *cnt)
 {
-    const int HW = W * H;
-    hipLaunchKernelGGL(k_wm_seed, dim3((HW + 255) / 256), dim3(256), 0, s, valid, HW, list, cnt);
+    const int HW = W * H, per_block = 256 * WM_SEED_PER;
+    hipLaunchKernelGGL(k_wm_seed, dim3((HW + per_block - 1) / per_block), dim3(256), 0, s, valid, HW, list, cnt);
 }
 
 // one sweep: evaluate list `act` (count *n_act) -> changed pixels (chg, *n_chg) -> applied, dependents -> list `next` (*n_next)
 void launch_wm_sweep(hipStream_t s, uint8_t *cur, const uint8_t *orig, const uint8_t *valid, const float4 *g1, int W, int H, int maxDis,
                      int right, const int *act, const int *n_act, uint8_t *newv, int *chg, int *n_chg, int *stamp, int mark,
-                     int *next, int *n_next)
-{
+                     int *next, int *n_next, const float *wts, const int *slot_of, const int *inv, const int *n_inv, uint8_t *chgb, uint8_t *rowany)
+{   // wts / slot_of: the weight cache (launch_wm_weights) or null; inv / n_inv: the list of all invalid pixels (the first sweep's
+    // list); chgb, rowany: byte maps of the gather form (zero at the start)
+    const bool cached = wts != nullptr;
     const dim3 ga(2048);
     // two waves per CU at D = 256 (64 KB of LDS each), up to ten at D <= 64; the grid strides over batches of 64 pixels
     const size_t lds = (size_t)maxDis * 64 * sizeof(float);
     const PcDev dev = pc_dev();
     const int per_cu = (int)(160 * 1024 / (lds > 16384 ? lds : 16384));
     const dim3 ge(dev.nxcd * dev.cus_per_xcd * (per_cu < 1 ? 1 : per_cu));
-    if (right) hipLaunchKernelGGL(k_wm_eval<true>, ge, dim3(64), lds, s, (const uint8_t *)cur, orig, g1, act, n_act, newv, chg, n_chg, W, H, maxDis);
-    else hipLaunchKernelGGL(k_wm_eval<false>, ge, dim3(64), lds, s, (const uint8_t *)cur, orig, g1, act, n_act, newv, chg, n_chg, W, H, maxDis);
+#define PSM_LAUNCH_WL(R, CA) \
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_wm_eval<R, CA>), ge, dim3(64), lds, s, (const uint8_t *)cur, orig, g1, act, n_act, newv, chg, n_chg, W, H, maxDis, (const float4 *)wts, slot_of)
+    if (right) { if (cached) PSM_LAUNCH_WL(true, true); else PSM_LAUNCH_WL(true, false); }
+    else { if (cached) PSM_LAUNCH_WL(false, true); else PSM_LAUNCH_WL(false, false); }
+#undef PSM_LAUNCH_WL
     // ... and the one-wave-per-pixel form for short lists (either kernel returns at once when the list is not its size)
     const int nb = (maxDis + 63) / 64;
     const dim3 gw(8192);
-#define PSM_LAUNCH_WE(R, NBV) \
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_wm_eval_w<R, NBV>), gw, dim3(64), 0, s, (const uint8_t *)cur, orig, g1, act, n_act, newv, chg, n_chg, W, H, maxDis)
+#define PSM_LAUNCH_WE(R, NBV, CA) \
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_wm_eval_w<R, NBV, CA>), gw, dim3(64), 0, s, (const uint8_t *)cur, orig, g1, act, n_act, newv, chg, n_chg, W, H, maxDis, wts, slot_of)
+#define PSM_LAUNCH_WE2(R, NBV) { if (cached) PSM_LAUNCH_WE(R, NBV, true); else PSM_LAUNCH_WE(R, NBV, false); }
     if (right) {
-        if (nb <= 1) PSM_LAUNCH_WE(true, 1); else if (nb == 2) PSM_LAUNCH_WE(true, 2); else if (nb == 3) PSM_LAUNCH_WE(true, 3); else PSM_LAUNCH_WE(true, 4);
+        if (nb <= 1) PSM_LAUNCH_WE2(true, 1) else if (nb == 2) PSM_LAUNCH_WE2(true, 2) else if (nb == 3) PSM_LAUNCH_WE2(true, 3) else PSM_LAUNCH_WE2(true, 4)
     } else {
-        if (nb <= 1) PSM_LAUNCH_WE(false, 1); else if (nb == 2) PSM_LAUNCH_WE(false, 2); else if (nb == 3) PSM_LAUNCH_WE(false, 3); else PSM_LAUNCH_WE(false, 4);
+        if (nb <= 1) PSM_LAUNCH_WE2(false, 1) else if (nb == 2) PSM_LAUNCH_WE2(false, 2) else if (nb == 3) PSM_LAUNCH_WE2(false, 3) else PSM_LAUNCH_WE2(false, 4)
     }
+#undef PSM_LAUNCH_WE2
 #undef PSM_LAUNCH_WE
-    hipLaunchKernelGGL(k_wm_apply, ga, dim3(64), 0, s, cur, (const uint8_t *)newv, valid, (const int *)chg, (const int *)n_chg, stamp, mark, next, n_next, W, H);
+    hipLaunchKernelGGL(k_wm_apply, ga, dim3(64), 0, s, cur, (const uint8_t *)newv, valid, (const int *)chg, (const int *)n_chg, n_inv, stamp, mark, next, n_next, W, H, chgb, rowany);
+    hipLaunchKernelGGL(k_wm_gather, dim3(2048), dim3(256), 0, s, inv, n_inv, (const int *)n_chg, (const uint8_t *)chgb, (const uint8_t *)rowany, mark, next, n_next, W, H);
 }
 
 void launch_wgt_median(hipStream_t s, uint8_t *dis, const uint8_t *valid, const float4 *g1, int W, int H, int maxDis, int right,

@@ -23,6 +23,10 @@ def run(name, H, W, D, lv):
 
 H, W, D = 375, 450, 64
 rng = np.random.default_rng(0)
+if len(sys.argv) > 1 and sys.argv[1] == "hd20":      # one case, for a kernel trace
+    H, W, D = 1080, 1920, 256
+    run("1080p iid 20%", H, W, D, (rng.random((H, W)) > 0.2).astype(np.uint8))
+    sys.exit(0)
 run("none invalid", H, W, D, np.ones((H, W), np.uint8))
 run("iid 5%", H, W, D, (rng.random((H, W)) > 0.05).astype(np.uint8))
 run("iid 43%", H, W, D, (rng.random((H, W)) > 0.43).astype(np.uint8))
