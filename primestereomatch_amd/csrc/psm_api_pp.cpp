@@ -133,8 +133,10 @@ int psm_wgt_median(psm_ctx *c, uint8_t *lmap, uint8_t *rmap, size_t stride)
             }
         }
         int sw = 0;
+        bool tail[2] = {false, false};     // the list going into the next sweep is short: two launches per sweep, more sweeps per check
         while (sw < CAP && !(done[0] && done[1])) {
-            const int upto = sw + CHK < CAP ? sw + CHK : CAP;
+            const int chk = ((tail[0] || done[0]) && (tail[1] || done[1])) ? 2 * CHK : CHK;
+            const int upto = sw + chk < CAP ? sw + chk : CAP;
             {
                 Prof p(c, PSM_K_WMF);
                 for (; sw < upto; ++sw)
@@ -142,7 +144,7 @@ int psm_wgt_median(psm_ctx *c, uint8_t *lmap, uint8_t *rmap, size_t stride)
                         if (!done[s])
                             launch_wm_sweep(c->stream, c->maps + s * HW, orig[s], c->valid + s * HW, c->g[s].g1, c->W, c->H, c->D, s,
                                             sw == 0 ? inv[s] : list[s][(sw + 1) & 1], cnt[s] + 2 * sw, newv[s], chg[s], cnt[s] + 2 * sw + 1, stamp[s], sw + 1,
-                                            list[s][sw & 1], cnt[s] + 2 * (sw + 1), wts[s], slot_of[s], inv[s], cnt[s], chgb[s], rowany[s]);
+                                            list[s][sw & 1], cnt[s] + 2 * (sw + 1), wts[s], slot_of[s], inv[s], cnt[s], chgb[s], rowany[s], tail[s]);
             }
             if (check_launch(c, "wgt_median (sweeps)")) return 1;
             for (int s = 0; s < 2; ++s)
@@ -160,6 +162,7 @@ int psm_wgt_median(psm_ctx *c, uint8_t *lmap, uint8_t *rmap, size_t stride)
                         break;
                     }
                 }
+                tail[s] = sw < CAP && hc[s * ncnt + 2 * sw] <= 2048;      // (the count the last sweep left for the next one)
             }
         }
         // no fixed point within CAP sweeps (long chains of pixels that keep flipping each other): start over from the input

@@ -437,7 +437,7 @@ template <bool RIGHT, int NB, bool CACHED>
 __global__ __launch_bounds__(64) void k_wm_eval_w(const uint8_t *__restrict__ cur, const uint8_t *__restrict__ orig,
                                                const float4 *__restrict__ g1, const int *__restrict__ list, const int *n_act,
                                                uint8_t *__restrict__ newv, int *__restrict__ chg, int *n_chg, int W, int H, int maxDis,
-                                               const float *__restrict__ wts, const int *__restrict__ slot_of)
+                                               const float *__restrict__ wts, const int *__restrict__ slot_of, int force)
 {
     // NB == 1: taps in window raster order.  NB > 1: the voting taps stably partitioned by dep / 64 (bucket j holds, in raster
     // order, the taps of the bins lane + 64 j, buckets back to back), so a lane walks every tap once instead of NB times;
@@ -447,7 +447,7 @@ __global__ __launch_bounds__(64) void k_wm_eval_w(const uint8_t *__restrict__ cu
     __shared__ float hist[64 * NB];
     const int lane = threadIdx.x;
     const int n = *n_act;
-    if (n >= WM_LANE_MIN) return;              // long lists: k_wm_eval
+    if (!force && n >= WM_LANE_MIN) return;    // long lists: k_wm_eval (force: a tail sweep, launched without it)
     constexpr int WM_ROUNDS = (WM_TAPS + 63) / 64;
     const unsigned long long below = (1ull << lane) - 1ull;
     for (int i = blockIdx.x; i < n; i += gridDim.x) {
@@ -590,11 +590,11 @@ __global__ __launch_bounds__(256) void k_wm_gather(const int *__restrict__ inv, 
 // is evaluated again in the next sweep (stamp: once)
 __global__ __launch_bounds__(64) void k_wm_apply(uint8_t *__restrict__ cur, const uint8_t *__restrict__ newv, const uint8_t *__restrict__ valid,
                                                 const int *__restrict__ chg, const int *n_chg, const int *n_inv, int *__restrict__ stamp, int mark,
-                                                int *__restrict__ next, int *n_next, int W, int H, uint8_t *__restrict__ chgb, uint8_t *__restrict__ rowany)
+                                                int *__restrict__ next, int *n_next, int W, int H, uint8_t *__restrict__ chgb, uint8_t *__restrict__ rowany, int force)
 {
     const int lane = threadIdx.x;
     const int n = *n_chg;
-    if (wm_gather_form(n, *n_inv)) {   // gather form: only mark (one thread per changed pixel); k_wm_gather builds the next list
+    if (!force && wm_gather_form(n, *n_inv)) {   // gather form: only mark (one thread per changed pixel); k_wm_gather builds the next list
         for (int i = blockIdx.x * 64 + lane; i < n; i += gridDim.x * 64) {
             const int pix = chg[i];
             const int y = pix / W, x = pix - y * W;
@@ -646,8 +646,9 @@ void launch_wm_seed(hipStream_t s, const uint8_t *valid, int W, int H, int *list
 // one sweep: evaluate list `act` (count *n_act) -> changed pixels (chg, *n_chg) -> applied, dependents -> list `next` (*n_next)
 void launch_wm_sweep(hipStream_t s, uint8_t *cur, const uint8_t *orig, const uint8_t *valid, const float4 *g1, int W, int H, int maxDis,
                      int right, const int *act, const int *n_act, uint8_t *newv, int *chg, int *n_chg, int *stamp, int mark,
-                     int *next, int *n_next, const float *wts, const int *slot_of, const int *inv, const int *n_inv, uint8_t *chgb, uint8_t *rowany)
-{   // wts / slot_of: the weight cache (launch_wm_weights) or null; inv / n_inv: the list of all invalid pixels (the first sweep's
+                     int *next, int *n_next, const float *wts, const int *slot_of, const int *inv, const int *n_inv, uint8_t *chgb, uint8_t *rowany, bool tail)
+{   // tail: the host has seen a short list going into this sweep - only the one-wave-per-pixel evaluation and the scatter form of
+    // the dependents are launched (both made to take whatever the list turns out to be): two launches instead of four   // wts / slot_of: the weight cache (launch_wm_weights) or null; inv / n_inv: the list of all invalid pixels (the first sweep's
     // list); chgb, rowany: byte maps of the gather form (zero at the start)
     const bool cached = wts != nullptr;
     const dim3 ga(2048);
@@ -656,16 +657,18 @@ void launch_wm_sweep(hipStream_t s, uint8_t *cur, const uint8_t *orig, const uin
     const PcDev dev = pc_dev();
     const int per_cu = (int)(160 * 1024 / (lds > 16384 ? lds : 16384));
     const dim3 ge(dev.nxcd * dev.cus_per_xcd * (per_cu < 1 ? 1 : per_cu));
+    const int force = tail ? 1 : 0;
 #define PSM_LAUNCH_WL(R, CA) \
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_wm_eval<R, CA>), ge, dim3(64), lds, s, (const uint8_t *)cur, orig, g1, act, n_act, newv, chg, n_chg, W, H, maxDis, (const float4 *)wts, slot_of)
-    if (right) { if (cached) PSM_LAUNCH_WL(true, true); else PSM_LAUNCH_WL(true, false); }
+    if (tail) {}
+    else if (right) { if (cached) PSM_LAUNCH_WL(true, true); else PSM_LAUNCH_WL(true, false); }
     else { if (cached) PSM_LAUNCH_WL(false, true); else PSM_LAUNCH_WL(false, false); }
 #undef PSM_LAUNCH_WL
     // ... and the one-wave-per-pixel form for short lists (either kernel returns at once when the list is not its size)
     const int nb = (maxDis + 63) / 64;
     const dim3 gw(8192);
 #define PSM_LAUNCH_WE(R, NBV, CA) \
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_wm_eval_w<R, NBV, CA>), gw, dim3(64), 0, s, (const uint8_t *)cur, orig, g1, act, n_act, newv, chg, n_chg, W, H, maxDis, wts, slot_of)
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_wm_eval_w<R, NBV, CA>), gw, dim3(64), 0, s, (const uint8_t *)cur, orig, g1, act, n_act, newv, chg, n_chg, W, H, maxDis, wts, slot_of, force)
 #define PSM_LAUNCH_WE2(R, NBV) { if (cached) PSM_LAUNCH_WE(R, NBV, true); else PSM_LAUNCH_WE(R, NBV, false); }
     if (right) {
         if (nb <= 1) PSM_LAUNCH_WE2(true, 1) else if (nb == 2) PSM_LAUNCH_WE2(true, 2) else if (nb == 3) PSM_LAUNCH_WE2(true, 3) else PSM_LAUNCH_WE2(true, 4)
@@ -674,8 +677,8 @@ void launch_wm_sweep(hipStream_t s, uint8_t *cur, const uint8_t *orig, const uin
     }
 #undef PSM_LAUNCH_WE2
 #undef PSM_LAUNCH_WE
-    hipLaunchKernelGGL(k_wm_apply, ga, dim3(64), 0, s, cur, (const uint8_t *)newv, valid, (const int *)chg, (const int *)n_chg, n_inv, stamp, mark, next, n_next, W, H, chgb, rowany);
-    hipLaunchKernelGGL(k_wm_gather, dim3(2048), dim3(256), 0, s, inv, n_inv, (const int *)n_chg, (const uint8_t *)chgb, (const uint8_t *)rowany, mark, next, n_next, W, H);
+    hipLaunchKernelGGL(k_wm_apply, ga, dim3(64), 0, s, cur, (const uint8_t *)newv, valid, (const int *)chg, (const int *)n_chg, n_inv, stamp, mark, next, n_next, W, H, chgb, rowany, force);
+    if (!tail) hipLaunchKernelGGL(k_wm_gather, dim3(2048), dim3(256), 0, s, inv, n_inv, (const int *)n_chg, (const uint8_t *)chgb, (const uint8_t *)rowany, mark, next, n_next, W, H);
 }
 
 void launch_wgt_median(hipStream_t s, uint8_t *dis, const uint8_t *valid, const float4 *g1, int W, int H, int maxDis, int right,
