@@ -210,7 +210,10 @@ int psm_fill_invalid(psm_ctx *ctx, uint8_t *lmap, uint8_t *rmap, size_t stride);
  * recursion (every sweep evaluates all pixels whose earlier window taps changed; it stops, at the reference's map, when
  * a sweep changes nothing); falls back to a row-dataflow pipeline with the reference's own dependency chain if 96
  * sweeps do not reach it (PSM_OPT_FLAGS 4194304: dataflow form only).
- * Needs W, H >= 9 (the reference's modulo wrap is undefined below that).  lmap/rmap (optional) receive the maps. */
+ * Needs W, H >= 9 (the reference's modulo wrap is undefined below that).  lmap/rmap (optional) receive the maps.
+ * Device memory: from 8192 invalid pixels per map the 19 x 19 window weights of every invalid pixel are formed once and kept
+ * for the sweeps - 1.5 KB per invalid pixel (0.6 GB per 1080p map at 20 % invalid), held by the context until psm_destroy;
+ * above 12 GB for the pair, or when the allocation fails, the evaluations form their weights themselves (slower, same maps). */
 int psm_wgt_median(psm_ctx *ctx, uint8_t *lmap, uint8_t *rmap, size_t stride);
 /* What the last psm_wgt_median did, per map {left, right}: sweeps until the fixed point (-1: dataflow form) and pixel
  * evaluations in total.  Either pointer may be NULL. */
