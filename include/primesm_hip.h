@@ -72,7 +72,9 @@ enum psm_flag {
                                            the seeded key plane) */
     PSM_FLAG_WMF_DATAFLOW = 4194304,    /* psm_wgt_median runs its row-dataflow form only */
     PSM_FLAG_WMF_TWO_SWEEPS = 8388608,  /* ... at most 2 sweeps of its parallel form (test hook for the fall-back) */
-    PSM_FLAGS_ALL = 128 | 4096 | 8192 | 1048576 | 2097152 | 4194304 | 8388608
+    PSM_FLAG_WMF_NO_CACHE = 16777216,   /* ... without the cache of window weights (1.5 KB of device memory per invalid pixel):
+                                           every evaluation forms its weights itself; same maps */
+    PSM_FLAGS_ALL = 128 | 4096 | 8192 | 1048576 | 2097152 | 4194304 | 8388608 | 16777216
 };
 
 /* Number of usable HIP devices; 0 if none.  Replaces openCLdevicepoll()

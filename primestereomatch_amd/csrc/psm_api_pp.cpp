@@ -115,7 +115,7 @@ int psm_wgt_median(psm_ctx *c, uint8_t *lmap, uint8_t *rmap, size_t stride)
             PSM_HIP(c, hipStreamSynchronize(c->stream));
             size_t need[2], tot = 0;
             for (int s = 0; s < 2; ++s) { need[s] = n0[s] >= WM_LANE_MIN ? (size_t)n0[s] * WM_WPIX : 0; tot += need[s]; }
-            if (tot && tot * sizeof(float) <= WM_CACHE_MAX) {
+            if (tot && tot * sizeof(float) <= WM_CACHE_MAX && !(c->march.flags & PSM_FLAG_WMF_NO_CACHE)) {
                 if (c->wm_wts_n < tot) {
                     (void)hipFree(c->wm_wts);
                     c->wm_wts = nullptr;
