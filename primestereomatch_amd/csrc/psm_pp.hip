@@ -309,8 +309,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2))) void
         if constexpr (CACHED) wrow = wts + (size_t)slot_of[pix] * (WM_WPIX / 4);
         unsigned dlo = (unsigned)maxDis, dhi = 0u;   // range of the bins this evaluation touches: dlo + 1 .. dhi (zeroed again after the scan)
         float tot = 0.0f;
-        // One window row at a time: its 19 + 19 loads (every lane its own pixel: uncoalesced, latency bound) are all issued
-        // before the first weight is formed, and the next row's are in flight while this row is accumulated.
+        // One window row at a time: its loads (five dwords of disparities and five float4 of cached weights, or the 19 g1 values
+        // the weights are formed from; every lane its own pixel: uncoalesced) are all issued before the row is accumulated, and
+        // the next row's are in flight meanwhile.
         float4 gq[2][CACHED ? WM_WROW / 4 : WM_K];     // CACHED: the row's weights instead of its g1 values
         // the 19 disparities of a window row, packed four to a dword.  A row is 19 consecutive bytes of one plane (the current
         // iterate for an earlier row, the input for a later one; the pixel's own row: left of it / from it on) unless the window
@@ -357,8 +358,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2))) void
             }
         };
         auto take_row = [&](int slot, int wy) __attribute__((always_inline)) {
-            // (the 19 weights first: independent double-precision chains - division, exp - the scheduler can interleave; with
-            // one or two waves per SIMD a single chain would run at its own latency)
+            // (!CACHED: the 19 weights first - independent double-precision chains, division and exp, the scheduler can interleave)
             float wk[WM_WROW];
             if constexpr (CACHED) {
 #pragma unroll
