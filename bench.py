@@ -51,19 +51,43 @@ ALG = {"f32": {"cvf_fused": 40.0, "cvf_a": 20.0, "cvc": 4.0, "wta": 4.0, "box8":
 FORM_NAME = {0: "store", 1: "planes", 2: "keys"}
 
 
-def spawn_ranks(n):
-    """Re-run this command as n ranks (one per GPU) under torch.distributed.run; returns its exit code."""
+def spawn_ranks(n, args):
+    """Re-run this command as n ranks (one per GPU) under torch.distributed.run; returns its exit code.
+    --same-device (all ranks on GPU 0: the N > 1 protocol on a one-GPU box) with --backend auto: RCCL is tried first; if it
+    refuses the duplicate device (or does not come up within two minutes) the run is repeated with the exchange staged through
+    host memory over gloo (primestereomatch_amd/exchange.py) - the line then says which transport carried it and why."""
+    import signal
     import socket
     import subprocess
-    with socket.socket() as so:
-        so.bind(("127.0.0.1", 0))
-        port = so.getsockname()[1]
-    env = dict(os.environ)
-    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # the host driver only supports dmabuf IPC (RCCL needs it)
-    env.setdefault("OMP_NUM_THREADS", "8")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
-           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
-    return subprocess.run(cmd, env=env).returncode
+
+    def run(extra, timeout=None):
+        with socket.socket() as so:
+            so.bind(("127.0.0.1", 0))
+            port = so.getsockname()[1]
+        env = dict(os.environ)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # the host driver only supports dmabuf IPC (RCCL needs it)
+        env.setdefault("OMP_NUM_THREADS", "8")
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:] + extra
+        p = subprocess.Popen(cmd, env=env, start_new_session=True, stderr=subprocess.PIPE if timeout else None, text=True)
+        try:
+            _, err = p.communicate(timeout=timeout)
+        except subprocess.TimeoutExpired:
+            os.killpg(p.pid, signal.SIGKILL)           # (our own process group: the launcher and its ranks)
+            p.wait()
+            return 124, "no communicator within %d s" % timeout
+        return p.returncode, err
+
+    if args.same_device and args.backend == "auto":
+        rc, err = run(["--backend", "nccl", "--nccl-probe"], timeout=120)
+        if rc == 0:
+            return run(["--backend", "nccl"])[0]
+        why = [ln.strip() for ln in (err or "").splitlines() if "rror" in ln or "uplicate" in ln or "NCCL WARN" in ln]
+        why = (why[-1] if why else str(err or "").strip().splitlines()[-1:] or ["rc %d" % rc])
+        why = why if isinstance(why, str) else why[0]
+        print("bench.py: RCCL with %d ranks on one device failed (%s) - staging the exchange over gloo" % (n, why[:200]), file=sys.stderr)
+        return run(["--backend", "gloo", "--backend-note", "RCCL refused %d ranks on one device: %s" % (n, why[:200])])[0]
+    return run([])[0]
 
 
 def parse_args():
@@ -81,7 +105,9 @@ def parse_args():
     ap.add_argument("--cpu-sample-d", type=int, default=0,
                     help="disparities in the CPU-baseline sample (0 = auto: the whole D at 1080p and below (~10 s on 8 threads), "
                          "proportionally fewer for larger images)")
-    ap.add_argument("--cpu-wide", action="store_true", help="also time the CPU baseline on min(64, host cores) threads (doubles its run time)")
+    ap.add_argument("--no-cpu-wide", action="store_true",
+                    help="skip the second CPU-baseline run on min(64, host cores) threads (SURVEY.md 8d asks for 8 threads and for the "
+                         "box's core count; the second run adds a few seconds)")
     ap.add_argument("--force-dist", action="store_true", help="use the torch.distributed path even for N=1")
     ap.add_argument("--exchange", default="", choices=["", "allreduce", "allgather", "none"],
                     help="--shard disp, N>1: the one exchange step - all_gather of the packed keys ((N-1)x33 MB per rank at 1080p; "
@@ -105,6 +131,14 @@ def parse_args():
                          "(default: a frame's collective overlaps the next frame's filter; two buffers)")
     ap.add_argument("--verify", action="store_true",
                     help="N=1: also compare the maps of the timed path with a fresh single-context run (always done for N>1)")
+    ap.add_argument("--same-device", action="store_true",
+                    help="N > 1: every rank uses GPU 0 - the N > 1 protocol (two buffers, pending exchange, gather / merge at world N) "
+                         "on a box with one GPU; a correctness run, not a scaling measurement")
+    ap.add_argument("--backend", default="auto", choices=["auto", "nccl", "gloo"],
+                    help="transport of the one exchange per frame: nccl = RCCL on device tensors (default); gloo = the same collective "
+                         "staged through page-locked host tensors (for --same-device when RCCL refuses a duplicate device)")
+    ap.add_argument("--nccl-probe", action="store_true", help=argparse.SUPPRESS)     # internal: init RCCL, one collective, exit
+    ap.add_argument("--backend-note", default="", help=argparse.SUPPRESS)
     ap.add_argument("--shard-sim", type=int, default=0,
                     help="diagnostic: time only rank 0's share of a G-rank job on this GPU (no exchange); "
                          "the JSON line is then NOT the headline metric")
@@ -126,13 +160,16 @@ def main():
     if N > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
         # bare `python bench.py --gpus N`: become the launcher - one rank per GPU under torch.distributed.run on
         # 127.0.0.1 - and pass rank 0's single JSON line through
-        return spawn_ranks(N)
+        return spawn_ranks(N, args)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     use_dist = (N > 1) or args.force_dist
-    torch = dist = None
+    torch = dist = ex = None
     json_fd = None
+    dev_index = 0 if args.same_device else local_rank
+    xname = "RCCL" if args.backend in ("auto", "nccl") else "gloo (host-staged)"
+    backend = "nccl" if args.backend == "auto" else args.backend
     if use_dist:
         # RCCL prints a version banner on the C-level stdout (flushed at exit, i.e. after our line): keep stdout for the ONE
         # JSON line only - everything else written to fd 1 by this process goes to stderr
@@ -147,9 +184,19 @@ def main():
             raise SystemExit(f"bench.py --gpus {N}: WORLD_SIZE={world} in the environment does not match")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local_rank))
+        torch.cuda.set_device(dev_index)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        from primestereomatch_amd.exchange import Exchange
+        ex = Exchange(torch, dist, backend)
+        if args.nccl_probe:      # does a communicator of these ranks come up at all?  (--same-device: usually not)
+            t = torch.ones(4, dtype=torch.int64, device="cuda")
+            ex.all_reduce_min(t)
+            torch.cuda.synchronize()
+            dist.destroy_process_group()
+            return 0
 
     import numpy as np
     import primestereomatch_amd as P
@@ -173,7 +220,7 @@ def main():
 
     def single_gpu_maps():
         """The same pair through a fresh unsharded context on this GPU: what every sharded run must reproduce bit for bit."""
-        with P.DispEst(l, r, D, 8, True, device=local_rank, dtype=dtype) as ref:
+        with P.DispEst(l, r, D, 8, True, device=dev_index, dtype=dtype) as ref:
             if args.fgf:
                 ref.setSubsampleRate(args.fgf)
             ref.CostConst_GPU()
@@ -202,7 +249,7 @@ def main():
             d0, d1 = 0, D // args.shard_sim
         else:
             d0, d1 = 0, D
-        de = P.DispEst(l, r, D, 8, True, device=local_rank, d_range=(d0, d1), dtype=dtype)
+        de = P.DispEst(l, r, D, 8, True, device=dev_index, d_range=(d0, d1), dtype=dtype)
         if args.seg_rows >= 0:
             de.set_option(capi.PSM_OPT_SEG_ROWS, args.seg_rows)
         de.set_option(capi.PSM_OPT_KERNEL_VARIANT, args.variant)
@@ -247,7 +294,7 @@ def main():
 
         def stripe_exchange(mb, async_op):
             stripes.pack_stripe(mb, y0, y1, send, H, W, rows_max)
-            return dist.all_gather_into_tensor(recv, send, async_op=async_op)      # the one exchange step (RCCL)
+            return ex.all_gather(recv, send, async_op=async_op)      # the one exchange step (RCCL; or staged over gloo)
 
         def step():
             de.CostConst_GPU()
@@ -255,7 +302,7 @@ def main():
                 de.CostFilter_FGF_GPU()
                 if use_dist:
                     de.DispSelect_partial(keys_local.data_ptr())
-                    dist.all_reduce(keys_local, op=dist.ReduceOp.MIN)
+                    ex.all_reduce_min(keys_local)
                     de.DispSelect_merge(keys_local.data_ptr(), 1, download=False)
                 elif args.shard_sim > 1:
                     de.DispSelect_partial()
@@ -288,7 +335,7 @@ def main():
                 de.set_key_buffer(kb.data_ptr())
                 de.CostFilter_GPU()
                 finish_pending()
-                w_ = dist.all_reduce(kb, op=dist.ReduceOp.MIN, async_op=True)
+                w_ = ex.all_reduce_min(kb, async_op=True)
                 pending.append(((w_,), kb))
                 return
             if use_dist:
@@ -298,10 +345,10 @@ def main():
                 if exchange == "none":       # diagnostic only: cost of the torch collective call itself
                     de.DispSelect_merge(keys_local.data_ptr(), 1, download=False)
                 elif exchange == "allreduce":
-                    dist.all_reduce(keys_local, op=dist.ReduceOp.MIN)     # the one exchange step (RCCL)
+                    ex.all_reduce_min(keys_local)                         # the one exchange step (RCCL)
                     de.DispSelect_merge(keys_local.data_ptr(), 1, download=False)
                 else:
-                    dist.all_gather_into_tensor(keys_all, keys_local)     # the one exchange step (RCCL)
+                    ex.all_gather(keys_all, keys_local)                   # the one exchange step (RCCL)
                     de.DispSelect_merge(keys_all.data_ptr(), world, download=False)
             elif args.shard_sim > 1 and not rows_mode:
                 de.DispSelect_partial()
@@ -318,7 +365,7 @@ def main():
 
         def barrier():
             if use_dist:
-                dist.barrier()
+                ex.barrier()
 
         for _ in range(args.warmup):
             step()
@@ -336,9 +383,7 @@ def main():
         launch_times = de.filter_launch_times()
         de.set_option(capi.PSM_OPT_PROFILE, 0)
         if use_dist:
-            t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            elapsed = float(t.item())
+            elapsed = ex.max_float(elapsed)
         rec = {"shard": shard if (use_dist or args.shard_sim > 1) else None,
                "exchange": (("all_gather of map rows" if rows_mode else exchange) if use_dist else None),
                "ms_per_step": 1e3 * elapsed / args.steps, "value": voxels_per_step / (elapsed / args.steps)}
@@ -534,22 +579,23 @@ def main():
     cpu = None
     oracle_maps = None
     O = None
-    want_oracle = rank == 0 and args.shard_sim <= 1 and not args.fgf and \
-        ((world == 1 and not args.no_cpu_baseline) or (world > 1 and not args.no_oracle_check))
+    sim = args.shard_sim > 1
+    want_oracle = rank == 0 and not args.fgf and \
+        ((world == 1 and not sim and not args.no_cpu_baseline) or ((world > 1 or sim) and not args.no_oracle_check))
     if want_oracle:
         from oracle import psm_oracle_py as O   # checker / baseline only - never on the GPU path
         cores = os.cpu_count() or 1
         threads = min(8, cores)                 # MAX_CPU_THREADS (include/ComFunc.h:52)
         sd = args.cpu_sample_d if args.cpu_sample_d > 0 else int(256.0 * (1920 * 1080) / (W * H))
         sd = max(2, min(sd, D))
-        if world > 1:
-            sd, threads = D, min(32, cores)     # N > 1: a checker run only (no cpu_baseline in the line)
+        if world > 1 or sim:
+            sd, threads = D, min(32, cores)     # N > 1 / --shard-sim: a checker run only (no cpu_baseline in the line)
         tcpu = time.perf_counter()
         res = (O.pipeline_u8 if dtype == "u8" else O.pipeline_f32)(l, r, sd, threads=threads)
         tcpu = time.perf_counter() - tcpu
         if sd == D:
             oracle_maps = [res["ldisp"], res["rdisp"]]
-        if world == 1:
+        if world == 1 and not sim:
             stage_s = (res["cvc_ms"] + res["cvf_ms"] + res["dispsel_ms"]) * 1e-3
             cpu = {"value": round(2.0 * W * H * sd / stage_s, 1), "unit": "voxels/s", "cores": threads,
                    "kind": "port", "host_cores": cores,
@@ -560,7 +606,7 @@ def main():
             # the same restatement on more host cores (SURVEY.md 8d asks for 8 threads and for the box's core count):
             # context only, the contract's cpu_baseline is the 8-thread figure above
             wide = min(64, cores)
-            if args.cpu_wide and wide > threads:
+            if not args.no_cpu_wide and wide > threads:
                 resw = (O.pipeline_u8 if dtype == "u8" else O.pipeline_f32)(l, r, sd, threads=wide)
                 sw = (resw["cvc_ms"] + resw["cvf_ms"] + resw["dispsel_ms"]) * 1e-3
                 cpu["wide"] = {"value": round(2.0 * W * H * sd / sw, 1), "cores": wide}
@@ -577,6 +623,45 @@ def main():
         if timed_maps is not None and oracle_maps is not None:      # (the maps downloaded right after the timed region, too)
             checks["oracle_maps_equal"] = bool(checks["oracle_maps_equal"] and np.array_equal(timed_maps[0], oracle_maps[0])
                                                and np.array_equal(timed_maps[1], oracle_maps[1]))
+        de.set_option(capi.PSM_OPT_ASYNC, 1)
+
+    # ---- --shard-sim G: the timed context holds share 0 of a G-part job.  The other G - 1 shares run once, untimed, in fresh
+    # contexts on this GPU; the whole is put together by the library's single-process exchange (psm_gather_rows_ctx /
+    # psm_disp_merge_ctx) with the TIMED context as the root, and compared with the unsharded run and the oracle ----
+    if rank == 0 and sim and not args.fgf:
+        G = args.shard_sim
+        de.set_option(capi.PSM_OPT_ASYNC, 0)
+        step(); sync()
+        parts_ctx = [de]
+        for g_ in range(1, G):
+            if rows_mode:
+                _, ya, yb = stripes.stripe_bounds(H, G, g_)
+                if yb <= ya:
+                    continue
+                o_ = P.DispEst(l, r, D, 8, True, device=dev_index, dtype=dtype)
+                o_.set_rows(ya, yb)
+            else:
+                o_ = P.DispEst(l, r, D, 8, True, device=dev_index, d_range=(D * g_ // G, D * (g_ + 1) // G), dtype=dtype)
+            if args.flags >= 0:
+                o_.set_option(capi.PSM_OPT_FLAGS, args.flags)
+            o_.CostConst_GPU()
+            o_.CostFilter_GPU()
+            o_.DispSelect_device() if rows_mode else o_.DispSelect_partial()
+            parts_ctx.append(o_)
+        if rows_mode:
+            de.gather_rows_ctx(parts_ctx)
+        else:
+            de.DispSelect_merge_ctx(parts_ctx)
+        whole = [de.lDisMap.copy(), de.rDisMap.copy()]
+        for o_ in parts_ctx[1:]:
+            o_.close()
+        ref_maps = single_gpu_maps()[:2]
+        checks["verified_vs_single_gpu"] = bool(all(np.array_equal(a, b) for a, b in zip(ref_maps, whole)))
+        if oracle_maps is not None:
+            nl, nr = int(np.count_nonzero(whole[0] != oracle_maps[0])), int(np.count_nonzero(whole[1] != oracle_maps[1]))
+            checks["oracle_maps_equal"], checks["oracle_map_mismatches"] = nl == 0 and nr == 0, [nl, nr]
+        checks["shard_sim_check"] = (f"share 0 (timed context) + {G - 1} untimed shares on this GPU, put together by "
+                                     + ("psm_gather_rows_ctx" if rows_mode else "psm_disp_merge_ctx"))
         de.set_option(capi.PSM_OPT_ASYNC, 1)
 
     # ---- post-processing stages on the finished maps (PP::processDM: lrCheck, fillInv, wgtMedian; src/PP.cpp:405-410) ----
@@ -643,8 +728,8 @@ def main():
             a = measure(other, args.exchange or "allgather")
             alt = {"shard": other, "exchange": a["exchange"], "ms_per_step": a["ms_per_step"], "value": a["value"],
                    "median_ms_per_step": a["median_ms_per_step"], "filter_launches": a["filter_launches"],
-                   "parallelism": (f"D sharded over {world} ranks + 1 RCCL {a['exchange']} of packed minima per frame" if other == "disp"
-                                   else f"{world} row stripes + 1 RCCL all_gather of the map rows per frame"),
+                   "parallelism": (f"D sharded over {world} ranks + 1 {xname} {a['exchange']} of packed minima per frame" if other == "disp"
+                                   else f"{world} row stripes + 1 {xname} all_gather of the map rows per frame"),
                    "note": ("the configuration BASELINE configs[3] / the north star name (D slices sharded, one all-gather of per-pixel minima); "
                             "same maps as the headline axis" if other == "disp" else "row stripes; same maps as the headline axis")}
             if rank == 0:
@@ -662,15 +747,20 @@ def main():
             "data": "synthetic",
             "config": {"workload": desc, "W": W, "H": H, "D": D, "voxels_per_step": voxels_per_step,
                        "parallelism": "1 GPU" if world == 1 and not use_dist else
-                                      (f"{world} row stripes of {geo['rows_max']} rows (all {D} slices each) + 1 RCCL all_gather of the map rows per frame"
-                                       if rows_mode else f"D sharded over {world} ranks + 1 RCCL {exchange} of packed minima"),
+                                      (f"{world} row stripes of {geo['rows_max']} rows (all {D} slices each) + 1 {xname} all_gather of the map rows per frame"
+                                       if rows_mode else f"D sharded over {world} ranks + 1 {xname} {exchange} of packed minima"),
                        "kernel_variant": args.variant, "shard_sim": args.shard_sim, "lr_check_on_gpu": bool(lrc),
-                       "shard": head["shard"]},
+                       "shard": head["shard"], "ranks": world, "same_device": bool(args.same_device),
+                       "exchange_backend": (backend if use_dist else None)},
             "roofline": roofline, "cpu_baseline": cpu, "kernels": kern,
             "kernels_sum_ms_per_step": round(kernels_sum, 4), "kernels_sum_le_step": bool(kernels_sum <= ms_per_step * 1.005),
             "median_ms_per_step": head["median_ms_per_step"], "pcie": pcie,
         }
         out.update(checks)
+        if args.same_device and use_dist:
+            out["same_device_note"] = (f"{world} ranks share GPU 0: the N > 1 protocol (alternating buffers, pending exchange, gather / merge at world "
+                                       f"{world}) run for correctness - value is NOT a scaling measurement"
+                                       + (f"; {args.backend_note}" if args.backend_note else ""))
         if alt:
             out["alt_shard"] = alt
         if pp:

@@ -362,7 +362,7 @@ int filter_both(psm_ctx *c)
         // The reduction of the planes is the last thing that touches the keys: when the context holds every slice it writes the
         // maps (the low byte of each key) in the same pass, and psm_disp_select has no kernel left to launch.
         uint8_t *const early = c->Dloc == c->D ? c->maps : nullptr;
-        if (early && c->ev_down) PSM_HIP(c, hipStreamWaitEvent(c->stream, c->ev_down, 0));   // (still the source of the last frame's download?)
+        if (early && maps_writable(c)) return 1;   // (still the source of the last frame's download?)
         Prof p(c, PSM_K_WTA);
         launch_chunk_min2sides(c->stream, c->march, c->W, c->H, c->Dloc, c->gf_scratch, c->keys_cur, early);
         c->maps_early = early;

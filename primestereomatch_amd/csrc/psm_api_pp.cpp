@@ -29,7 +29,7 @@ int psm_fill_invalid(psm_ctx *c, uint8_t *lmap, uint8_t *rmap, size_t stride)
 {
     if (!c) return 1;
     if (!c->have_maps || !c->have_valid) return fail(c, "psm_fill_invalid: needs disparity maps and psm_lr_check");
-    if (bind(c)) return 1;
+    if (bind(c) || maps_writable(c)) return 1;
     const double t0 = now_us();
     const size_t HW = (size_t)c->W * c->H;
     {
@@ -78,7 +78,7 @@ int psm_wgt_median(psm_ctx *c, uint8_t *lmap, uint8_t *rmap, size_t stride)
     if (!c->have_maps || !c->have_valid) return fail(c, "psm_wgt_median: needs disparity maps and psm_lr_check");
     if (!c->have_images) return fail(c, "psm_wgt_median: no image pair uploaded (colour weights)");
     if (c->W < 9 || c->H < 9) return fail(c, "psm_wgt_median: image %dx%d smaller than the 19x19 window's wrap allows", c->W, c->H);
-    if (bind(c)) return 1;
+    if (bind(c) || maps_writable(c)) return 1;
     const double t0 = now_us();
     if (!c->have_g1 && run_prep(c)) return 1;
     const size_t HW = (size_t)c->W * c->H;
@@ -109,7 +109,13 @@ int psm_wgt_median(psm_ctx *c, uint8_t *lmap, uint8_t *rmap, size_t stride)
         // WM_CACHE_MAX bytes for the pair the evaluations form their weights themselves, as they do for short lists).
         float *wts[2] = {nullptr, nullptr};
         {
-            constexpr size_t WM_CACHE_MAX = (size_t)12 << 30;
+            // at most 12 GB, and never more than half of what the device has free right now: the volumes, the spare volume and
+            // the FGF scratch of this or another context on the device are allocated on first use and must still fit
+            size_t WM_CACHE_MAX = (size_t)12 << 30, mem_free = 0, mem_total = 0;
+            if (hipMemGetInfo(&mem_free, &mem_total) == hipSuccess) {
+                const size_t avail = mem_free + c->wm_wts_n * sizeof(float);     // (what we hold already counts as available to us)
+                if (avail / 2 < WM_CACHE_MAX) WM_CACHE_MAX = avail / 2;
+            } else (void)hipGetLastError();
             int n0[2];
             for (int s = 0; s < 2; ++s) PSM_HIP(c, hipMemcpyAsync(&n0[s], cnt[s], sizeof(int), hipMemcpyDeviceToHost, c->stream));
             PSM_HIP(c, hipStreamSynchronize(c->stream));
@@ -192,7 +198,7 @@ int psm_upload_maps(psm_ctx *c, const uint8_t *lmap, const uint8_t *rmap, const 
     if (!c) return 1;
     if (stride == 0) stride = c->W;
     if (stride < (size_t)c->W) return fail(c, "psm_upload_maps: stride %zu < width %d", stride, c->W);
-    if (bind(c)) return 1;
+    if (bind(c) || maps_writable(c)) return 1;
     c->maps_early = nullptr;
     const size_t HW = (size_t)c->W * c->H;
     const uint8_t *src[4] = {lmap, rmap, lvalid, rvalid};

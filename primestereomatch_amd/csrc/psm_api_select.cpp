@@ -73,7 +73,7 @@ int wta_launch(psm_ctx *c, long long *keys, uint8_t *maps)
 {
     const size_t HW = (size_t)c->W * c->H;
     // the map buffer may still be the source of an asynchronous download of the previous frame
-    if (maps && c->ev_down) PSM_HIP(c, hipStreamWaitEvent(c->stream, c->ev_down, 0));
+    if (maps && maps_writable(c)) return 1;
     // a side that is not the select filter's packed minima was selected from a whole volume: its map is whole
     if (!(c->gf_virtual[0] && c->gf_virtual[1])) { c->have_rows = false; c->rows_y0 = 0; c->rows_y1 = c->H; }
     if (c->gf_virtual[0] && c->gf_virtual[1] && !keys && maps) {   // both sides already reduced to keys: one launch for both maps
@@ -199,7 +199,7 @@ int psm_gather_rows_ctx(psm_ctx *root, psm_ctx *const *stripes, int nstripes, ui
     }
     for (int y = 0; y < root->H; ++y)
         if (!covered[y]) return fail(root, "psm_gather_rows_ctx: no stripe holds row %d", y);
-    if (bind(root)) return 1;
+    if (bind(root) || maps_writable(root)) return 1;
     const size_t HW = (size_t)root->W * root->H;
     for (int i = 0; i < nstripes; ++i) {
         psm_ctx *s = stripes[i];
@@ -250,7 +250,7 @@ int psm_disp_merge(psm_ctx *c, const void *dev_keys_all, int nranks, uint8_t *lm
     if (bind(c)) return 1;
     const double t0 = now_us();
     const size_t n = 2 * (size_t)c->W * c->H;
-    if (c->ev_down) PSM_HIP(c, hipStreamWaitEvent(c->stream, c->ev_down, 0));
+    if (maps_writable(c)) return 1;
     {
         Prof p(c, PSM_K_MERGE);
         launch_merge(c->stream, (const long long *)dev_keys_all, n, nranks, (int)n, c->maps);

@@ -122,6 +122,13 @@ int end_stage(psm_ctx *c, int stage, double t0);
 int bind(psm_ctx *c);
 void adopt_new_pair(psm_ctx *c, int depth);   // a new image pair is current: nothing derived from the previous one survives
 inline size_t velem(const psm_ctx *c) { return c->dtype == PSM_U8 ? 1 : 4; }
+// Call before anything on c->stream writes c->maps: the buffer may still be the source of an asynchronous download
+// (psm_download_maps_async on the copy stream) - the writer waits for that copy on the device, the host never blocks.
+inline int maps_writable(psm_ctx *c)
+{
+    if (c->ev_down) PSM_HIP(c, hipStreamWaitEvent(c->stream, c->ev_down, 0));
+    return 0;
+}
 
 // RAII bracket of one kernel launch with hipEvents on the launch stream (PSM_OPT_PROFILE 1)
 struct Prof {

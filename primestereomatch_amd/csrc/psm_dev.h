@@ -1,4 +1,4 @@
-// psm_dev.h - device helpers shared by the marching kernels (psm_kernels.hip, psm_pc2.hip): REFLECT_101 indexing,
+// psm_dev.h - device helpers shared by the marching kernels (psm_kernels.hip, psm_pc.hip): REFLECT_101 indexing,
 // cross-lane exchanges, the sliding fp64 trees of the 8-tap box filter, the per-voxel model solve.
 #pragma once
 #include <hip/hip_runtime.h>

@@ -1,5 +1,5 @@
-// psm_kernels.h - launcher interface between the C-ABI layer (psm_api.cpp) and the gfx950
-// kernels (psm_kernels.hip).  Internal to libprimesm_hip.so.
+// psm_kernels.h - launcher interface between the C-ABI layer (psm_api_*.cpp) and the gfx950
+// kernels (psm_kernels.hip, psm_pc.hip, psm_fgf.hip, psm_pp.hip).  Internal to libprimesm_hip.so.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>

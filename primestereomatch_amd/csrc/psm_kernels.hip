@@ -17,7 +17,7 @@
 // one kernel, producer and consumer waves coupled through an LDS ring, so a voxel costs one 4-byte store
 // and no volume read.  The two-stage kernels (k_cvc_t, k_cvf_a, k_cvf_b), the plain box filter (k_box8) and
 // the direct per-voxel kernels are the fallback / diagnostic / cross-check forms of the same arithmetic.
-// The Fast Guided Filter row lives in psm_fgf.hip, the two-columns-per-lane experiment in psm_pc2.hip.
+// The Fast Guided Filter row lives in psm_fgf.hip, the fused product kernel in psm_pc.hip, post-processing in psm_pp.hip.
 // MFMA is not used: nothing here is a dense contraction.
 #include "psm_kernels.h"
 #include "psm_cost.h"

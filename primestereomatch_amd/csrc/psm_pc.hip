@@ -38,6 +38,7 @@
 #include "psm_dev.h"
 
 #include <cstdlib>
+#include <mutex>
 
 #ifndef PSM_PC_TIMING
 #define PSM_PC_TIMING 0   // 1: every wave accumulates its cycles between barriers (work) and inside them (wait) per role
@@ -674,8 +675,10 @@ __global__ __launch_bounds__(256) void k_fill_keys(long long *__restrict__ keys,
 PcDev pc_dev()
 {
     static PcDev cache[64];
+    static std::mutex mu;                        // hosts drive one context per thread / GPU: first use may be concurrent
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    std::lock_guard<std::mutex> lock(mu);
     PcDev &d = cache[dev];
     if (d.nxcd == 0) {
         int nx = 0, cus = 0;

@@ -124,3 +124,76 @@ def test_stripe_bounds_tile_the_image():
                 assert 0 <= y0 <= y1 <= H and y1 - y0 <= R and (y0 == g * R or y0 == H)
                 rows += list(range(y0, y1))
             assert rows == list(range(H))
+
+
+def _exchange_worker(rank, world, port, q):
+    """primestereomatch_amd.exchange.Exchange over gloo, CPU tensors standing in for device tensors: the frame-pipelined
+    protocol of bench.py (two alternating key tensors, the collective of frame i finished inside step i+1) for both
+    exchanges, against the unsharded result."""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from primestereomatch_amd import stripes
+        from primestereomatch_amd.exchange import Exchange
+        ex = Exchange(torch, dist, "gloo")
+        H, W, frames = 10, 7, 5
+        n = 2 * H * W
+        ok = True
+        # ---- disparity shards: per frame a key tensor per rank; the minimum over ranks one step later ----
+        rng = np.random.default_rng(5)
+        allkeys = rng.integers(-2**40, 2**40, size=(frames, world, n), dtype=np.int64)    # every rank knows all (to check)
+        kbuf = [torch.empty(n, dtype=torch.int64) for _ in range(2)]
+        pending, got = [], []
+        for f in range(frames):
+            kb = kbuf[f & 1]
+            kb.copy_(torch.from_numpy(allkeys[f, rank]))
+            while pending:                                  # finish_pending(): frame f-1's collective -> its result
+                w, b = pending.pop(0)
+                w.wait()
+                got.append(b.clone().numpy())
+            pending.append((ex.all_reduce_min(kb, async_op=True), kb))
+        w, b = pending.pop(0); w.wait(); got.append(b.clone().numpy())
+        ok &= all(np.array_equal(got[f], allkeys[f].min(axis=0)) for f in range(frames))
+        gat = torch.empty(world * n, dtype=torch.int64)
+        ex.all_gather(gat, torch.from_numpy(allkeys[0, rank].copy()))
+        ok &= bool(np.array_equal(gat.view(world, n).numpy(), allkeys[0]))
+        # ---- row stripes: the finished rows of both maps, gathered asynchronously, assembled one step later ----
+        full = rng.integers(0, 256, size=(frames, 2, H, W), dtype=np.uint8)
+        R, y0, y1 = stripes.stripe_bounds(H, world, rank)
+        mbuf = [torch.zeros(n + 4, dtype=torch.uint8) for _ in range(2)]
+        send, recv = torch.zeros(2 * R * W, dtype=torch.uint8), torch.zeros(world * 2 * R * W, dtype=torch.uint8)
+        pending, maps = [], []
+        for f in range(frames):
+            mb = mbuf[f & 1]
+            mb.fill_(255)
+            mb[:n].view(2, H, W)[:, y0:y1] = torch.from_numpy(full[f][:, y0:y1].copy())
+            while pending:
+                w, b = pending.pop(0)
+                w.wait()
+                stripes.assemble(recv, world, H, W, R, b)
+                maps.append(b[:n].clone().numpy().reshape(2, H, W))
+            stripes.pack_stripe(mb, y0, y1, send, H, W, R)
+            pending.append((ex.all_gather(recv, send, async_op=True), mb))
+        w, b = pending.pop(0); w.wait(); stripes.assemble(recv, world, H, W, R, b); maps.append(b[:n].clone().numpy().reshape(2, H, W))
+        ok &= all(np.array_equal(maps[f], full[f]) for f in range(frames))
+        ok &= ex.max_float(float(rank)) == float(world - 1) and ex.collectives == 2 * frames + 1
+        ex.barrier()
+        q.put((rank, bool(ok)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_staged_exchange_frame_pipeline(world):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_exchange_worker, args=(r, world, 29850 + world, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+    assert all(res[r] for r in range(world)), res

@@ -212,3 +212,29 @@ def test_scaled_sums_domain(psm, oracle, k):
         de.DispSelect_GPU()
         assert np.array_equal(de.lDisMap, oracle.wta(q[0])) and np.array_equal(de.rDisMap, oracle.wta(q[1]))
         assert np.array_equal(de.download_volume(0), q[0]) and np.array_equal(de.download_volume(1), q[1])
+
+
+def test_async_download_is_not_raced_by_later_map_writers(psm, oracle):
+    """Round-3 advisor finding: psm_download_maps_async promises the maps as they were when it was called; every later entry
+    that rewrites the device maps in place (fillInv, wgtMedian, psm_upload_maps, a gather / merge into them) must wait for that
+    copy on the device.  A large pair makes the D2H long enough for the race to show without the wait."""
+    from primestereomatch_amd import synth
+    W, H, D = 1920, 1080, 16
+    l, r, _ = synth.make_pair(W, H, D, seed=3)
+    with psm.DispEst(l, r, D) as de:
+        de.CostConst_GPU(); de.CostFilter_GPU(); de.DispSelect_GPU()
+        raw = [de.lDisMap.copy(), de.rDisMap.copy()]
+        de.LRCheck_GPU()
+        for writer in ("fill", "median", "upload"):
+            de.upload_maps(raw[0], raw[1], de.lValid, de.rValid)
+            de.download_maps_async()
+            if writer == "fill":
+                de._ck(de._lib.psm_fill_invalid(de._h, None, None, 0), "fill")
+            elif writer == "median":
+                de._ck(de._lib.psm_wgt_median(de._h, None, None, 0), "wmf")
+            else:
+                de.upload_maps(np.zeros_like(raw[0]), np.zeros_like(raw[1]))
+            lm, rm = de.download_maps_wait()
+            assert np.array_equal(lm, raw[0]) and np.array_equal(rm, raw[1]), writer
+            after = [m.copy() for m in de.download_maps()]
+            assert not (np.array_equal(after[0], raw[0]) and np.array_equal(after[1], raw[1])), writer   # the writer did run

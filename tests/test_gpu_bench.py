@@ -60,14 +60,29 @@ def test_distributed_path_world1_verified(shard, exchange, extra):
     assert a["shard"] == ("disp" if shard == "rows" else "rows") and a["verified_vs_single_gpu"] is True and a["ms_per_step"] > 0
 
 
-@pytest.mark.parametrize("shard", ["rows", "disp"])
-def test_distributed_path_world2_rccl_when_two_gpus(shard):
+@pytest.mark.parametrize("shard,extra", [("rows", ()), ("disp", ()), ("rows", ("--no-frame-pipeline",)), ("disp", ("--exchange", "allgather"))])
+def test_distributed_path_world2(shard, extra):
+    """bench.py's real step() at world size 2, both axes per invocation, frame-pipelined and not: on two GPUs over RCCL when
+    the box has them; on a one-GPU box both ranks share device 0 (--same-device; RCCL is tried first and, when it refuses the
+    duplicate device, the same collectives are staged through host memory over gloo behind the same pending / finish_pending /
+    alternating-buffer code).  Everything that only exists at world >= 2 runs here: stripes.assemble on gathered tensors,
+    DispSelect_merge(world = 2) on a real all-gather result, set_map_buffer(whole) / set_key_buffer alternation."""
     from primestereomatch_amd import capi
-    if capi.device_count() < 2:
-        pytest.skip("needs 2 GPUs (the driver's multi-GPU bench covers N > 1 on an 8-GPU node)")
-    j = _bench("--gpus", "2", "--shard", shard, "--config", "c3", "--steps", "3", "--warmup", "1", "--no-cpu-baseline")   # bare command: self-launch
-    assert j["n_gpus"] == 2 and j["verified_vs_single_gpu"] is True and j["oracle_maps_equal"] is True
-    assert j["alt_shard"]["verified_vs_single_gpu"] is True and j["alt_shard"]["oracle_maps_equal"] is True
+    same = () if capi.device_count() >= 2 else ("--same-device",)
+    j = _bench("--gpus", "2", "--shard", shard, "--config", "c3", "--steps", "4", "--warmup", "2", *same, *extra, timeout=900)   # bare command: self-launch
+    assert j["n_gpus"] == 2 and j["config"]["ranks"] == 2 and j["config"]["shard"] == shard
+    assert j["verified_vs_single_gpu"] is True and j["oracle_maps_equal"] is True
+    a = j["alt_shard"]
+    assert a["shard"] != shard and a["verified_vs_single_gpu"] is True and a["oracle_maps_equal"] is True
+    assert j["config"]["exchange_backend"] in ("nccl", "gloo") and j["config"]["same_device"] is bool(same)
+
+
+def test_shard_sim_lines_are_verified():
+    """--shard-sim G: the timed share + the other G - 1 shares (untimed) put together by the library's single-process exchange
+    equal the unsharded maps and the oracle's."""
+    for shard in ("rows", "disp"):
+        j = _bench("--shard-sim", "4", "--shard", shard, "--config", "c3", "--steps", "3", "--warmup", "1")
+        assert j["verified_vs_single_gpu"] is True and j["oracle_maps_equal"] is True, shard
 
 
 @pytest.mark.parametrize("parts", [2, 8])
