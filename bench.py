@@ -82,9 +82,13 @@ def spawn_ranks(n, args):
         rc, err = run(["--backend", "nccl", "--nccl-probe"], timeout=120)
         if rc == 0:
             return run(["--backend", "nccl"])[0]
-        why = [ln.strip() for ln in (err or "").splitlines() if "rror" in ln or "uplicate" in ln or "NCCL WARN" in ln]
-        why = (why[-1] if why else str(err or "").strip().splitlines()[-1:] or ["rc %d" % rc])
-        why = why if isinstance(why, str) else why[0]
+        lines = [ln.strip() for ln in (err or "").splitlines() if ln.strip()]
+        why = "rc %d" % rc
+        for pat in ("uplicate GPU", "ncclInvalid", "NCCL error", "NCCL WARN", "DistBackendError", "HIP error", "Error"):
+            hit = [ln for ln in lines if pat in ln and "traceback" not in ln]
+            if hit:
+                why = hit[-1]
+                break
         print("bench.py: RCCL with %d ranks on one device failed (%s) - staging the exchange over gloo" % (n, why[:200]), file=sys.stderr)
         return run(["--backend", "gloo", "--backend-note", "RCCL refused %d ranks on one device: %s" % (n, why[:200])])[0]
     return run([])[0]
@@ -595,6 +599,11 @@ def main():
         tcpu = time.perf_counter() - tcpu
         if sd == D:
             oracle_maps = [res["ldisp"], res["rdisp"]]
+        elif dtype == "f32" and not args.no_oracle_check:
+            # (larger than 1080p x 256: the timed cpu_baseline is a sample of the disparities; the maps come from the oracle's
+            # streaming form - same jobs and arithmetic, no volumes held - on up to 32 threads, outside every timed region)
+            rs = O.pipeline_f32_maps(l, r, D, threads=min(32, cores))
+            oracle_maps = [rs["ldisp"], rs["rdisp"]]
         if world == 1 and not sim:
             stage_s = (res["cvc_ms"] + res["cvf_ms"] + res["dispsel_ms"]) * 1e-3
             cpu = {"value": round(2.0 * W * H * sd / stage_s, 1), "unit": "voxels/s", "cores": threads,

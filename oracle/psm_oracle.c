@@ -750,6 +750,95 @@ done:
     return rc;
 }
 
+/* ---- the same pipeline, maps only, without holding the volumes ----
+ * psmo_pipeline_f32 keeps both [D][H][W] float volumes (17 GB at 3840 x 2160 x 256).  The checker of the largest
+ * configuration only needs the two maps: here every block of `threads` disparities is built, filtered (the same
+ * buildCV_thread / filterCV_thread jobs on the same arithmetic) and folded into the running DispSel::CVSelect minimum in
+ * ascending d with strict '<' (src/DispSel.cpp:96-104: identical to the loop over a stored volume), then its slices are
+ * reused.  Memory: threads x (1 + 9 + 2) planes.  Test infrastructure like the rest of this file. */
+typedef struct {
+    const float *slices;   /* [nd][H][W], disparities d0 .. d0+nd-1 */
+    int d0, nd, W, y0, y1;
+    size_t N;
+    float *minCost;
+    uint8_t *disp;
+} fold_TD;
+
+static void *fold_rows_thread(void *arg)
+{
+    fold_TD *t = (fold_TD *)arg;
+    for (int y = t->y0; y < t->y1; ++y)
+        for (int x = 0; x < t->W; ++x) {
+            const size_t i = (size_t)y * t->W + x;
+            float m = t->minCost[i];
+            int k = t->disp[i];
+            for (int j = 0; j < t->nd; ++j) {
+                const int d = t->d0 + j;
+                if (d == 0) continue;                    /* the loop of src/DispSel.cpp:96 starts at d = 1 */
+                const float c = t->slices[(size_t)j * t->N + i];
+                if (c < m) { m = c; k = d; }
+            }
+            t->minCost[i] = m;
+            t->disp[i] = (uint8_t)k;
+        }
+    return NULL;
+}
+
+int psmo_pipeline_f32_maps(const uint8_t *l_bgr, const uint8_t *r_bgr, int H, int W, int D, int threads,
+                           uint8_t *ldisp, uint8_t *rdisp)
+{
+    if (!l_bgr || !r_bgr || !ldisp || !rdisp || H < 8 || W < 8 || D < 1 || D > 256 || threads < 1) return -1;
+    if (threads > PSMO_MAX_CPU_THREADS * 32) threads = PSMO_MAX_CPU_THREADS * 32;
+    const size_t N = (size_t)H * W;
+    int rc = -1;
+    float *lImg = (float *)malloc(N * 3 * sizeof(float)), *rImg = (float *)malloc(N * 3 * sizeof(float));
+    float *lG = (float *)malloc(N * sizeof(float)), *rG = (float *)malloc(N * sizeof(float));
+    float *blk = (float *)malloc((size_t)threads * N * sizeof(float));
+    float *minCost = (float *)malloc(N * sizeof(float));
+    float *guide = (float *)malloc(12 * N * sizeof(float));
+    float *ws = (float *)malloc((size_t)threads * 9 * N * sizeof(float));
+    double *hs = (double *)malloc((size_t)threads * N * sizeof(double));
+    job *jobs = (job *)malloc((size_t)threads * sizeof(job));
+    buildCV_TD *btd = (buildCV_TD *)malloc((size_t)threads * sizeof(buildCV_TD));
+    filterCV_TD *ftd = (filterCV_TD *)malloc((size_t)threads * sizeof(filterCV_TD));
+    fold_TD *wtd = (fold_TD *)malloc((size_t)threads * sizeof(fold_TD));
+    pthread_t *tid = (pthread_t *)malloc((size_t)threads * sizeof(pthread_t));
+    if (!lImg || !rImg || !lG || !rG || !blk || !minCost || !guide || !ws || !hs || !jobs || !btd || !ftd || !wtd || !tid) goto done;
+    psmo_u8_to_f32(l_bgr, N * 3, lImg);
+    psmo_u8_to_f32(r_bgr, N * 3, rImg);
+    psmo_cvc_preprocess(lImg, H, W, lG);
+    psmo_cvc_preprocess(rImg, H, W, rG);
+    for (int side = 0; side < 2; ++side) {
+        uint8_t *disp = side ? rdisp : ldisp;
+        psmo_cvf_preprocess(side ? rImg : lImg, H, W, guide, guide + 3 * N, guide + 6 * N);
+        for (size_t i = 0; i < N; ++i) { minCost[i] = INFINITY; disp[i] = 0; }
+        for (int d0 = 0; d0 < D; d0 += threads) {
+            const int nd = D - d0 < threads ? D - d0 : threads;
+            for (int j = 0; j < nd; ++j) {
+                btd[j] = side ? (buildCV_TD){rImg, lImg, rG, lG, H, W, d0 + j, 1, blk + (size_t)j * N}
+                              : (buildCV_TD){lImg, rImg, lG, rG, H, W, d0 + j, 0, blk + (size_t)j * N};
+                jobs[j] = (job){buildCV_thread, &btd[j]};
+            }
+            run_blocked(jobs, nd, threads);
+            for (int j = 0; j < nd; ++j) {
+                ftd[j] = (filterCV_TD){guide, guide + 3 * N, guide + 6 * N, H, W, blk + (size_t)j * N, ws + (size_t)j * 9 * N, hs + (size_t)j * N};
+                jobs[j] = (job){filterCV_thread, &ftd[j]};
+            }
+            run_blocked(jobs, nd, threads);
+            for (int t = 0; t < threads; ++t) {
+                wtd[t] = (fold_TD){blk, d0, nd, W, (int)((long)H * t / threads), (int)((long)H * (t + 1) / threads), N, minCost, disp};
+                pthread_create(&tid[t], NULL, fold_rows_thread, &wtd[t]);
+            }
+            for (int t = 0; t < threads; ++t) pthread_join(tid[t], NULL);
+        }
+    }
+    rc = 0;
+done:
+    free(lImg); free(rImg); free(lG); free(rG); free(blk); free(minCost); free(guide); free(ws); free(hs);
+    free(jobs); free(btd); free(ftd); free(wtd); free(tid);
+    return rc;
+}
+
 typedef struct {
     const float *img, *setup;
     int H, W, s;

@@ -132,6 +132,12 @@ int psmo_pipeline_f32(const uint8_t *l_bgr, const uint8_t *r_bgr, int H, int W, 
                       uint8_t *ldisp, uint8_t *rdisp, float *lvol, float *rvol, float *raw_l,
                       float *raw_r, psmo_times *times);
 
+/* The same pipeline, maps only, without holding the two [D][H][W] volumes (17 GB at 3840 x 2160 x 256): blocks of `threads`
+ * disparities are built, filtered and folded into the running DispSel::CVSelect minimum (ascending d, strict '<',
+ * src/DispSel.cpp:96-104), so the maps are those of psmo_pipeline_f32 bit for bit. */
+int psmo_pipeline_f32_maps(const uint8_t *l_bgr, const uint8_t *r_bgr, int H, int W, int D, int threads,
+                           uint8_t *ldisp, uint8_t *rdisp);
+
 /* CostConst() -> CostFilter_FGF() -> DispSelect_CPU(): the snapshot's live CPU branch
  * (src/StereoMatch.cpp:207-224), s = subsample_rate in {2,4,8}. */
 int psmo_pipeline_fgf(const uint8_t *l_bgr, const uint8_t *r_bgr, int H, int W, int D, int threads, int s,

@@ -146,6 +146,20 @@ def pipeline_f32(l_bgr, r_bgr, D, threads=8, want_volumes=False, want_raw=False)
     return out
 
 
+def pipeline_f32_maps(l_bgr, r_bgr, D, threads=8):
+    """The two maps of pipeline_f32 without holding the volumes (blocks of `threads` slices folded into the running WTA)."""
+    l, r = _u8(l_bgr), _u8(r_bgr)
+    H, W, _ = l.shape
+    ld = np.empty((H, W), np.uint8)
+    rd = np.empty((H, W), np.uint8)
+    fn = lib().psmo_pipeline_f32_maps
+    fn.restype = C.c_int
+    rc = fn(_p(l), _p(r), H, W, int(D), int(threads), _p(ld), _p(rd))
+    if rc != 0:
+        raise ValueError("psmo_pipeline_f32_maps rejected the arguments (rc=%d)" % rc)
+    return {"ldisp": ld, "rdisp": rd}
+
+
 def gray_grad_u8(img_u8):
     img = _u8(img_u8)
     H, W, _ = img.shape

@@ -96,6 +96,61 @@ def test_4k_two_phase_maps_equal_oracle(psm, oracle):
         assert np.array_equal(de.lValid, lv) and np.array_equal(de.rValid, rv)
 
 
+_REF4K = {}
+
+
+def oracle_maps_4k(oracle):
+    """3840 x 2160 x 256 (BASELINE configs[4] as written): the streaming form of the oracle (psmo_pipeline_f32_maps - same
+    jobs, same arithmetic, blocks of `threads` slices folded into the running WTA instead of two 8.5 GB volumes)."""
+    if not _REF4K:
+        from primestereomatch_amd import synth
+        W, H, D = 3840, 2160, 256
+        l, r, _ = synth.make_pair(W, H, D, seed=0)
+        ref = oracle.pipeline_f32_maps(l, r, D, threads=min(32, THREADS))
+        _REF4K["v"] = (l, r, ref["ldisp"], ref["rdisp"])
+    return _REF4K["v"]
+
+
+def test_4k_full_range_maps_equal_oracle(psm, oracle):
+    """configs[4] end to end: the one geometry where the minima planes leave the L2s and the planner picks seed stride 4 -
+    both maps over the whole image and all 256 disparities, + the L-R check the config names, two frames."""
+    W, H, D = 3840, 2160, 256
+    l, r, el, er = oracle_maps_4k(oracle)
+    with psm.DispEst(l, r, D) as de:
+        for _ in range(2):
+            de.CostConst_GPU(); de.CostFilter_GPU(); de.DispSelect_GPU()
+            assert (mism(de.lDisMap, el), mism(de.rDisMap, er)) == (0, 0)
+        de.LRCheck_GPU()
+        lv, rv = oracle.lr_check(el, er)
+        assert np.array_equal(de.lValid, lv) and np.array_equal(de.rValid, rv)
+
+
+def test_4k_full_range_eight_stripes_and_eight_shards_equal_oracle(psm, oracle):
+    from primestereomatch_amd import stripes
+    W, H, D = 3840, 2160, 256
+    l, r, el, er = oracle_maps_4k(oracle)
+    ctxs = [psm.DispEst(l, r, D) for _ in range(8)]
+    try:
+        for g, c in enumerate(ctxs):
+            _, y0, y1 = stripes.stripe_bounds(H, 8, g)
+            c.set_rows(y0, y1)
+            c.CostConst_GPU(); c.CostFilter_GPU(); c.DispSelect_GPU()
+        ctxs[0].gather_rows_ctx(ctxs)
+        assert (mism(ctxs[0].lDisMap, el), mism(ctxs[0].rDisMap, er)) == (0, 0)
+    finally:
+        for c in ctxs:
+            c.close()
+    shards = [psm.DispEst(l, r, D, d_range=(D * g // 8, D * (g + 1) // 8)) for g in range(8)]
+    try:
+        for s in shards:
+            s.CostConst_GPU(); s.CostFilter_GPU(); s.DispSelect_partial()
+        shards[0].DispSelect_merge_ctx(shards)
+        assert (mism(shards[0].lDisMap, el), mism(shards[0].rDisMap, er)) == (0, 0)
+    finally:
+        for s in shards:
+            s.close()
+
+
 def test_u8_mode_on_the_384x288_cones_crop(psm, oracle, golden):
     """BASELINE configs[0]: Middlebury Cones, 384x288, D=64, 8-bit char mode - bit-exact against oracle.pipeline_u8."""
     g = golden("cones_pair.npz")
