@@ -135,6 +135,12 @@ def parse_args():
                          "(default: a frame's collective overlaps the next frame's filter; two buffers)")
     ap.add_argument("--verify", action="store_true",
                     help="N=1: also compare the maps of the timed path with a fresh single-context run (always done for N>1)")
+    ap.add_argument("--batch", type=int, default=1,
+                    help="N = 1: B different stereo pairs of the configuration per step through ONE set of launches (psm_compute_batch: the "
+                         "reference's loop over pairs / datasets, src/main.cpp:64-73); value counts the voxels of all B pairs")
+    ap.add_argument("--graph", action="store_true",
+                    help="with --batch: the launches of a step replayed as one hipGraph (PSM_OPT_GRAPH); the fused kernel's in-region "
+                         "time stamps are off then (they need a slot per launch), its time comes from the separate event pass")
     ap.add_argument("--same-device", action="store_true",
                     help="N > 1: every rank uses GPU 0 - the N > 1 protocol (two buffers, pending exchange, gather / merge at world N) "
                          "on a box with one GPU; a correctness run, not a scaling measurement")
@@ -205,6 +211,7 @@ def main():
     import numpy as np
     import primestereomatch_amd as P
     from primestereomatch_amd import capi, stripes, synth
+    from primestereomatch_amd.dispest import compute_batch
 
     W, H, D, desc = CONFIGS[args.config]
     dtype = args.dtype or ("u8" if args.config.startswith("c1") else "f32")
@@ -212,7 +219,10 @@ def main():
     if dtype == "u8" and not args.config.startswith("c1"):
         desc = desc.replace("float32", "8-bit char mode")
     l, r, _ = synth.make_pair(W, H, D, seed=0)
-    voxels_per_step = 2.0 * W * H * D           # both volumes, all ranks
+    use_batch = (args.batch > 1 or args.batch == -1) and N == 1 and not args.force_dist and args.shard_sim <= 1 and not args.fgf
+    B = abs(args.batch) if use_batch else 1      # (--batch -1: ONE pair through the batch entry - one call instead of three)
+    batch_pairs = [(l, r)] + [synth.make_pair(W, H, D, seed=b)[:2] for b in range(1, B)]    # B different pairs
+    voxels_per_step = 2.0 * W * H * D * B       # both volumes, all ranks, all pairs of a batch
     # BASELINE configs[4]: "+ PP left-right check on-GPU" - lrCheck (src/PP.cpp:17-50) on the finished maps, part of the step
     lrc = (args.lr_check == 1 or (args.lr_check < 0 and args.config == "c5")) and not (args.shard_sim > 1)
     side_stream = None
@@ -260,6 +270,14 @@ def main():
         if args.flags >= 0:
             de.set_option(capi.PSM_OPT_FLAGS, args.flags)
         de.set_option(capi.PSM_OPT_ASYNC, 1)
+        batch_all = [de]
+        for pl_, pr_ in batch_pairs[1:]:
+            o_ = P.DispEst(pl_, pr_, D, 8, True, device=dev_index, dtype=dtype)
+            if args.seg_rows >= 0:
+                o_.set_option(capi.PSM_OPT_SEG_ROWS, args.seg_rows)
+            if args.flags >= 0:
+                o_.set_option(capi.PSM_OPT_FLAGS, args.flags)
+            batch_all.append(o_)
         if rows_mode:
             de.set_rows(y0, y1)
         if args.fgf:
@@ -301,6 +319,9 @@ def main():
             return ex.all_gather(recv, send, async_op=async_op)      # the one exchange step (RCCL; or staged over gloo)
 
         def step():
+            if use_batch:                    # all B pairs: one prep, one guidance, one fused grid (blockIdx.z = pair), one reduction
+                compute_batch(batch_all)
+                return
             de.CostConst_GPU()
             if args.fgf:
                 de.CostFilter_FGF_GPU()
@@ -375,7 +396,10 @@ def main():
             step()
         # the fused filter kernel stamps its own start / end from here on: two atomics per workgroup, no events between the
         # kernels - the launches of the timed region itself are what roofline reports
-        de.set_option(capi.PSM_OPT_PROFILE, 2)
+        if args.graph and use_batch:
+            de.set_option(capi.PSM_OPT_GRAPH, 1)
+        else:
+            de.set_option(capi.PSM_OPT_PROFILE, 2)
         sync()
         de.filter_launch_times()
         sync(); barrier(); sync()
@@ -411,7 +435,7 @@ def main():
                                   for f, v in sorted(by_form.items())}
         rec["filter_ms_per_step"] = sum(ms for ms, _ in launch_times) / args.steps if launch_times else None
         rec["geometry"] = {"rows": [y0, y1], "slices": [d0, d1], "rows_max": rows_max, "parts": parts, "rows_mode": rows_mode}
-        rec["sync"], rec["step"], rec["de"] = sync, step, de
+        rec["sync"], rec["step"], rec["de"], rec["batch_all"] = sync, step, de, batch_all
         return rec
 
     def check_maps(rec, ref_maps, oracle_maps):
@@ -436,7 +460,7 @@ def main():
     # ================= headline measurement =================
     exchange = args.exchange or ("allreduce" if args.shard == "disp" else "allgather")
     head = measure(args.shard, exchange)
-    de, sync, step = head["de"], head["sync"], head["step"]
+    de, sync, step, batch_all = head["de"], head["sync"], head["step"], head["batch_all"]
     geo = head["geometry"]
     (y0, y1), (d0, d1), rows_mode = geo["rows"], geo["slices"], geo["rows_mode"]
     ms_per_step, value = head["ms_per_step"], head["value"]
@@ -463,7 +487,37 @@ def main():
         d2h = 1e3 * (time.perf_counter() - ts)
         pcie = {"h2d_ms": round(h2d, 3), "d2h_ms": round(d2h, 3), "h2d_bytes": int(l.nbytes + r.nbytes), "d2h_bytes": 2 * W * H,
                 "note": "u8 pair in, two u8 maps out; excluded from value"}
-        if not use_dist and args.frame_loop > 0 and not args.fgf:
+        if use_batch and args.frame_loop > 0:
+            # the batch as a frame loop: every frame's B pairs travel while the previous batch computes, its 2 B maps return
+            # while the next one computes (per-context psm_upload_pair_async / psm_download_maps_async around psm_compute_batch)
+            nf = args.frame_loop
+
+            def bframe(i, last):
+                compute_batch(batch_all)               # adopts the pairs staged during the previous frame
+                for o_, (pl_, pr_) in zip(batch_all, batch_pairs):
+                    if not last:
+                        o_.setInputImages_async(pl_, pr_)
+                    if i > 0:
+                        o_.download_maps_wait()
+                    o_.download_maps_async()
+
+            for i in range(3):
+                bframe(i, False)
+            for o_ in batch_all:
+                o_.download_maps_wait()
+            sync()
+            compute_batch(batch_all); sync()
+            ts = time.perf_counter()
+            for i in range(nf):
+                bframe(i, i + 1 == nf)
+            bl = [tuple(m.copy() for m in o_.download_maps_wait()) for o_ in batch_all]
+            sync()
+            loop_ms = 1e3 * (time.perf_counter() - ts) / nf
+            pcie["frame_loop"] = {"frames": nf, "pairs_per_frame": B, "ms_per_frame": round(loop_ms, 4), "over_step_ms": round(loop_ms - ms_per_step, 4),
+                                  "maps_equal_timed_path": bool(np.array_equal(bl[0][0], timed_maps[0]) and np.array_equal(bl[0][1], timed_maps[1])),
+                                  "note": "H2D of every frame's B pairs + D2H of its 2 B maps inside the loop, overlapped with the kernels"}
+            step(); sync()
+        elif not use_dist and args.frame_loop > 0 and not args.fgf:
             # the reference's use is a frame loop (src/main.cpp:64-73) whose stage timers include the copies: pair i+1
             # travels (psm_upload_pair_async) and the maps of frame i-1 return (psm_download_maps_async) while frame i computes
             nf = args.frame_loop
@@ -534,7 +588,7 @@ def main():
         algb["cvf_fgf"] = 4.0 + 68.0 / (args.fgf * args.fgf)
     dom = max(("cvf_fgf",) if args.fgf else ("cvf_fused", "cvf_a"), key=lambda k: kern.get(k, {"avg_ms": 0})["avg_ms"])
     lps = max(1, round(kern[dom]["launches_per_step"]))
-    vox_per_launch = 2.0 * W * (y1 - y0) * (d1 - d0) / lps                        # (this rank's rows and slices)
+    vox_per_launch = 2.0 * W * (y1 - y0) * (d1 - d0) * B / lps                    # (this rank's rows and slices; all pairs of a batch)
     dom_ms = kern[dom]["avg_ms"]
     achieved = algb[dom] * vox_per_launch / (dom_ms * 1e-3) / 1e9
     two_phase = select_mode and "keys" in fl and "planes" in fl
@@ -629,6 +683,17 @@ def main():
         if use_dist or args.verify:
             ref_maps = single_gpu_maps()
         checks = check_maps(head, ref_maps, oracle_maps)
+        if B > 1:      # every pair of the batch against its own single-pair run through the three reference entry points
+            okb = True
+            for o_, (pl_, pr_) in zip(batch_all, batch_pairs):
+                got_ = [m.copy() for m in o_.download_maps()]
+                with P.DispEst(pl_, pr_, D, 8, True, device=dev_index, dtype=dtype) as one:
+                    if args.flags >= 0:
+                        one.set_option(capi.PSM_OPT_FLAGS, args.flags)
+                    one.CostConst_GPU(); one.CostFilter_GPU(); one.DispSelect_GPU()
+                    okb = okb and bool(np.array_equal(one.lDisMap, got_[0]) and np.array_equal(one.rDisMap, got_[1]))
+            checks["verified_vs_single_gpu"] = okb
+            checks["batch_check"] = f"each of the {B} pairs of the batch == its own CostConst_GPU / CostFilter_GPU / DispSelect_GPU run"
         if timed_maps is not None and oracle_maps is not None:      # (the maps downloaded right after the timed region, too)
             checks["oracle_maps_equal"] = bool(checks["oracle_maps_equal"] and np.array_equal(timed_maps[0], oracle_maps[0])
                                                and np.array_equal(timed_maps[1], oracle_maps[1]))
@@ -726,7 +791,8 @@ def main():
                "note": "the north star's '>= 60 % of HBM-read roofline on the CVF box-filter pass': a stand-alone pass that writes as much as "
                        "it reads cannot reach it (read_frac_of_peak); inside the fused kernel the 16 box passes of a frame take "
                        "ms_per_step / 16 each (fused_pass_equivalent_*) - only in that accounting is it met"}
-    de.close()
+    for o_ in batch_all:
+        o_.close()
 
     # ================= the other sharding axis (N > 1) =================
     alt = None
@@ -759,12 +825,15 @@ def main():
                                       (f"{world} row stripes of {geo['rows_max']} rows (all {D} slices each) + 1 {xname} all_gather of the map rows per frame"
                                        if rows_mode else f"D sharded over {world} ranks + 1 {xname} {exchange} of packed minima"),
                        "kernel_variant": args.variant, "shard_sim": args.shard_sim, "lr_check_on_gpu": bool(lrc),
-                       "shard": head["shard"], "ranks": world, "same_device": bool(args.same_device),
+                       "shard": head["shard"], "batch": B, "graph": bool(args.graph and use_batch), "ranks": world, "same_device": bool(args.same_device),
                        "exchange_backend": (backend if use_dist else None)},
             "roofline": roofline, "cpu_baseline": cpu, "kernels": kern,
             "kernels_sum_ms_per_step": round(kernels_sum, 4), "kernels_sum_le_step": bool(kernels_sum <= ms_per_step * 1.005),
             "median_ms_per_step": head["median_ms_per_step"], "pcie": pcie,
         }
+        if B > 1:
+            out["ms_per_pair"] = ms_per_step / B
+            out["config"]["workload"] = f"{B} x " + desc + " per step (psm_compute_batch: one set of launches for all pairs)"
         out.update(checks)
         if args.same_device and use_dist:
             out["same_device_note"] = (f"{world} ranks share GPU 0: the N > 1 protocol (alternating buffers, pending exchange, gather / merge at world "

@@ -53,7 +53,9 @@ enum {
                                    kernel stamps its own start / end instead (psm_filter_launch_times) */
     PSM_OPT_SEG_ROWS = 3,       /* rows per y-segment of the marching kernels (0 = auto)      */
     PSM_OPT_WAVES = 4,          /* waves (disparity slices) per workgroup: 1,2,4,8            */
-    PSM_OPT_FLAGS = 5           /* PSM_FLAG_* bits below; no flag changes any result */
+    PSM_OPT_FLAGS = 5,          /* PSM_FLAG_* bits below; no flag changes any result */
+    PSM_OPT_GRAPH = 6           /* 1: psm_compute_batch captures its launches once as a hipGraph and replays it while the batch
+                                   (contexts, geometry, options) stays the same; ignored while PSM_OPT_PROFILE is on */
 };
 
 /* PSM_OPT_FLAGS bits.  The default (0) is the product path: cost volumes and filtered volumes stay virtual, the fused
@@ -239,6 +241,21 @@ int psm_set_map_buffer(psm_ctx *ctx, void *dev_maps, int whole);
  * maps into root's maps (root may be one of them); checks that the stripes tile [0, H) and that every context has run
  * psm_disp_select for the frame.  lmap/rmap (optional) receive the whole maps. */
 int psm_gather_rows_ctx(psm_ctx *root, psm_ctx *const *stripes, int nstripes, uint8_t *lmap, uint8_t *rmap, size_t stride);
+
+/* ---- several pairs per launch: the reference's use on Middlebury-size data is a loop over pairs / datasets
+ * (src/main.cpp:64-73, src/StereoMatch.cpp:556-607) - one 450 x 375 x 64 pair is 1.7 rounds of the chip's resident workgroups
+ * behind four launches at their latency floor ----
+ * psm_compute_batch runs DispEst::CostConst_GPU + CostFilter_GPU + DispSelect_GPU (src/DispEst.cpp:272-276,299-308,323-328) for
+ * the n contexts ctxs[0..n) - same width, height, max_disp, slice range, dtype, device and options, each holding its own pair
+ * (psm_upload_pair / psm_upload_pair_async) - in SHARED launches: one image preparation, one guidance kernel, one fused
+ * CVC + CVF + WTA grid over all pairs (two in the two-phase form), one reduction.  Afterwards every context is exactly where
+ * psm_cost_construct + psm_cost_filter + psm_disp_select(ctx, NULL, NULL, 0) would have left it - same maps bit for bit
+ * (psm_download_maps, psm_download_maps_async), same packed minima on a disparity shard, post-processing and volume readers
+ * as usual.  The launches run on ctxs[0]'s stream, ordered after everything already queued on the other contexts' streams
+ * and before anything queued on them later; synchronous on return unless ctxs[0] has PSM_OPT_ASYNC.  Default select path
+ * only: contexts with a row stripe, the storing flags or the direct kernel variant are refused.  Stage timers of every context
+ * receive the batch's wall time. */
+int psm_compute_batch(psm_ctx *const *ctxs, int n);
 
 /* ---- debug / bench entry points (no counterpart in the reference) ---- */
 /* Replace the device maps and validity masks (any may be NULL = keep) - lets the post-processing stages run on maps

@@ -125,13 +125,18 @@ void free_all(psm_ctx *c)
     (void)hipFree(c->gf_scratch);
     (void)hipFree(c->pc_ts);
     (void)hipFree(c->fgf);
+    if (c->batch_graph) (void)hipGraphExecDestroy(c->batch_graph);
+    (void)hipFree(c->batch_tab);
+    if (c->batch_pin) (void)hipHostFree(c->batch_pin);
+    for (hipEvent_t e : {c->ev_batch, c->ev_tab[0], c->ev_tab[1]})
+        if (e) (void)hipEventDestroy(e);
     for (auto &t : c->timers)
         for (auto &p : t.pending) {
             (void)hipEventDestroy(p.first);
             (void)hipEventDestroy(p.second);
         }
     for (auto e : c->event_pool) (void)hipEventDestroy(e);
-    for (hipEvent_t e : {c->ev_up, c->ev_maps, c->ev_down, c->ev_free})
+    for (hipEvent_t e : {c->ev_up, c->ev_maps, c->ev_down, c->ev_free, c->ev_stage[0], c->ev_stage[1]})
         if (e) (void)hipEventDestroy(e);
     if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
@@ -309,6 +314,7 @@ int psm_set_option(psm_ctx *c, int option, int value)
     case PSM_OPT_FLAGS:
         if (value & ~PSM_FLAGS_ALL) return fail(c, "psm_set_option: unknown flag bits 0x%x", value & ~PSM_FLAGS_ALL);
         c->march.flags = value; return 0;
+    case PSM_OPT_GRAPH: c->opt_graph = value != 0; return 0;
     default: return fail(c, "psm_set_option: unknown option %d", option);
     }
 }
@@ -363,22 +369,27 @@ int psm_upload_pair_async(psm_ctx *c, const void *l, const void *r, int channels
     if (!c->copy_stream) PSM_HIP(c, hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
     for (hipEvent_t *e : {&c->ev_up, &c->ev_free})
         if (!*e) PSM_HIP(c, hipEventCreateWithFlags(e, hipEventDisableTiming));
-    if (!c->pin_up) PSM_HIP(c, hipHostMalloc((void **)&c->pin_up, 2 * c->raw_bytes, hipHostMallocDefault));
+    if (!c->pin_up) PSM_HIP(c, hipHostMalloc((void **)&c->pin_up, 4 * c->raw_bytes, hipHostMallocDefault));
     for (int s = 0; s < 2; ++s)
         if (!c->raw_next[s]) PSM_HIP(c, hipMalloc(&c->raw_next[s], c->raw_bytes));
-    // the staging memory still feeds the previous asynchronous upload until ev_up has fired
-    if (c->up_recorded) PSM_HIP(c, hipEventSynchronize(c->ev_up));
+    // two staging slots, used alternately: the host only waits for the copy issued TWO uploads ago (the previous one may still
+    // be queued behind the current frame's kernels - waiting for it would tie the host to the device's pace)
+    const int slot = c->stage_slot ^= 1;
+    if (!c->ev_stage[slot]) PSM_HIP(c, hipEventCreateWithFlags(&c->ev_stage[slot], hipEventDisableTiming));
+    else PSM_HIP(c, hipEventSynchronize(c->ev_stage[slot]));
+    uint8_t *stage = c->pin_up + (size_t)slot * 2 * c->raw_bytes;
     const void *src[2] = {l, r};
     for (int s = 0; s < 2; ++s) {
-        uint8_t *dst = c->pin_up + s * c->raw_bytes;
+        uint8_t *dst = stage + s * c->raw_bytes;
         if (stride_bytes == row) memcpy(dst, src[s], img);
         else for (int y = 0; y < c->H; ++y) memcpy(dst + (size_t)y * row, (const uint8_t *)src[s] + (size_t)y * stride_bytes, row);
     }
     // raw_next was the current pair two frames ago: its k_prep (recorded as ev_free by psm_cost_construct) must be over
     PSM_HIP(c, hipStreamWaitEvent(c->copy_stream, c->ev_free, 0));
     for (int s = 0; s < 2; ++s)
-        PSM_HIP(c, hipMemcpyAsync(c->raw_next[s], c->pin_up + s * c->raw_bytes, img, hipMemcpyHostToDevice, c->copy_stream));
+        PSM_HIP(c, hipMemcpyAsync(c->raw_next[s], stage + s * c->raw_bytes, img, hipMemcpyHostToDevice, c->copy_stream));
     PSM_HIP(c, hipEventRecord(c->ev_up, c->copy_stream));
+    PSM_HIP(c, hipEventRecord(c->ev_stage[slot], c->copy_stream));
     c->up_recorded = true;
     c->next_depth = depth;
     return 0;

@@ -99,7 +99,7 @@ int fgf_flush(psm_ctx *c, int side)
 
 }  // namespace psm
 
-namespace {
+namespace psm {
 
 // chunk planes of the select-mode fused kernel
 int ensure_gf_scratch(psm_ctx *c, size_t bytes)
@@ -113,6 +113,22 @@ int ensure_gf_scratch(psm_ctx *c, size_t bytes)
     c->gf_scratch_bytes = bytes;
     return 0;
 }
+
+// the pair psm_upload_pair_async staged becomes the current one: the kernels wait for its copy on the device
+int adopt_staged_pair(psm_ctx *c)
+{
+    if (c->next_depth < 0) return 0;
+    PSM_HIP(c, hipStreamWaitEvent(c->stream, c->ev_up, 0));
+    std::swap(c->raw[0], c->raw_next[0]);
+    std::swap(c->raw[1], c->raw_next[1]);
+    adopt_new_pair(c, c->next_depth);
+    c->next_depth = -1;
+    return 0;
+}
+
+}  // namespace psm
+
+namespace {
 
 // build the (float) cost slices of `side` for rows [ybeg, yend)
 void launch_cvc_rows(psm_ctx *c, int side, int ybeg, int yend)
@@ -379,14 +395,7 @@ int psm_cost_construct(psm_ctx *c)
 {
     if (!c) return 1;
     if (bind(c)) return 1;
-    if (c->next_depth >= 0) {
-        // the pair psm_upload_pair_async staged becomes the current one: the kernels wait for its copy on the device
-        PSM_HIP(c, hipStreamWaitEvent(c->stream, c->ev_up, 0));
-        std::swap(c->raw[0], c->raw_next[0]);
-        std::swap(c->raw[1], c->raw_next[1]);
-        adopt_new_pair(c, c->next_depth);
-        c->next_depth = -1;
-    }
+    if (adopt_staged_pair(c)) return 1;
     if (!c->have_images) return fail(c, "psm_cost_construct: no image pair uploaded");
     const double t0 = now_us();
     // Lazy cost volume: when the fused filter will consume the costs (marching kernels, PSM_FLAG_MATERIALISE_COSTS not set)

@@ -4,6 +4,7 @@
 //   psm_api_filter.cpp  CostConst / CostFilter: what is built lazily, which form of the fused kernel runs, materialisation
 //   psm_api_select.cpp  DispSelect: maps, packed minima, row stripes and disparity shards
 //   psm_api_pp.cpp      post-processing: L-R check, invalid fill, weighted median
+//   psm_api_batch.cpp   several Middlebury-size pairs per launch (psm_compute_batch)
 // Takes the place of the reference's oclUtil + CVC_cl / CVF_cl / DispSel_cl host wrappers
 // (src/oclUtil.cpp, src/CVC_cl.cpp, src/CVF_cl.cpp, src/DispSel_cl.cpp).
 #pragma once
@@ -33,7 +34,9 @@ struct psm_ctx {
     // device memory (DESIGN.md "HBM layout")
     void *raw[2] = {nullptr, nullptr};  // staged copy of the interleaved host images
     void *raw_next[2] = {nullptr, nullptr};   // second image slot (psm_upload_pair_async), allocated on first use
-    uint8_t *pin_up = nullptr;          // page-locked staging of the next pair (2 images), on first use
+    uint8_t *pin_up = nullptr;          // page-locked staging of the next pair (2 slots x 2 images, used alternately), on first use
+    hipEvent_t ev_stage[2] = {nullptr, nullptr};   // ... the H2D copy out of a slot has executed (the host may refill it)
+    int stage_slot = 0;
     int next_depth = -1;                // PSM_IMG_* of the pair in raw_next (-1: none pending)
     bool up_recorded = false;           // ev_up has been recorded at least once
     size_t raw_bytes = 0;
@@ -82,6 +85,18 @@ struct psm_ctx {
     size_t gf_scratch_bytes = 0;
     unsigned long long *pc_ts = nullptr;  // PSM_OPT_PROFILE 2: {first start, last end} device time stamps per k_cvf_pc launch
     int pc_ts_n = 0;                      // launches stamped since the last reset (slots: PC_TS_SLOTS)
+    // psm_compute_batch (this context as the first of a batch): device table of the pairs' plane pointers, its host copy
+    // (re-uploaded only when an entry changed) and the event the other contexts' streams wait for
+    psm::PcPair *batch_tab = nullptr;
+    std::vector<psm::PcPair> batch_host;
+    psm::PcPair *batch_pin = nullptr;    // page-locked staging of the table, two slots used alternately (a pageable source would make
+    size_t batch_cap = 0;                // the "asynchronous" copy wait for the stream to drain: one frame could not follow the other)
+    int batch_slot = 0;
+    hipEvent_t ev_tab[2] = {nullptr, nullptr};
+    hipEvent_t ev_batch = nullptr;
+    // PSM_OPT_GRAPH: the launches of a batch captured once as a hipGraph and replayed while nothing they depend on changes
+    hipGraphExec_t batch_graph = nullptr;
+    long long graph_sig[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     float4 *fgf_mab[2] = {nullptr, nullptr};
     void *fgf = nullptr;                // psm_cost_filter_fgf scratch (small planes), fgf_bytes long
     size_t fgf_bytes = 0;
@@ -96,7 +111,7 @@ struct psm_ctx {
     int raw_rows[2] = {RAW_ALL, RAW_ALL};
 
     // options
-    int opt_async = 0, opt_variant = 0, opt_profile = 0;
+    int opt_async = 0, opt_variant = 0, opt_profile = 0, opt_graph = 0;
     psm::March march = {0, 4, 0};
 
     double stage_us[PSM_STAGE_COUNT] = {0, 0, 0, 0};
@@ -162,6 +177,8 @@ int ensure_ab(psm_ctx *c);
 int ensure_spare(psm_ctx *c);
 int fgf_flush(psm_ctx *c, int side);
 int materialize(psm_ctx *c, int side);
+int adopt_staged_pair(psm_ctx *c);               // the pair psm_upload_pair_async staged becomes the current one
+int ensure_gf_scratch(psm_ctx *c, size_t bytes);
 unsigned long long *next_pc_stamp(psm_ctx *c);   // slot of the next k_cvf_pc launch (NULL unless PSM_OPT_PROFILE 2)
 
 // psm_api_select.cpp

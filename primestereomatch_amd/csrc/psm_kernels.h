@@ -29,6 +29,20 @@ struct March {       // geometry of the marching kernels
     int rows(int H) const { return y1(H) - y0(H); }
 };
 
+// ---- batched launches: B stereo pairs of one geometry share every launch of the default path (psm_compute_batch; the
+// reference's use on Middlebury-size data is a loop over pairs, src/main.cpp:64-73) ----
+struct PcPair {                  // one pair of the batch: an entry of a device table the kernels index with the pair number
+    const void *raw[2];          // staged interleaved images (left, right)
+    Guidance g[2];
+    uint8_t *p4[2];              // 8-bit char mode: {c0,c1,c2,grad} byte planes (else null)
+    void *scratch;               // chunk planes of the select kernel (both sides)
+    long long *keys;             // [2][H][W] packed minima
+    uint8_t *maps;               // [2][H][W]
+};
+void launch_prep_batch(hipStream_t s, const PcPair *tab, int npairs, size_t pitch, int depth_f32, int W, int H, bool u8_planes);
+void launch_guidance_batch(hipStream_t s, const PcPair *tab, int npairs, int W, int H);
+void launch_merge_batch(hipStream_t s, const PcPair *tab, int npairs, int W, int H);   // keys -> maps of every pair
+
 // image -> g1 (planarise, scale, gray, x-gradient).  src: device copy of the interleaved image.
 void launch_prep(hipStream_t s, const void *src, size_t pitch, int depth_f32, int W, int H, float4 *g1, const void *src1 = nullptr,
                  float4 *g11 = nullptr);
@@ -59,7 +73,7 @@ struct PcPlan {
     int rec_bytes;                                               // bytes per record (costs + disparities)
     size_t scratch_bytes() const { return rec_per_chunk * (size_t)nchunks * rec_bytes; }
 };
-PcPlan pc_plan(int W, int rows, int Dloc, int seg_rows_opt, int form);
+PcPlan pc_plan(int W, int rows, int Dloc, int seg_rows_opt, int form, int batch = 1);   // batch: pairs per launch (psm_compute_batch)
 int pc_seed_stride(int W, int H);                                // S of the two-phase selection: every S-th slice seeds the key plane
 // ts (may be NULL): slot of this launch in a buffer of 3 x PC_TS_SLOTS 64-bit words {first workgroup start | last workgroup
 // end | form} in ticks of the device's constant-rate clock (PSM_OPT_PROFILE 2, psm_filter_launch_times)
@@ -76,6 +90,13 @@ void launch_cvf_select2(hipStream_t s, March m, const Guidance *g, int W, int H,
 void launch_chunk_min2sides(hipStream_t s, March m, int W, int H, int Dloc, void *scratch, long long *keys, uint8_t *map);
 void launch_cvf_select_keys2(hipStream_t s, March m, const Guidance *g, int W, int H, int Dloc, int d_begin, long long *keys,
                              unsigned long long *ts = nullptr, const uint8_t *const *p4 = nullptr, int init = 1, int sel = 0, int step = 1);
+// the three launches above for `npairs` pairs at once (blockIdx.z = pair, pointers from the device table `tab`; every pair's
+// scratch holds 2 x pc_plan(..., PC_PLANES | PC_BOTH, npairs).scratch_bytes()); to_maps: the reduction also writes the maps
+void launch_cvf_select2_batch(hipStream_t s, March m, const PcPair *tab, int npairs, int W, int H, int Dloc, int d_begin,
+                              unsigned long long *ts, bool u8, int sel = 0, int step = 1);
+void launch_chunk_min2sides_batch(hipStream_t s, March m, const PcPair *tab, int npairs, int W, int H, int Dloc, bool to_maps);
+void launch_cvf_select_keys2_batch(hipStream_t s, March m, const PcPair *tab, int npairs, int W, int H, int Dloc, int d_begin,
+                                   unsigned long long *ts, bool u8, int sel, int step);
 // plain 8x8 box filter of every slice (the north-star kernel in isolation)
 void launch_box8(hipStream_t s, int variant, March m, const float *vol, float *out, int W, int H, int Dloc);
 // WTA over local slices -> packed keys (keys != NULL) and/or final map (map != NULL)

@@ -45,10 +45,12 @@ __device__ __forceinline__ void load_px(const void *src, size_t pitch, int y, in
 }
 
 template <bool F32>
-__global__ __launch_bounds__(256) void k_prep(const void *src, size_t pitch, int W, int H, float4 *g1, const void *src1, float4 *g11)
+__global__ __launch_bounds__(256) void k_prep(const void *src, size_t pitch, int W, int H, float4 *g1, const void *src1, float4 *g11,
+                                             const PcPair *__restrict__ tab)
 {
     int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
-    if (blockIdx.z == 1) { src = src1; g1 = g11; }    // second image of a two-image launch
+    if (tab) { src = tab[blockIdx.z >> 1].raw[blockIdx.z & 1]; g1 = tab[blockIdx.z >> 1].g[blockIdx.z & 1].g1; }   // batch: image z & 1 of pair z >> 1
+    else if (blockIdx.z == 1) { src = src1; g1 = g11; }    // second image of a two-image launch
     if (x >= W) return;
     float c0, c1, c2, l0, l1, l2, r0, r1, r2;
     load_px<F32>(src, pitch, y, x, c0, c1, c2);
@@ -62,9 +64,9 @@ void launch_prep(hipStream_t s, const void *src, size_t pitch, int depth_f32, in
 {   // src1 != NULL: both images in one launch
     dim3 grid((W + 255) / 256, H, src1 ? 2 : 1);
     if (depth_f32)
-        hipLaunchKernelGGL(k_prep<true>, grid, dim3(256), 0, s, src, pitch, W, H, g1, src1, g11);
+        hipLaunchKernelGGL(k_prep<true>, grid, dim3(256), 0, s, src, pitch, W, H, g1, src1, g11, (const PcPair *)nullptr);
     else
-        hipLaunchKernelGGL(k_prep<false>, grid, dim3(256), 0, s, src, pitch, W, H, g1, src1, g11);
+        hipLaunchKernelGGL(k_prep<false>, grid, dim3(256), 0, s, src, pitch, W, H, g1, src1, g11, (const PcPair *)nullptr);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -109,10 +111,12 @@ __device__ __forceinline__ void guide_finish(const float *m, float4 &g2, float4 
 // 4 x 56 pixels.  Round 2 ran one wave per (strip, segment) with all nine trees: one resident round of two waves per SIMD,
 // i.e. the kernel took as long as ONE wave's serial march (54 us at 1080p, 19 us at 450 x 375).  Same arithmetic, same bits.
 __global__ __launch_bounds__(192) void k_guide_march(const float4 *g1, int W, int H, int nstrips, int seg_rows,
-                                                    float4 *g2, float4 *g3, float2 *g4, Guidance second, int ybeg, int yend)
+                                                    float4 *g2, float4 *g3, float2 *g4, Guidance second, int ybeg, int yend,
+                                                    const PcPair *__restrict__ tab)
 {
     __shared__ float ms[2][4][9][64];            // [batch parity][row of the batch][channel][lane]
-    if (blockIdx.y == 1) { g1 = second.g1; g2 = second.g2; g3 = second.g3; g4 = second.g4; }   // second image of a two-image launch
+    if (tab) { const Guidance gg = tab[blockIdx.y >> 1].g[blockIdx.y & 1]; g1 = gg.g1; g2 = gg.g2; g3 = gg.g3; g4 = gg.g4; }   // batch: image y & 1 of pair y >> 1
+    else if (blockIdx.y == 1) { g1 = second.g1; g2 = second.g2; g3 = second.g3; g4 = second.g4; }   // second image of a two-image launch
     const int strip = blockIdx.x % nstrips, seg = blockIdx.x / nstrips;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int x0 = strip * 56;
@@ -177,7 +181,20 @@ void launch_guidance(hipStream_t s, Guidance g, int W, int H, const Guidance *se
     while (seg_rows < 64 && nstrips * ((rows + seg_rows - 1) / seg_rows) > wgs) ++seg_rows;
     const int nsegs = (rows + seg_rows - 1) / seg_rows;
     hipLaunchKernelGGL(k_guide_march, dim3(nstrips * nsegs, second ? 2 : 1), dim3(192), 0, s, (const float4 *)g.g1, W, H, nstrips, seg_rows, g.g2, g.g3, g.g4,
-                       second ? *second : Guidance{}, ybeg, yend);
+                       second ? *second : Guidance{}, ybeg, yend, (const PcPair *)nullptr);
+}
+
+// ---- the same two kernels for every pair of a batch (psm_compute_batch): one launch each, images indexed through the table ----
+void launch_guidance_batch(hipStream_t s, const PcPair *tab, int npairs, int W, int H)
+{
+    const int nstrips = (W + 55) / 56;
+    const PcDev dev = pc_dev();
+    const int wgs = 6 * dev.nxcd * dev.cus_per_xcd / (2 * npairs) > 0 ? 6 * dev.nxcd * dev.cus_per_xcd / (2 * npairs) : 1;
+    int seg_rows = 8;
+    while (seg_rows < 64 && nstrips * ((H + seg_rows - 1) / seg_rows) > wgs) ++seg_rows;
+    const int nsegs = (H + seg_rows - 1) / seg_rows;
+    hipLaunchKernelGGL(k_guide_march, dim3(nstrips * nsegs, 2 * npairs), dim3(192), 0, s, (const float4 *)nullptr, W, H, nstrips, seg_rows,
+                       (float4 *)nullptr, (float4 *)nullptr, (float2 *)nullptr, Guidance{}, 0, H, tab);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -676,6 +693,19 @@ void launch_merge(hipStream_t s, const long long *keys_all, size_t rank_stride, 
     hipLaunchKernelGGL(k_merge, dim3((n + 255) / 256), dim3(256), 0, s, keys_all, rank_stride, nranks, n, map);
 }
 
+// keys -> maps of every pair of a batch (the two-phase selection leaves keys; blockIdx.y = pair)
+__global__ __launch_bounds__(256) void k_merge_batch(const PcPair *__restrict__ tab, int n)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    tab[blockIdx.y].maps[i] = (uint8_t)((unsigned long long)tab[blockIdx.y].keys[i] & 0xffull);
+}
+void launch_merge_batch(hipStream_t s, const PcPair *tab, int npairs, int W, int H)
+{
+    const int n = 2 * W * H;
+    hipLaunchKernelGGL(k_merge_batch, dim3((n + 255) / 256, npairs), dim3(256), 0, s, tab, n);
+}
+
 // ------------------------------------------------------------------------------------------
 // PP lrCheck (src/PP.cpp:17-50)
 // ------------------------------------------------------------------------------------------
@@ -779,9 +809,10 @@ __device__ __forceinline__ int gray_u8(const uint8_t *p)
 }
 
 // planes4[y][x] = {c0, c1, c2, grad} as one 32-bit word per pixel
-__global__ __launch_bounds__(256) void k_prep_u8(const uint8_t *src, size_t pitch, int W, int H, uchar4 *out)
+__global__ __launch_bounds__(256) void k_prep_u8(const uint8_t *src, size_t pitch, int W, int H, uchar4 *out, const PcPair *__restrict__ tab)
 {
     int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (tab) { src = (const uint8_t *)tab[blockIdx.z >> 1].raw[blockIdx.z & 1]; out = (uchar4 *)tab[blockIdx.z >> 1].p4[blockIdx.z & 1]; }
     if (x >= W) return;
     const uint8_t *row = src + (size_t)y * pitch;
     const uint8_t *p = row + 3 * x;
@@ -791,7 +822,17 @@ __global__ __launch_bounds__(256) void k_prep_u8(const uint8_t *src, size_t pitc
 }
 void launch_prep_u8(hipStream_t s, const uint8_t *src, size_t pitch, int W, int H, uint8_t *planes4)
 {
-    hipLaunchKernelGGL(k_prep_u8, dim3((W + 255) / 256, H), dim3(256), 0, s, src, pitch, W, H, (uchar4 *)planes4);
+    hipLaunchKernelGGL(k_prep_u8, dim3((W + 255) / 256, H), dim3(256), 0, s, src, pitch, W, H, (uchar4 *)planes4, (const PcPair *)nullptr);
+}
+void launch_prep_batch(hipStream_t s, const PcPair *tab, int npairs, size_t pitch, int depth_f32, int W, int H, bool u8_planes)
+{
+    const dim3 grid((W + 255) / 256, H, 2 * npairs);
+    if (depth_f32)
+        hipLaunchKernelGGL(k_prep<true>, grid, dim3(256), 0, s, (const void *)nullptr, pitch, W, H, (float4 *)nullptr, (const void *)nullptr, (float4 *)nullptr, tab);
+    else
+        hipLaunchKernelGGL(k_prep<false>, grid, dim3(256), 0, s, (const void *)nullptr, pitch, W, H, (float4 *)nullptr, (const void *)nullptr, (float4 *)nullptr, tab);
+    if (u8_planes)
+        hipLaunchKernelGGL(k_prep_u8, grid, dim3(256), 0, s, (const uint8_t *)nullptr, pitch, W, H, (uchar4 *)nullptr, tab);
 }
 
 __device__ __forceinline__ uint8_t cost_u8(int clr3, int grd)

@@ -145,6 +145,7 @@ struct PcSel {
     int nxcd;      // XCDs of the device (blocks are dispatched round-robin over them)
     int spread;    // key form: dispatch the slices of a pair in `spread` interleaved passes (0 / 1: ascending)
     int n;         // ... over n slices
+    unsigned long long rec_total;   // BATCH launches: float4 cost records per side in a pair's scratch (the disparities follow them)
 };
 __device__ __forceinline__ int pc_slice(const PcSel &o, int i)
 {
@@ -173,15 +174,33 @@ __device__ __forceinline__ int pc_slice(const PcSel &o, int i)
 // (other side) and filter cost * (1/255.0f); the consumer waves re-quantise q8 = sat_u8(rintf(q * 255)) before the
 // strict-'<' selection (assets/dispsel.cl:41-62 with the initial minimum above 255) - the build-defined 8-bit contract
 // of oracle/psm_oracle.h, in one pass and without an 8-bit volume in memory.
-template <bool VEC4, int CVC, int MODE, bool U8 = false>
+// BATCH (psm_compute_batch): blockIdx.z = stereo pair; every plane pointer of the pair comes from the device table `batch`
+// (uniform: scalar loads), so B Middlebury-size pairs fill the chip for many rounds of workgroups instead of 1.7.
+template <bool VEC4, int CVC, int MODE, bool U8 = false, bool BATCH = false>
 __global__ __launch_bounds__(64 * (PcLayout<MODE>::NA + PcLayout<MODE>::NB)) PSM_PC_ATTR
 __attribute__((amdgpu_waves_per_eu(MODE == 2 ? 4 : 1, MODE == 2 ? 4 : 8)))   // the key form capped at 128 VGPRs = four workgroups per CU
 void k_cvf_pc(
     const float *__restrict__ vin, float *__restrict__ vout, const float4 *__restrict__ G1a, const float4 *__restrict__ G2a,
     const float4 *__restrict__ G3a, const float2 *__restrict__ G4a, int W, int H, int Dloc, int ngroups, int nsegs, int seg_rows,
     int ybeg, int yend, const float4 *__restrict__ Gothera, int d_begin, int DC, float *__restrict__ kcosta, unsigned *__restrict__ kdispa, int nbmax,
-    PcSide side1, PcSel dyn, unsigned long long *__restrict__ ts)
+    PcSide side1, PcSel dyn, unsigned long long *__restrict__ ts, const PcPair *__restrict__ batch)
 {
+    if constexpr (BATCH) {
+        static_assert(CVC == 3 && MODE != 0, "batched launches: both volumes per launch, select forms");
+        const PcPair pp = batch[blockIdx.z];
+        G1a = pp.g[0].g1; G2a = pp.g[0].g2; G3a = pp.g[0].g3; G4a = pp.g[0].g4; Gothera = pp.g[1].g1;
+        side1.G1 = pp.g[1].g1; side1.G2 = pp.g[1].g2; side1.G3 = pp.g[1].g3; side1.G4 = pp.g[1].g4; side1.Gother = pp.g[0].g1;
+        if (U8) { vin = (const float *)pp.p4[0]; vout = (float *)pp.p4[1]; }
+        if (MODE == 1) {     // minima planes: [side][costs | disparities] in the pair's scratch
+            kcosta = (float *)pp.scratch;
+            kdispa = (unsigned *)(kcosta + 4 * dyn.rec_total);
+            side1.kcost = (float *)((char *)pp.scratch + dyn.rec_total * 20);
+            side1.kdisp = (unsigned *)(side1.kcost + 4 * dyn.rec_total);
+        } else {             // key planes
+            kcosta = (float *)pp.keys;
+            side1.kcost = (float *)(pp.keys + (size_t)W * H);
+        }
+    }
     const bool right = CVC == 2 || (CVC == 3 && blockIdx.y == 1);      // buildCV_right arithmetic (uniform)
     const bool s1 = CVC == 3 && blockIdx.y == 1;
     const float4 *const G1 = s1 ? side1.G1 : G1a, *const G2 = s1 ? side1.G2 : G2a, *const G3 = s1 ? side1.G3 : G3a;
@@ -581,9 +600,19 @@ void k_cvf_pc(
 __global__ __launch_bounds__(256) void k_chunk_min(const float4 *kcost, const unsigned *kdisp, int nchunks, int npairs,
                                                   int nbmax, int ngroups, int seg_rows, int W, int H, long long *keys,
                                                   uint8_t *map, const float4 *__restrict__ kcost1, const unsigned *__restrict__ kdisp1,
-                                                  int ybeg, int yend)
+                                                  int ybeg, int yend, const PcPair *__restrict__ batch, int to_maps)
 {
     using L = PcLayout<1>;
+    if (batch) {             // batched launch: blockIdx.z = pair, planes / keys / maps from the table
+        const PcPair pp = batch[blockIdx.z];
+        const size_t rec_total = (size_t)npairs * nbmax * L::COLS * nchunks;
+        kcost = (const float4 *)pp.scratch;
+        kdisp = (const unsigned *)(kcost + rec_total);
+        kcost1 = (const float4 *)((const char *)pp.scratch + rec_total * 20);
+        kdisp1 = (const unsigned *)(kcost1 + rec_total);
+        keys = pp.keys;
+        map = to_maps ? pp.maps : nullptr;
+    }
     if (blockIdx.y == 1) {   // second volume of a two-side launch: its own planes, keys / map one image further
         kcost = kcost1;
         kdisp = kdisp1;
@@ -702,11 +731,11 @@ static int pc_env(const char *) { return 0; }
 // workgroups (key form: x 4).  Cost model, fitted to measurements at 1080p (DC = 1, 2, 4, 8, 16: 4.39, 4.41, 4.46, 4.71,
 // 4.99 ms for kernel + reduction): (rounds + 1/2) x rows walked per workgroup - the last round is on average half empty,
 // which is what makes long-running workgroups (large DC) expensive - plus two row-steps per chunk plane for the reduction.
-PcPlan pc_plan(int W, int rows, int Dloc, int seg_rows_opt, int form)
+PcPlan pc_plan(int W, int rows, int Dloc, int seg_rows_opt, int form, int batch)
 {   // form: PC_STORE; PC_PLANES (select with chunk planes) / PC_KEYS (select against a shared key plane, one slice per
     // workgroup, no reduction afterwards), each + PC_BOTH when one launch covers both volumes (twice the work items)
     const bool planes = (form & 3) == PC_PLANES, keys = (form & 3) == PC_KEYS;
-    const int sides = (form & PC_BOTH) ? 2 : 1;
+    const int sides = ((form & PC_BOTH) ? 2 : 1) * (batch > 1 ? batch : 1);   // volumes per launch
     const int cols = (form & 3) == PC_STORE ? PcLayout<0>::COLS : PcLayout<1>::COLS;
     const PcDev dev = pc_dev();
     PcPlan pl;
@@ -767,7 +796,7 @@ void launch_cvf_fused(hipStream_t s, March m, const float *vin, float *vout, Gui
 #define PSM_LAUNCH_PC(V4, CV)                                                                                              \
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_cvf_pc<V4, CV, 0>), grid, blk, 0, s, vin, vout, (const float4 *)gd.g1,            \
                        (const float4 *)gd.g2, (const float4 *)gd.g3, (const float2 *)gd.g4, W, H, Dloc, pl.ngroups, pl.nsegs, \
-                       pl.seg_rows, ybeg, yend, g1_other, d_begin, 1, (float *)nullptr, (unsigned *)nullptr, 0, PcSide{}, PcSel{0, 1, pl.nxcd, 0, Dloc}, (unsigned long long *)nullptr)
+                       pl.seg_rows, ybeg, yend, g1_other, d_begin, 1, (float *)nullptr, (unsigned *)nullptr, 0, PcSide{}, PcSel{0, 1, pl.nxcd, 0, Dloc, 0}, (unsigned long long *)nullptr, (const PcPair *)nullptr)
     const bool v4 = (W & 3) == 0;
     if (cvc_mode == 1) { if (v4) PSM_LAUNCH_PC(true, 1); else PSM_LAUNCH_PC(false, 1); }
     else if (cvc_mode == 2) { if (v4) PSM_LAUNCH_PC(true, 2); else PSM_LAUNCH_PC(false, 2); }
@@ -781,14 +810,14 @@ void launch_cvf_select(hipStream_t s, March m, const float *vin, Guidance gd, in
                        int d_begin, int cvc_mode, void *scratch, unsigned long long *ts, const uint8_t *p4_own, const uint8_t *p4_other)
 {
     const PcPlan pl = pc_plan(W, m.rows(H), Dloc, m.seg_rows, PC_PLANES);
-    const PcSel sel = {0, 1, pl.nxcd, 0, Dloc};
+    const PcSel sel = {0, 1, pl.nxcd, 0, Dloc, 0};
     float *kcost = (float *)scratch;                                           // nchunks * rec_per_chunk float4
     unsigned *kdisp = (unsigned *)(kcost + 4 * pl.rec_per_chunk * pl.nchunks);  // nchunks * rec_per_chunk uchar4
     const dim3 grid(pc_blocks(pl, pl.nchunks)), blk(64 * (PcLayout<1>::NA + PcLayout<1>::NB));
 #define PSM_LAUNCH_PC(CV, U8V, A0, A1)                                                                                      \
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_cvf_pc<false, CV, 1, U8V>), grid, blk, 0, s, A0, A1, (const float4 *)gd.g1,        \
                        (const float4 *)gd.g2, (const float4 *)gd.g3, (const float2 *)gd.g4, W, H, Dloc, pl.ngroups, pl.nsegs, \
-                       pl.seg_rows, m.y0(H), m.y1(H), g1_other, d_begin, pl.DC, kcost, kdisp, pl.nbmax, PcSide{}, sel, ts)
+                       pl.seg_rows, m.y0(H), m.y1(H), g1_other, d_begin, pl.DC, kcost, kdisp, pl.nbmax, PcSide{}, sel, ts, (const PcPair *)nullptr)
     if (p4_own && cvc_mode != 0) {
         if (cvc_mode == 1) PSM_LAUNCH_PC(1, true, (const float *)p4_own, (float *)const_cast<uint8_t *>(p4_other));
         else PSM_LAUNCH_PC(2, true, (const float *)p4_own, (float *)const_cast<uint8_t *>(p4_other));
@@ -805,7 +834,7 @@ void launch_chunk_min(hipStream_t s, March m, int W, int H, int Dloc, void *scra
     const unsigned *kdisp = (const unsigned *)(kcost + 4 * pl.rec_per_chunk * pl.nchunks);
     hipLaunchKernelGGL(k_chunk_min, dim3((unsigned)((pl.rec_per_chunk + 255) / 256)), dim3(256), 0, s, (const float4 *)kcost, (const unsigned *)kdisp,
                        pl.nchunks, pl.ngroups * pl.nsegs, pl.nbmax, pl.ngroups, pl.seg_rows, W, H, keys, map, (const float4 *)nullptr,
-                       (const unsigned *)nullptr, m.y0(H), m.y1(H));
+                       (const unsigned *)nullptr, m.y0(H), m.y1(H), (const PcPair *)nullptr, 0);
 }
 
 // Both volumes in one launch each (costs built on the fly): left volume = (g[0], other g[1].g1), right = (g[1], other g[0].g1).
@@ -816,7 +845,7 @@ void launch_cvf_select2(hipStream_t s, March m, const Guidance *g, int W, int H,
                         unsigned long long *ts, const uint8_t *const *p4, int sel, int step)
 {
     const PcPlan pl = pc_plan(W, m.rows(H), Dloc, m.seg_rows, PC_PLANES | PC_BOTH);
-    const PcSel ps = {sel, step, pl.nxcd, 0, Dloc};
+    const PcSel ps = {sel, step, pl.nxcd, 0, Dloc, 0};
     float *kcost0 = (float *)scratch;
     unsigned *kdisp0 = (unsigned *)(kcost0 + 4 * pl.rec_per_chunk * pl.nchunks);
     float *kcost1 = (float *)((char *)scratch + pl.scratch_bytes());
@@ -826,11 +855,11 @@ void launch_cvf_select2(hipStream_t s, March m, const Guidance *g, int W, int H,
     if (p4)
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_cvf_pc<false, 3, 1, true>), grid, blk, 0, s, (const float *)p4[0], (float *)const_cast<uint8_t *>(p4[1]),
                            (const float4 *)g[0].g1, (const float4 *)g[0].g2, (const float4 *)g[0].g3, (const float2 *)g[0].g4, W, H, Dloc, pl.ngroups,
-                           pl.nsegs, pl.seg_rows, m.y0(H), m.y1(H), (const float4 *)g[1].g1, d_begin, pl.DC, kcost0, kdisp0, pl.nbmax, s1, ps, ts);
+                           pl.nsegs, pl.seg_rows, m.y0(H), m.y1(H), (const float4 *)g[1].g1, d_begin, pl.DC, kcost0, kdisp0, pl.nbmax, s1, ps, ts, (const PcPair *)nullptr);
     else
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_cvf_pc<false, 3, 1>), grid, blk, 0, s, (const float *)nullptr, (float *)nullptr, (const float4 *)g[0].g1,
                            (const float4 *)g[0].g2, (const float4 *)g[0].g3, (const float2 *)g[0].g4, W, H, Dloc, pl.ngroups, pl.nsegs, pl.seg_rows, m.y0(H), m.y1(H),
-                           (const float4 *)g[1].g1, d_begin, pl.DC, kcost0, kdisp0, pl.nbmax, s1, ps, ts);
+                           (const float4 *)g[1].g1, d_begin, pl.DC, kcost0, kdisp0, pl.nbmax, s1, ps, ts, (const PcPair *)nullptr);
 }
 
 void launch_chunk_min2sides(hipStream_t s, March m, int W, int H, int Dloc, void *scratch, long long *keys, uint8_t *map)
@@ -841,7 +870,8 @@ void launch_chunk_min2sides(hipStream_t s, March m, int W, int H, int Dloc, void
     const float *kcost1 = (const float *)((const char *)scratch + pl.scratch_bytes());
     const unsigned *kdisp1 = (const unsigned *)(kcost1 + 4 * pl.rec_per_chunk * pl.nchunks);
     hipLaunchKernelGGL(k_chunk_min, dim3((unsigned)((pl.rec_per_chunk + 255) / 256), 2), dim3(256), 0, s, (const float4 *)kcost0, kdisp0,
-                       pl.nchunks, pl.ngroups * pl.nsegs, pl.nbmax, pl.ngroups, pl.seg_rows, W, H, keys, map, (const float4 *)kcost1, kdisp1, m.y0(H), m.y1(H));
+                       pl.nchunks, pl.ngroups * pl.nsegs, pl.nbmax, pl.ngroups, pl.seg_rows, W, H, keys, map, (const float4 *)kcost1, kdisp1, m.y0(H), m.y1(H),
+                       (const PcPair *)nullptr, 0);
 }
 
 // ... key form (MODE 2): keys[2][H][W] receives the packed minima (init: start from key(+inf, 0); otherwise continue from what
@@ -850,7 +880,7 @@ void launch_cvf_select_keys2(hipStream_t s, March m, const Guidance *g, int W, i
                              unsigned long long *ts, const uint8_t *const *p4, int init, int sel, int step)
 {
     const PcPlan pl = pc_plan(W, m.rows(H), Dloc, m.seg_rows, PC_KEYS | PC_BOTH);
-    const PcSel ps = {sel, step, pl.nxcd, pc_env("PSM_PC_SPREAD") > 0 ? pc_env("PSM_PC_SPREAD") : PC_KEY_SPREAD, Dloc};
+    const PcSel ps = {sel, step, pl.nxcd, pc_env("PSM_PC_SPREAD") > 0 ? pc_env("PSM_PC_SPREAD") : PC_KEY_SPREAD, Dloc, 0};
     const size_t HW = (size_t)W * H;
     if (init) hipLaunchKernelGGL(k_fill_keys, dim3((unsigned)((2 * HW + 255) / 256)), dim3(256), 0, s, keys, 2 * HW);
     const dim3 grid(pc_blocks(pl, Dloc), 2), blk(64 * (PcLayout<2>::NA + PcLayout<2>::NB));
@@ -859,11 +889,50 @@ void launch_cvf_select_keys2(hipStream_t s, March m, const Guidance *g, int W, i
     if (p4)
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_cvf_pc<false, 3, 2, true>), grid, blk, 0, s, (const float *)p4[0], (float *)const_cast<uint8_t *>(p4[1]),
                            (const float4 *)g[0].g1, (const float4 *)g[0].g2, (const float4 *)g[0].g3, (const float2 *)g[0].g4, W, H, Dloc, pl.ngroups,
-                           pl.nsegs, pl.seg_rows, m.y0(H), m.y1(H), (const float4 *)g[1].g1, d_begin, 1, (float *)keys, (unsigned *)nullptr, 0, s1, ps, ts);
+                           pl.nsegs, pl.seg_rows, m.y0(H), m.y1(H), (const float4 *)g[1].g1, d_begin, 1, (float *)keys, (unsigned *)nullptr, 0, s1, ps, ts, (const PcPair *)nullptr);
     else
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_cvf_pc<false, 3, 2, false>), grid, blk, 0, s, (const float *)nullptr, (float *)nullptr,
                            (const float4 *)g[0].g1, (const float4 *)g[0].g2, (const float4 *)g[0].g3, (const float2 *)g[0].g4, W, H, Dloc, pl.ngroups,
-                           pl.nsegs, pl.seg_rows, m.y0(H), m.y1(H), (const float4 *)g[1].g1, d_begin, 1, (float *)keys, (unsigned *)nullptr, 0, s1, ps, ts);
+                           pl.nsegs, pl.seg_rows, m.y0(H), m.y1(H), (const float4 *)g[1].g1, d_begin, 1, (float *)keys, (unsigned *)nullptr, 0, s1, ps, ts, (const PcPair *)nullptr);
+}
+
+// ---- the same launches for `npairs` stereo pairs at once (psm_compute_batch): blockIdx.z = pair, pointers from the table ----
+void launch_cvf_select2_batch(hipStream_t s, March m, const PcPair *tab, int npairs, int W, int H, int Dloc, int d_begin,
+                              unsigned long long *ts, bool u8, int sel, int step)
+{
+    const PcPlan pl = pc_plan(W, m.rows(H), Dloc, m.seg_rows, PC_PLANES | PC_BOTH, npairs);
+    const PcSel ps = {sel, step, pl.nxcd, 0, Dloc, (unsigned long long)pl.rec_per_chunk * pl.nchunks};
+    const dim3 grid(pc_blocks(pl, pl.nchunks), 2, npairs), blk(64 * (PcLayout<1>::NA + PcLayout<1>::NB));
+#define PSM_LAUNCH_PCB(U8V)                                                                                                   \
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_cvf_pc<false, 3, 1, U8V, true>), grid, blk, 0, s, (const float *)nullptr, (float *)nullptr,  \
+                       (const float4 *)nullptr, (const float4 *)nullptr, (const float4 *)nullptr, (const float2 *)nullptr, W, H, Dloc, \
+                       pl.ngroups, pl.nsegs, pl.seg_rows, m.y0(H), m.y1(H), (const float4 *)nullptr, d_begin, pl.DC, (float *)nullptr, \
+                       (unsigned *)nullptr, pl.nbmax, PcSide{}, ps, ts, tab)
+    if (u8) PSM_LAUNCH_PCB(true); else PSM_LAUNCH_PCB(false);
+#undef PSM_LAUNCH_PCB
+}
+
+void launch_chunk_min2sides_batch(hipStream_t s, March m, const PcPair *tab, int npairs, int W, int H, int Dloc, bool to_maps)
+{
+    const PcPlan pl = pc_plan(W, m.rows(H), Dloc, m.seg_rows, PC_PLANES | PC_BOTH, npairs);
+    hipLaunchKernelGGL(k_chunk_min, dim3((unsigned)((pl.rec_per_chunk + 255) / 256), 2, npairs), dim3(256), 0, s, (const float4 *)nullptr,
+                       (const unsigned *)nullptr, pl.nchunks, pl.ngroups * pl.nsegs, pl.nbmax, pl.ngroups, pl.seg_rows, W, H, (long long *)nullptr,
+                       (uint8_t *)nullptr, (const float4 *)nullptr, (const unsigned *)nullptr, m.y0(H), m.y1(H), tab, to_maps ? 1 : 0);
+}
+
+void launch_cvf_select_keys2_batch(hipStream_t s, March m, const PcPair *tab, int npairs, int W, int H, int Dloc, int d_begin,
+                                   unsigned long long *ts, bool u8, int sel, int step)
+{
+    const PcPlan pl = pc_plan(W, m.rows(H), Dloc, m.seg_rows, PC_KEYS | PC_BOTH, npairs);
+    const PcSel ps = {sel, step, pl.nxcd, PC_KEY_SPREAD, Dloc, 0};
+    const dim3 grid(pc_blocks(pl, Dloc), 2, npairs), blk(64 * (PcLayout<2>::NA + PcLayout<2>::NB));
+#define PSM_LAUNCH_PCB(U8V)                                                                                                   \
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_cvf_pc<false, 3, 2, U8V, true>), grid, blk, 0, s, (const float *)nullptr, (float *)nullptr,  \
+                       (const float4 *)nullptr, (const float4 *)nullptr, (const float4 *)nullptr, (const float2 *)nullptr, W, H, Dloc, \
+                       pl.ngroups, pl.nsegs, pl.seg_rows, m.y0(H), m.y1(H), (const float4 *)nullptr, d_begin, 1, (float *)nullptr,      \
+                       (unsigned *)nullptr, 0, PcSide{}, ps, ts, tab)
+    if (u8) PSM_LAUNCH_PCB(true); else PSM_LAUNCH_PCB(false);
+#undef PSM_LAUNCH_PCB
 }
 
 }  // namespace psm

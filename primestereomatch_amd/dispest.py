@@ -317,3 +317,15 @@ class DispEst:
 
     def reset_kernel_times(self):
         self._ck(self._lib.psm_reset_kernel_times(self._h), "reset_kernel_times")
+
+
+def compute_batch(des):
+    """CostConst_GPU + CostFilter_GPU + DispSelect (maps left on the device) of several DispEst objects of one geometry in
+    shared launches (psm_compute_batch): the reference's loop over pairs / datasets (src/main.cpp:64-73,
+    src/StereoMatch.cpp:556-607) as one grid.  Every object afterwards behaves as after the three single-pair calls
+    (download_maps(), LRCheck_GPU(), download_volume(), ...)."""
+    des = list(des)
+    if not des:
+        return
+    arr = (C.c_void_p * len(des))(*[d._h for d in des])
+    capi.check(des[0]._lib.psm_compute_batch(arr, len(des)), des[0]._h, "compute_batch")
