@@ -635,6 +635,7 @@ def main():
 
     # ---- CPU baseline: the oracle, driven like the reference pthreads path; its maps also check the timed path's ----
     cpu = None
+    tol_model_maps = None
     oracle_maps = None
     O = None
     sim = args.shard_sim > 1
@@ -653,6 +654,12 @@ def main():
         tcpu = time.perf_counter() - tcpu
         if sd == D:
             oracle_maps = [res["ldisp"], res["rdisp"]]
+            if dtype == "f32" and args.flags >= 0 and (args.flags & capi.PSM_FLAG_F32_TOL):
+                # the tolerance form is checked against ITS model (oracle variant F32_L1: the same one extra fp32 rounding per pair of
+                # taps) - bit for bit -, and the line says how many disparities differ from the canonical oracle's
+                with O.variant(O.VAR_F32_L1):
+                    rm_ = O.pipeline_f32(l, r, sd, threads=min(32, cores))
+                tol_model_maps = [rm_["ldisp"], rm_["rdisp"]]
         elif dtype == "f32" and not args.no_oracle_check:
             # (larger than 1080p x 256: the timed cpu_baseline is a sample of the disparities; the maps come from the oracle's
             # streaming form - same jobs and arithmetic, no volumes held - on up to 32 threads, outside every timed region)
@@ -683,6 +690,10 @@ def main():
         if use_dist or args.verify:
             ref_maps = single_gpu_maps()
         checks = check_maps(head, ref_maps, oracle_maps)
+        if tol_model_maps is not None and timed_maps is not None:
+            checks["tolerance_form"] = {"flag": "PSM_FLAG_F32_TOL", "maps_equal_its_oracle_model": bool(np.array_equal(timed_maps[0], tol_model_maps[0]) and
+                                                                                                   np.array_equal(timed_maps[1], tol_model_maps[1])),
+                                        "pixels_differing_from_the_canonical_oracle": checks.get("oracle_map_mismatches")}
         if B > 1:      # every pair of the batch against its own single-pair run through the three reference entry points
             okb = True
             for o_, (pl_, pr_) in zip(batch_all, batch_pairs):

@@ -53,7 +53,7 @@ enum {
                                    kernel stamps its own start / end instead (psm_filter_launch_times) */
     PSM_OPT_SEG_ROWS = 3,       /* rows per y-segment of the marching kernels (0 = auto)      */
     PSM_OPT_WAVES = 4,          /* waves (disparity slices) per workgroup: 1,2,4,8            */
-    PSM_OPT_FLAGS = 5,          /* PSM_FLAG_* bits below; no flag changes any result */
+    PSM_OPT_FLAGS = 5,          /* PSM_FLAG_* bits below; no flag but PSM_FLAG_F32_TOL changes any result */
     PSM_OPT_GRAPH = 6           /* 1: psm_compute_batch captures its launches once as a hipGraph and replays it while the batch
                                    (contexts, geometry, options) stays the same; ignored while PSM_OPT_PROFILE is on */
 };
@@ -76,7 +76,13 @@ enum psm_flag {
     PSM_FLAG_WMF_TWO_SWEEPS = 8388608,  /* ... at most 2 sweeps of its parallel form (test hook for the fall-back) */
     PSM_FLAG_WMF_NO_CACHE = 16777216,   /* ... without the cache of window weights (1.5 KB of device memory per invalid pixel):
                                            every evaluation forms its weights itself; same maps */
-    PSM_FLAGS_ALL = 128 | 4096 | 8192 | 1048576 | 2097152 | 4194304 | 8388608 | 16777216
+    PSM_FLAG_F32_TOL = 33554432,        /* float mode, default (select) path of psm_cost_filter: the TOLERANCE form of the fused kernel -
+                                           level 1 of its horizontal window sums in fp32 instead of fp64 (fewer four-cycle
+                                           instructions).  The ONLY flag that changes results: filtered costs within 1e-4 of
+                                           the default form's (measured: <= 4e-5, no disparity changed on the test pairs), not
+                                           bit-identical.  The storing form (psm_download_volume ...) stays exact; 8-bit mode
+                                           ignores the flag.  Off by default. */
+    PSM_FLAGS_ALL = 128 | 4096 | 8192 | 1048576 | 2097152 | 4194304 | 8388608 | 16777216 | 33554432
 };
 
 /* Number of usable HIP devices; 0 if none.  Replaces openCLdevicepoll()

@@ -235,6 +235,59 @@ static void box8_ws(const float *src, int H, int W, float *dst, double *hs)
     }
 }
 
+/* Tolerance-form MODELS of the per-slice box filters (psmo_set_variant; never the canon - they put a number on what a cheaper
+ * HIP form of the sliding trees would cost in accuracy before any kernel is written, tests/test_oracle.py):
+ *   PSMO_VAR_F32_L1   level 1 of the horizontal tree on the fp32 inputs: (double)(float)(t0 + t1) ...
+ *   PSMO_VAR_F32_L2   levels 1 and 2 in fp32
+ *   PSMO_VAR_RUNCOL   the vertical pass as OpenCV's running ColumnSum (fp64) instead of the balanced tree
+ * The guidance precompute (d-invariant) keeps the canonical filter. */
+static void box8_slice(const float *src, int H, int W, float *dst, double *hs)
+{
+    if (!(g_variant & (PSMO_VAR_F32_L1 | PSMO_VAR_F32_L2 | PSMO_VAR_RUNCOL)) || g_box_order == PSMO_BOX_OCV) { box8_ws(src, H, W, dst, hs); return; }
+    for (int y = 0; y < H; ++y) {
+        const float *s = src + (size_t)y * W;
+        double *h = hs + (size_t)y * W;
+        for (int x = 0; x < W; ++x) {
+            const float t0 = s[r101(x - 4, W)], t1 = s[r101(x - 3, W)], t2 = s[r101(x - 2, W)], t3 = s[r101(x - 1, W)],
+                        t4 = s[x], t5 = s[r101(x + 1, W)], t6 = s[r101(x + 2, W)], t7 = s[r101(x + 3, W)];
+            if (g_variant & PSMO_VAR_F32_L2) {
+                const float a = (t0 + t1) + (t2 + t3), b = (t4 + t5) + (t6 + t7);
+                h[x] = (double)a + (double)b;
+            } else if (g_variant & PSMO_VAR_F32_L1) {
+                const float a = t0 + t1, b = t2 + t3, c = t4 + t5, d = t6 + t7;
+                h[x] = ((double)a + (double)b) + ((double)c + (double)d);
+            } else h[x] = T8((double)t0, (double)t1, (double)t2, (double)t3, (double)t4, (double)t5, (double)t6, (double)t7);
+        }
+    }
+    if (g_variant & PSMO_VAR_RUNCOL) {
+        double *SUM = (double *)calloc((size_t)W, sizeof(double));
+        for (int j = 0; j < 7; ++j) {
+            const double *Sp = hs + (size_t)r101(j - 4, H) * W;
+            for (int x = 0; x < W; ++x) SUM[x] += Sp[x];
+        }
+        for (int y = 0; y < H; ++y) {
+            const double *Sp = hs + (size_t)r101(y + 3, H) * W, *Sm = hs + (size_t)r101(y - 4, H) * W;
+            float *o = dst + (size_t)y * W;
+            for (int x = 0; x < W; ++x) {
+                const double s0 = SUM[x] + Sp[x];
+                o[x] = (float)(s0 * (1.0 / 64));
+                SUM[x] = s0 - Sm[x];
+            }
+        }
+        free(SUM);
+        return;
+    }
+    for (int y = 0; y < H; ++y) {
+        const double *r0 = hs + (size_t)r101(y - 4, H) * W, *r1 = hs + (size_t)r101(y - 3, H) * W,
+                     *r2 = hs + (size_t)r101(y - 2, H) * W, *r3 = hs + (size_t)r101(y - 1, H) * W,
+                     *r4 = hs + (size_t)y * W, *r5 = hs + (size_t)r101(y + 1, H) * W,
+                     *r6 = hs + (size_t)r101(y + 2, H) * W, *r7 = hs + (size_t)r101(y + 3, H) * W;
+        float *o = dst + (size_t)y * W;
+        for (int x = 0; x < W; ++x)
+            o[x] = (float)(T8(r0[x], r1[x], r2[x], r3[x], r4[x], r5[x], r6[x], r7[x]) * (1.0 / 64));
+    }
+}
+
 void psmo_box8(const float *src, int H, int W, float *dst)
 {
     double *hs = (double *)malloc((size_t)H * W * sizeof(double));
@@ -281,11 +334,11 @@ static void guided_filter_ws(const float *rgb, const float *mean_I, const float 
     float *q = ws + 8 * N;          /* N */
 
     /* src/CVF.cpp:81-82 */
-    box8_ws(p, H, W, mean_p, hs);
+    box8_slice(p, H, W, mean_p, hs);
     /* src/CVF.cpp:86-89 */
     for (int c = 0; c < 3; ++c) {
         for (size_t i = 0; i < N; ++i) tmp[i] = rgb[c * N + i] * p[i];
-        box8_ws(tmp, H, W, mean_Ip + c * N, hs);
+        box8_slice(tmp, H, W, mean_Ip + c * N, hs);
     }
     /* src/CVF.cpp:91-95: cov_Ip = mean_Ip - mean_I*mean_p */
     for (int c = 0; c < 3; ++c)
@@ -340,9 +393,9 @@ static void guided_filter_ws(const float *rgb, const float *mean_I, const float 
         memcpy(ab_out + 3 * N, mean_p, N * sizeof(float));
     }
     /* src/CVF.cpp:157-163 */
-    box8_ws(mean_p, H, W, q, hs);
+    box8_slice(mean_p, H, W, q, hs);
     for (int c = 0; c < 3; ++c) {
-        box8_ws(a + c * N, H, W, tmp, hs);
+        box8_slice(a + c * N, H, W, tmp, hs);
         for (size_t i = 0; i < N; ++i) {
             float t = tmp[i] * rgb[c * N + i];
             q[i] = q[i] + t;

@@ -76,7 +76,9 @@ int psmo_get_box_order(void);
 
 /* Toolchain-dependent readings of two reference lines (see psm_oracle.c: myCostGrd2, guided_filter_ws).  0 = canon.
  * Used by tests only, to bound how far the reference binary can be from the canonical arithmetic. */
-enum { PSMO_VAR_FABS_DOUBLE = 1, PSMO_VAR_FMA_SOLVE = 2 };
+enum { PSMO_VAR_FABS_DOUBLE = 1, PSMO_VAR_FMA_SOLVE = 2,
+       /* tolerance-form models of the per-slice box filters (psm_oracle.c: box8_slice) */
+       PSMO_VAR_F32_L1 = 4, PSMO_VAR_F32_L2 = 8, PSMO_VAR_RUNCOL = 16 };
 void psmo_set_variant(int bits);
 int psmo_get_variant(void);
 

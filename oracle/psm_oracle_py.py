@@ -256,6 +256,7 @@ def pipeline_fgf(l_bgr, r_bgr, D, s=4, threads=8, want_volumes=False):
 
 BOX_TREE, BOX_OCV = 0, 1
 VAR_FABS_DOUBLE, VAR_FMA_SOLVE = 1, 2
+VAR_F32_L1, VAR_F32_L2, VAR_RUNCOL = 4, 8, 16     # tolerance-form models of the per-slice box filters (psm_oracle.c: box8_slice)
 
 
 class variant:

@@ -24,6 +24,7 @@ PSM_OPT_ASYNC, PSM_OPT_KERNEL_VARIANT, PSM_OPT_PROFILE, PSM_OPT_SEG_ROWS, PSM_OP
 PSM_FLAG_MATERIALISE_COSTS, PSM_FLAG_FGF_STORE, PSM_FLAG_STORE_FILTERED = 128, 4096, 8192
 PSM_FLAG_TWO_PHASE_ON, PSM_FLAG_TWO_PHASE_OFF = 1048576, 2097152
 PSM_FLAG_WMF_DATAFLOW, PSM_FLAG_WMF_TWO_SWEEPS, PSM_FLAG_WMF_NO_CACHE = 4194304, 8388608, 16777216
+PSM_FLAG_F32_TOL = 33554432
 
 # every symbol include/primesm_hip.h declares: (name, restype, argtypes)
 _vp, _i, _sz = C.c_void_p, C.c_int, C.c_size_t

@@ -68,9 +68,13 @@ __device__ __forceinline__ double rol4(double v)
 #ifndef PSM_XLANE_MODE
 #define PSM_XLANE_MODE 2   // measured on the fused filter at 1080p x 256: mode 0 5.29 ms, 1 4.76, 2 4.69, 3 5.98
 #endif
+// L1F32 (the tolerance form, PSM_FLAG_F32_TOL): level 1 of the tree on the fp32 inputs - one DPP move, one fp32 add and one
+// conversion instead of two conversions, a DPP move and an fp64 add.  One more fp32 rounding per pair of taps: not the oracle's
+// bits, max |dq| 1e-5 on Cones / Teddy and 4e-5 on the synthetic pairs, no WTA pixel changed (oracle model PSMO_VAR_F32_L1).
+template <bool L1F32 = false>
 __device__ __forceinline__ double hsum8(float v, int i1, int i2, int i4)
 {
-    double s2 = __dadd_rn((double)v, (double)(PSM_XLANE_MODE >= 1 ? rol1(v) : lane_get(v, i1)));
+    double s2 = L1F32 ? (double)__fadd_rn(v, rol1(v)) : __dadd_rn((double)v, (double)(PSM_XLANE_MODE >= 1 ? rol1(v) : lane_get(v, i1)));
     double s4 = __dadd_rn(s2, PSM_XLANE_MODE >= 2 ? rol2(s2) : lane_get(s2, i2));
     return __dadd_rn(s4, PSM_XLANE_MODE >= 3 ? rol4(s4) : lane_get(s4, i4));
 }

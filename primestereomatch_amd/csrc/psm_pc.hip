@@ -36,6 +36,7 @@
 #include "psm_kernels.h"
 #include "psm_cost.h"
 #include "psm_dev.h"
+#include "../../include/primesm_hip.h"
 
 #include <cstdlib>
 #include <mutex>
@@ -176,7 +177,9 @@ __device__ __forceinline__ int pc_slice(const PcSel &o, int i)
 // of oracle/psm_oracle.h, in one pass and without an 8-bit volume in memory.
 // BATCH (psm_compute_batch): blockIdx.z = stereo pair; every plane pointer of the pair comes from the device table `batch`
 // (uniform: scalar loads), so B Middlebury-size pairs fill the chip for many rounds of workgroups instead of 1.7.
-template <bool VEC4, int CVC, int MODE, bool U8 = false, bool BATCH = false>
+// TOL (PSM_FLAG_F32_TOL, float mode only): level 1 of the horizontal trees of both roles in fp32 (psm_dev.h: hsum8<true>) - within
+// the 1e-4 BASELINE.json states for float mode, not the oracle's bits; the default stays the bit-exact form.
+template <bool VEC4, int CVC, int MODE, bool U8 = false, bool BATCH = false, bool TOL = false>
 __global__ __launch_bounds__(64 * (PcLayout<MODE>::NA + PcLayout<MODE>::NB)) PSM_PC_ATTR
 __attribute__((amdgpu_waves_per_eu(MODE == 2 ? 4 : 1, MODE == 2 ? 4 : 8)))   // the key form capped at 128 VGPRs = four workgroups per CU
 void k_cvf_pc(
@@ -185,6 +188,7 @@ void k_cvf_pc(
     int ybeg, int yend, const float4 *__restrict__ Gothera, int d_begin, int DC, float *__restrict__ kcosta, unsigned *__restrict__ kdispa, int nbmax,
     PcSide side1, PcSel dyn, unsigned long long *__restrict__ ts, const PcPair *__restrict__ batch)
 {
+    static_assert(!TOL || (!U8 && MODE != 0), "the tolerance form exists for the float select forms only");
     if constexpr (BATCH) {
         static_assert(CVC == 3 && MODE != 0, "batched launches: both volumes per launch, select forms");
         const PcPair pp = batch[blockIdx.z];
@@ -365,10 +369,10 @@ void k_cvf_pc(
                 p = inb ? p : cb_;                                                                  \
             }                                                                                       \
         }                                                                                           \
-        double h0 = hsum8(p, i1, i2, i4);                                                           \
-        double h1 = hsum8(__fmul_rn(gin[K & 1].x, p), i1, i2, i4);                                  \
-        double h2 = hsum8(__fmul_rn(gin[K & 1].y, p), i1, i2, i4);                                  \
-        double h3 = hsum8(__fmul_rn(gin[K & 1].z, p), i1, i2, i4);                                  \
+        double h0 = hsum8<TOL>(p, i1, i2, i4);                                                      \
+        double h1 = hsum8<TOL>(__fmul_rn(gin[K & 1].x, p), i1, i2, i4);                             \
+        double h2 = hsum8<TOL>(__fmul_rn(gin[K & 1].y, p), i1, i2, i4);                             \
+        double h3 = hsum8<TOL>(__fmul_rn(gin[K & 1].z, p), i1, i2, i4);                             \
         double n0 = vstep<K>(t0, h0), n1 = vstep<K>(t1, h1), n2 = vstep<K>(t2, h2), n3 = vstep<K>(t3, h3); \
         float4 r = solve_ab(PSM_BOX(n0), PSM_BOX(n1), PSM_BOX(n2), PSM_BOX(n3), o2[LEANA ? 0 : (K & 1)], o3[LEANA ? 0 : (K & 1)], o4[LEANA ? 0 : (K & 1)]); \
         if ((DST) != nullptr && mvalid) (DST)[K * PC_MCOLS] = r;                                    \
@@ -511,10 +515,10 @@ void k_cvf_pc(
 #define PSM_STEP_PB(K)                                                                              \
     {                                                                                               \
         if (K < 3) a_nxt = *model_of(j0 + K + 1);     /* model row of the next feed, one step ahead */ \
-        double h0 = hsum8(a_cur.x, i1, i2, i4);                                                     \
-        double h1 = hsum8(a_cur.y, i1, i2, i4);                                                     \
-        double h2 = hsum8(a_cur.z, i1, i2, i4);                                                     \
-        double h3 = hsum8(a_cur.w, i1, i2, i4);                                                     \
+        double h0 = hsum8<TOL>(a_cur.x, i1, i2, i4);                                                \
+        double h1 = hsum8<TOL>(a_cur.y, i1, i2, i4);                                                \
+        double h2 = hsum8<TOL>(a_cur.z, i1, i2, i4);                                                \
+        double h3 = hsum8<TOL>(a_cur.w, i1, i2, i4);                                                \
         double n0 = vstep<K>(t0, h0), n1 = vstep<K>(t1, h1), n2 = vstep<K>(t2, h2), n3 = vstep<K>(t3, h3); \
         qv[K] = __fadd_rn(__fadd_rn(__fadd_rn(PSM_BOX(n3), __fmul_rn(PSM_BOX(n0), o1x[LEANB ? (K & 1) : K])),        \
                                     __fmul_rn(PSM_BOX(n1), o1y[LEANB ? (K & 1) : K])), __fmul_rn(PSM_BOX(n2), o1z[LEANB ? (K & 1) : K])); \
@@ -844,6 +848,7 @@ void launch_chunk_min(hipStream_t s, March m, int W, int H, int Dloc, void *scra
 void launch_cvf_select2(hipStream_t s, March m, const Guidance *g, int W, int H, int Dloc, int d_begin, void *scratch,
                         unsigned long long *ts, const uint8_t *const *p4, int sel, int step)
 {
+    const bool tol = !p4 && (m.flags & PSM_FLAG_F32_TOL);
     const PcPlan pl = pc_plan(W, m.rows(H), Dloc, m.seg_rows, PC_PLANES | PC_BOTH);
     const PcSel ps = {sel, step, pl.nxcd, 0, Dloc, 0};
     float *kcost0 = (float *)scratch;
@@ -856,6 +861,10 @@ void launch_cvf_select2(hipStream_t s, March m, const Guidance *g, int W, int H,
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_cvf_pc<false, 3, 1, true>), grid, blk, 0, s, (const float *)p4[0], (float *)const_cast<uint8_t *>(p4[1]),
                            (const float4 *)g[0].g1, (const float4 *)g[0].g2, (const float4 *)g[0].g3, (const float2 *)g[0].g4, W, H, Dloc, pl.ngroups,
                            pl.nsegs, pl.seg_rows, m.y0(H), m.y1(H), (const float4 *)g[1].g1, d_begin, pl.DC, kcost0, kdisp0, pl.nbmax, s1, ps, ts, (const PcPair *)nullptr);
+    else if (tol)
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_cvf_pc<false, 3, 1, false, false, true>), grid, blk, 0, s, (const float *)nullptr, (float *)nullptr, (const float4 *)g[0].g1,
+                           (const float4 *)g[0].g2, (const float4 *)g[0].g3, (const float2 *)g[0].g4, W, H, Dloc, pl.ngroups, pl.nsegs, pl.seg_rows, m.y0(H), m.y1(H),
+                           (const float4 *)g[1].g1, d_begin, pl.DC, kcost0, kdisp0, pl.nbmax, s1, ps, ts, (const PcPair *)nullptr);
     else
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_cvf_pc<false, 3, 1>), grid, blk, 0, s, (const float *)nullptr, (float *)nullptr, (const float4 *)g[0].g1,
                            (const float4 *)g[0].g2, (const float4 *)g[0].g3, (const float2 *)g[0].g4, W, H, Dloc, pl.ngroups, pl.nsegs, pl.seg_rows, m.y0(H), m.y1(H),
@@ -888,6 +897,10 @@ void launch_cvf_select_keys2(hipStream_t s, March m, const Guidance *g, int W, i
                        (float *)(keys + HW), nullptr};
     if (p4)
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_cvf_pc<false, 3, 2, true>), grid, blk, 0, s, (const float *)p4[0], (float *)const_cast<uint8_t *>(p4[1]),
+                           (const float4 *)g[0].g1, (const float4 *)g[0].g2, (const float4 *)g[0].g3, (const float2 *)g[0].g4, W, H, Dloc, pl.ngroups,
+                           pl.nsegs, pl.seg_rows, m.y0(H), m.y1(H), (const float4 *)g[1].g1, d_begin, 1, (float *)keys, (unsigned *)nullptr, 0, s1, ps, ts, (const PcPair *)nullptr);
+    else if (m.flags & PSM_FLAG_F32_TOL)
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_cvf_pc<false, 3, 2, false, false, true>), grid, blk, 0, s, (const float *)nullptr, (float *)nullptr,
                            (const float4 *)g[0].g1, (const float4 *)g[0].g2, (const float4 *)g[0].g3, (const float2 *)g[0].g4, W, H, Dloc, pl.ngroups,
                            pl.nsegs, pl.seg_rows, m.y0(H), m.y1(H), (const float4 *)g[1].g1, d_begin, 1, (float *)keys, (unsigned *)nullptr, 0, s1, ps, ts, (const PcPair *)nullptr);
     else
