@@ -34,7 +34,11 @@ typedef struct psm_ctx psm_ctx;
 
 /* element type of the cost volume ("float mode" / "8-bit char mode") */
 enum { PSM_F32 = 0, PSM_U8 = 1 };
-/* element type of host images handed to psm_upload_pair */
+/* element type of host images handed to psm_upload_pair.  PSM_IMG_F32 images are used as they are (the reference hands
+ * DispEst images already scaled by 1/255, src/StereoMatch.cpp:195-198).  The default (select) forms of psm_cost_filter carry the
+ * 1/64 of the box filters as one exact power of two at the end, which is bit-identical to the reference's per-sum scaling while
+ * no intermediate under- or overflows: float images whose non-zero magnitudes leave 2^-10 .. 2^10 (measured on the device when
+ * they arrive) make psm_cost_filter run its storing form - the reference's arithmetic op for op, ~25 % slower - automatically. */
 enum { PSM_IMG_U8 = 0, PSM_IMG_F32 = 1 };
 /* volume side: the reference's buffers CV_LCV / CV_RCV (include/ComFunc.h:65) */
 enum { PSM_LEFT = 0, PSM_RIGHT = 1 };
@@ -272,6 +276,9 @@ int psm_upload_maps(psm_ctx *ctx, const uint8_t *lmap, const uint8_t *rmap, cons
 /* Copy slices [d0,d1) (global disparity numbers) of a volume to/from dense host memory
  * [d1-d0][H][W]; element type = the context's dtype. */
 int psm_download_volume(psm_ctx *ctx, int side, int d0, int d1, void *host);
+/* Uploaded float costs may have any scale: slices whose non-zero magnitudes leave 2^-60 .. 2^60 (measured on the device) make
+ * the following psm_cost_filter run its storing form (see PSM_IMG_F32 above) - same results as the reference arithmetic at any
+ * scale, never a silent difference between the two forms. */
 int psm_upload_volume(psm_ctx *ctx, int side, int d0, int d1, const void *host);
 /* After psm_cost_filter: the a0,a1,a2,b intermediates of the LAST filtered side (right) are
  * still in the scratch buffer; psm_filter_stage_a(side) runs only the first half of the

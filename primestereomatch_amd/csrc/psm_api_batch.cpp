@@ -35,6 +35,14 @@ extern "C" int psm_compute_batch(psm_ctx *const *ctxs, int n)
     }
     if (bind(c0)) return 1;
     const double t0 = now_us();
+    for (int i = 0; i < n; ++i) {        // (float images staged asynchronously bring their range with them)
+        psm_ctx *c = ctxs[i];
+        if (c->next_depth >= 0 && c->range_next_pending) {
+            PSM_HIP(c0, hipEventSynchronize(c->ev_up));
+            if (!range_inside(c, 1, -PSM_IMG_EXP, PSM_IMG_EXP)) return fail(c0, "psm_compute_batch: the float images of context %d are outside the select forms' domain (2^-10 .. 2^10)", i);
+        } else if (c->next_depth < 0 && !scaled_forms_ok(c))
+            return fail(c0, "psm_compute_batch: the float images of context %d are outside the select forms' domain (2^-10 .. 2^10); use the single-pair entry points", i);
+    }
     const int W = c0->W, H = c0->H, Dloc = c0->Dloc;
     hipStream_t s = c0->stream;
     if (!c0->ev_batch) PSM_HIP(c0, hipEventCreateWithFlags(&c0->ev_batch, hipEventDisableTiming));

@@ -126,6 +126,8 @@ void free_all(psm_ctx *c)
     (void)hipFree(c->pc_ts);
     (void)hipFree(c->fgf);
     if (c->batch_graph) (void)hipGraphExecDestroy(c->batch_graph);
+    (void)hipFree(c->range_dev);
+    if (c->range_pin) (void)hipHostFree(c->range_pin);
     (void)hipFree(c->batch_tab);
     if (c->batch_pin) (void)hipHostFree(c->batch_pin);
     for (hipEvent_t e : {c->ev_batch, c->ev_tab[0], c->ev_tab[1]})
@@ -182,6 +184,28 @@ int check_slices(psm_ctx *c, const char *who, int side, int d0, int d1)
 }  // namespace
 
 namespace psm {
+
+int range_enqueue(psm_ctx *c, hipStream_t stream, int slot, const float *p0, size_t n0, const float *p1, size_t n1)
+{
+    if (!c->range_dev) {
+        PSM_HIP(c, hipMalloc((void **)&c->range_dev, 8 * sizeof(unsigned)));
+        PSM_HIP(c, hipHostMalloc((void **)&c->range_pin, 8 * sizeof(unsigned), hipHostMallocDefault));
+    }
+    c->range_pin[2 * slot] = 0u; c->range_pin[2 * slot + 1] = 255u;
+    PSM_HIP(c, hipMemsetD32Async((hipDeviceptr_t)(c->range_dev + 2 * slot), 0, 1, stream));
+    PSM_HIP(c, hipMemsetD32Async((hipDeviceptr_t)(c->range_dev + 2 * slot + 1), 255, 1, stream));
+    if (p0 && n0) launch_range_f32(stream, p0, n0, c->range_dev + 2 * slot);
+    if (p1 && n1) launch_range_f32(stream, p1, n1, c->range_dev + 2 * slot);
+    PSM_HIP(c, hipMemcpyAsync(c->range_pin + 2 * slot, c->range_dev + 2 * slot, 2 * sizeof(unsigned), hipMemcpyDeviceToHost, stream));
+    return 0;
+}
+
+bool range_inside(const psm_ctx *c, int slot, int lo_exp, int hi_exp)
+{
+    const unsigned emax = c->range_pin[2 * slot], emin = c->range_pin[2 * slot + 1];
+    if (emax == 0 && emin == 255) return true;                    // all zero
+    return (int)emax - 127 <= hi_exp && (int)emin - 127 >= lo_exp;
+}
 
 // Host rows -> packed device rows on the context's stream.  hipMemcpy2D takes a row-by-row path when the row length is not a
 // multiple of 4 bytes (measured: 6.5 ms for a 450 x 375 x 3 pair, 18.9 ms for 1919 x 1080 x 3, against 0.05 / 0.25 ms): contiguous
@@ -346,11 +370,16 @@ int psm_upload_pair(psm_ctx *c, const void *l, const void *r, int channels, size
     const void *src[2] = {l, r};
     for (int s = 0; s < 2; ++s)
         if (h2d_rows(c, c->raw[s], src[s], row, stride_bytes, c->H)) return 1;
+    // float images are used as they are: their range decides whether the select forms' scaled window sums apply
+    const size_t nf = (size_t)c->W * c->H * 3;
+    if (depth == PSM_IMG_F32 && range_enqueue(c, c->stream, 0, (const float *)c->raw[0], nf, (const float *)c->raw[1], nf)) return 1;
     // the copy reads caller memory: always complete it before returning (CVC_cl::buildCV copies
     // out of the cv::Mats synchronously, src/CVC_cl.cpp:113-160)
     PSM_HIP(c, hipStreamSynchronize(c->stream));
     c->next_depth = -1;                 // a pair staged by psm_upload_pair_async is superseded
+    c->range_next_pending = false;
     adopt_new_pair(c, depth);
+    c->img_domain_ok = depth != PSM_IMG_F32 || range_inside(c, 0, -PSM_IMG_EXP, PSM_IMG_EXP);
     return 0;
 }
 
@@ -388,6 +417,12 @@ int psm_upload_pair_async(psm_ctx *c, const void *l, const void *r, int channels
     PSM_HIP(c, hipStreamWaitEvent(c->copy_stream, c->ev_free, 0));
     for (int s = 0; s < 2; ++s)
         PSM_HIP(c, hipMemcpyAsync(c->raw_next[s], stage + s * c->raw_bytes, img, hipMemcpyHostToDevice, c->copy_stream));
+    c->range_next_pending = false;
+    if (depth == PSM_IMG_F32) {         // (measured behind the copy on the copy stream; read when the pair is adopted)
+        const size_t nf = (size_t)c->W * c->H * 3;
+        if (range_enqueue(c, c->copy_stream, 1, (const float *)c->raw_next[0], nf, (const float *)c->raw_next[1], nf)) return 1;
+        c->range_next_pending = true;
+    }
     PSM_HIP(c, hipEventRecord(c->ev_up, c->copy_stream));
     PSM_HIP(c, hipEventRecord(c->ev_stage[slot], c->copy_stream));
     c->up_recorded = true;
@@ -421,7 +456,12 @@ int psm_upload_volume(psm_ctx *c, int side, int d0, int d1, const void *host)
     if (ensure_vol(c, side)) return 1;
     const size_t S = (size_t)c->W * c->H * velem(c);
     PSM_HIP(c, hipMemcpyAsync((char *)c->vol[side] + (size_t)(d0 - c->d0) * S, host, (size_t)(d1 - d0) * S, hipMemcpyHostToDevice, c->stream));
+    if (c->dtype == PSM_F32 && range_enqueue(c, c->stream, 2 + side, (const float *)((char *)c->vol[side] + (size_t)(d0 - c->d0) * S),
+                                             (size_t)(d1 - d0) * c->W * c->H, nullptr, 0)) return 1;
     PSM_HIP(c, hipStreamSynchronize(c->stream));
+    // costs of arbitrary scale: outside 2^-60 .. 2^60 the filter of this volume runs the storing form (sticky until the next
+    // psm_cost_construct replaces the volume)
+    if (c->dtype == PSM_F32 && !range_inside(c, 2 + side, -PSM_VOL_EXP, PSM_VOL_EXP)) c->vol_domain_ok[side] = false;
     c->have_cost = true;
     c->have_maps = false;
     c->raw_rows[side] = psm_ctx::RAW_ALL;

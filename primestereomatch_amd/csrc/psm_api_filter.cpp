@@ -118,10 +118,17 @@ int ensure_gf_scratch(psm_ctx *c, size_t bytes)
 int adopt_staged_pair(psm_ctx *c)
 {
     if (c->next_depth < 0) return 0;
+    bool ok = true;
+    if (c->range_next_pending) {        // float images: their range arrived with the copy (long done in a running frame loop)
+        PSM_HIP(c, hipEventSynchronize(c->ev_up));
+        ok = range_inside(c, 1, -PSM_IMG_EXP, PSM_IMG_EXP);
+        c->range_next_pending = false;
+    }
     PSM_HIP(c, hipStreamWaitEvent(c->stream, c->ev_up, 0));
     std::swap(c->raw[0], c->raw_next[0]);
     std::swap(c->raw[1], c->raw_next[1]);
     adopt_new_pair(c, c->next_depth);
+    c->img_domain_ok = ok;
     c->next_depth = -1;
     return 0;
 }
@@ -165,7 +172,7 @@ int filter_u8_stored(psm_ctx *c, int side)
     launch_u8_to_f32(c->stream, (const uint8_t *)c->vol[side], c->fvol, V);
     {
         Prof p(c, PSM_K_CVF_F);
-        launch_cvf_fused(c->stream, c->march, c->fvol, c->spare, c->g[side], c->W, c->H, c->Dloc, 0, c->H, c->g[1 - side].g1, c->d0, 0);
+        launch_cvf_fused(c->stream, c->march, c->fvol, c->spare, c->g[side], c->W, c->H, c->Dloc, 0, c->H, c->g[1 - side].g1, c->d0, 0, next_pc_stamp(c));
     }
     launch_f32_to_u8(c->stream, c->spare, (uint8_t *)c->vol[side], V);   // q8 = sat_u8(rintf(q * 255))
     return check_launch(c, "cvf (8-bit, storing form)");
@@ -199,11 +206,11 @@ int materialize(psm_ctx *c, int side)
         if (c->raw_rows[side] == psm_ctx::RAW_ALL) {          // materialised costs in vol[side]: out of place
             if (ensure_spare(c)) return 1;
             launch_cvf_fused(c->stream, c->march, (const float *)c->vol[side], c->spare, c->g[side], c->W, c->H, c->Dloc, 0, c->H,
-                             c->g[1 - side].g1, c->d0, 0);
+                             c->g[1 - side].g1, c->d0, 0, next_pc_stamp(c));
             std::swap(*(float **)&c->vol[side], c->spare);
         } else {
             launch_cvf_fused(c->stream, c->march, nullptr, (float *)c->vol[side], c->g[side], c->W, c->H, c->Dloc, 0, c->H,
-                             c->g[1 - side].g1, c->d0, 1 + side);
+                             c->g[1 - side].g1, c->d0, 1 + side, next_pc_stamp(c));
         }
         c->gf_virtual[side] = false;
         c->raw_rows[side] = psm_ctx::RAW_ALL;                 // vol[side] now holds real (filtered) data
@@ -239,7 +246,7 @@ int filter_side(psm_ctx *c, int side, bool stage_b)
     // Default: the fused kernel in "select" mode - the WTA over the local slices runs inside the filter, the filtered
     // volume stays virtual (PSM_FLAG_STORE_FILTERED forces the storing form; the direct variant is its own filter)
     const bool sel8 = c->dtype == PSM_U8 && c->raw_rows[side] != psm_ctx::RAW_ALL;   // 8-bit mode: select form only with costs on the fly
-    if (stage_b && (c->dtype == PSM_F32 || sel8) && c->opt_variant == 0 && !(c->march.flags & PSM_FLAG_STORE_FILTERED)) {
+    if (stage_b && (c->dtype == PSM_F32 || sel8) && c->opt_variant == 0 && !(c->march.flags & PSM_FLAG_STORE_FILTERED) && scaled_forms_ok(c)) {
         const bool lazy = c->raw_rows[side] != psm_ctx::RAW_ALL;
         const PcPlan pl = pc_plan(W, c->march.rows(H), c->Dloc, c->march.seg_rows, PC_PLANES);
         if (ensure_gf_scratch(c, pl.scratch_bytes())) return 1;
@@ -273,7 +280,7 @@ int filter_side(psm_ctx *c, int side, bool stage_b)
             // filtered volume is written straight into it
             {
                 Prof p(c, PSM_K_CVF_F);
-                launch_cvf_fused(c->stream, c->march, nullptr, fv, c->g[side], W, H, c->Dloc, 0, H, c->g[1 - side].g1, c->d0, 1 + side);
+                launch_cvf_fused(c->stream, c->march, nullptr, fv, c->g[side], W, H, c->Dloc, 0, H, c->g[1 - side].g1, c->d0, 1 + side, next_pc_stamp(c));
             }
             c->raw_rows[side] = psm_ctx::RAW_ALL;   // vol[side] now holds real (filtered) data
             return check_launch(c, "cvf (fused, lazy costs)");
@@ -283,7 +290,7 @@ int filter_side(psm_ctx *c, int side, bool stage_b)
         float *out = c->spare;
         {
             Prof p(c, PSM_K_CVF_F);
-            launch_cvf_fused(c->stream, c->march, fv, out, c->g[side], W, H, c->Dloc, 0, H, c->g[1 - side].g1, c->d0, 0);
+            launch_cvf_fused(c->stream, c->march, fv, out, c->g[side], W, H, c->Dloc, 0, H, c->g[1 - side].g1, c->d0, 0, next_pc_stamp(c));
         }
         if (c->dtype == PSM_U8) {
             launch_f32_to_u8(c->stream, out, (uint8_t *)c->vol[side], V);   // q8 = sat_u8(rintf(q * 255))
@@ -312,7 +319,7 @@ int filter_side(psm_ctx *c, int side, bool stage_b)
 // launches per frame instead of twelve.  The default path (costs built on the fly, both sides fresh).
 bool can_filter_both(const psm_ctx *c)
 {
-    return c->opt_variant == 0 && !(c->march.flags & PSM_FLAG_STORE_FILTERED) &&
+    return c->opt_variant == 0 && !(c->march.flags & PSM_FLAG_STORE_FILTERED) && scaled_forms_ok(c) &&
            c->raw_rows[0] != psm_ctx::RAW_ALL && c->raw_rows[1] != psm_ctx::RAW_ALL && !c->gf_virtual[0] && !c->gf_virtual[1] &&
            !c->fgf_virtual[0] && !c->fgf_virtual[1];
 }
@@ -410,6 +417,7 @@ int psm_cost_construct(psm_ctx *c)
     if (c->ev_free) PSM_HIP(c, hipEventRecord(c->ev_free, c->stream));   // the staged images have been read: their slot may be refilled
     c->fgf_virtual[0] = c->fgf_virtual[1] = 0;   // a new cost volume replaces whatever was pending
     c->gf_virtual[0] = c->gf_virtual[1] = false;
+    c->vol_domain_ok[0] = c->vol_domain_ok[1] = true;   // (uploaded volumes are gone; the costs now follow from the images)
     c->maps_early = nullptr;
     for (int s = 0; s < 2; ++s) {
         if (lazy) {
@@ -444,7 +452,7 @@ int psm_cost_filter(psm_ctx *c)
         if (filter_both(c)) return 1;
     } else {
         if (striped) return fail(c, "psm_cost_filter: a row stripe (psm_set_rows) needs the default select form of the filter "
-                                    "(no variant / storing flag, cost volumes not materialised)");
+                                    "(no variant / storing flag, cost volumes not materialised, images / volumes inside the select forms' domain)");
         for (int s = 0; s < 2; ++s)
             if (filter_side(c, s, true)) return 1;
     }

@@ -110,6 +110,15 @@ struct psm_ctx {
     enum { RAW_ALL = 0, RAW_NONE = 1 };
     int raw_rows[2] = {RAW_ALL, RAW_ALL};
 
+    // Domain of the scaled window sums (select forms of the fused kernel carry the 1/64 of both box filters as one 2^-12 at the
+    // end: bit-identical to the per-sum scaling only while no intermediate under- or overflows).  8-bit images are always
+    // inside; float images (non-zero |I| within 2^-10 .. 2^10) and uploaded cost volumes (2^-60 .. 2^60) are measured on the
+    // device when they arrive; outside, psm_cost_filter runs the storing form (the oracle's arithmetic op for op) + k_wta.
+    bool img_domain_ok = true, img_next_domain_ok = true, vol_domain_ok[2] = {true, true};
+    unsigned *range_dev = nullptr;      // [4][2] exponent ranges (current pair, staged pair, volume L, volume R), on first use
+    unsigned *range_pin = nullptr;      // page-locked copy
+    bool range_next_pending = false;    // the staged pair's range is still on its way (read when the pair is adopted)
+
     // options
     int opt_async = 0, opt_variant = 0, opt_profile = 0, opt_graph = 0;
     psm::March march = {0, 4, 0};
@@ -179,6 +188,11 @@ int fgf_flush(psm_ctx *c, int side);
 int materialize(psm_ctx *c, int side);
 int adopt_staged_pair(psm_ctx *c);               // the pair psm_upload_pair_async staged becomes the current one
 int ensure_gf_scratch(psm_ctx *c, size_t bytes);
+// psm_api_core.cpp: measure the exponent range of n floats on `stream` into slot (0..3) of the context's range buffers
+int range_enqueue(psm_ctx *c, hipStream_t stream, int slot, const float *p0, size_t n0, const float *p1, size_t n1);
+bool range_inside(const psm_ctx *c, int slot, int lo_exp, int hi_exp);     // after the stream has been synchronised
+inline bool scaled_forms_ok(const psm_ctx *c) { return c->img_domain_ok && c->vol_domain_ok[0] && c->vol_domain_ok[1]; }
+constexpr int PSM_IMG_EXP = 10, PSM_VOL_EXP = 60;
 unsigned long long *next_pc_stamp(psm_ctx *c);   // slot of the next k_cvf_pc launch (NULL unless PSM_OPT_PROFILE 2)
 
 // psm_api_select.cpp

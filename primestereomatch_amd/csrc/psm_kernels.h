@@ -43,6 +43,8 @@ void launch_prep_batch(hipStream_t s, const PcPair *tab, int npairs, size_t pitc
 void launch_guidance_batch(hipStream_t s, const PcPair *tab, int npairs, int W, int H);
 void launch_merge_batch(hipStream_t s, const PcPair *tab, int npairs, int W, int H);   // keys -> maps of every pair
 
+// biased-exponent range of n floats: out[0] = max, out[1] = min over the non-zero values (initialise out to {0, 255})
+void launch_range_f32(hipStream_t s, const float *p, size_t n, unsigned *out);
 // image -> g1 (planarise, scale, gray, x-gradient).  src: device copy of the interleaved image.
 void launch_prep(hipStream_t s, const void *src, size_t pitch, int depth_f32, int W, int H, float4 *g1, const void *src1 = nullptr,
                  float4 *g11 = nullptr);
@@ -60,7 +62,7 @@ void launch_cvf_b_direct(hipStream_t s, const float4 *ab, float *vol, Guidance g
 // fused stage A+B: vin -> vout (distinct buffers), output rows [ybeg, yend) within [4, H-3)
 // cvc_mode 0: read the cost slices from vin; 1/2: build the left/right costs on the fly from the g1 planes
 void launch_cvf_fused(hipStream_t s, March m, const float *vin, float *vout, Guidance g, int W, int H, int Dloc,
-                      int ybeg, int yend, const float4 *g1_other, int d_begin, int cvc_mode);
+                      int ybeg, int yend, const float4 *g1_other, int d_begin, int cvc_mode, unsigned long long *ts = nullptr);
 // The same kernel with the winner-takes-all fused in ("select" forms): the filtered volume is never written.
 //   plane form: per pixel the running minimum over chunks of DC slices in scratch planes -> launch_chunk_min* -> packed WTA keys
 //   key form:   64-bit atomicMin on a key plane that already holds good bounds (second phase of the two-phase selection)

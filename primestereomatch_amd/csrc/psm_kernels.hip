@@ -70,6 +70,33 @@ void launch_prep(hipStream_t s, const void *src, size_t pitch, int depth_f32, in
 }
 
 // ------------------------------------------------------------------------------------------
+// Range of a float buffer as biased exponents: out[0] = max exponent, out[1] = min exponent over the non-zero values
+// (caller initialises {0, 255}; NaN / inf count as 255, subnormals as 0).  Guards the domain of the scaled window sums of the
+// select forms (psm_pc.hip): float images and uploaded cost volumes outside it run the storing form.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_range_f32(const float *__restrict__ p, size_t n, unsigned *out)
+{
+    __shared__ unsigned smax[4], smin[4];
+    unsigned emax = 0, emin = 255;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const unsigned b = __float_as_uint(p[i]) & 0x7fffffffu;
+        if (b) { const unsigned e = b >> 23; emax = max(emax, e); emin = min(emin, e); }
+    }
+    for (int o = 32; o > 0; o >>= 1) { emax = max(emax, (unsigned)__shfl_xor((int)emax, o)); emin = min(emin, (unsigned)__shfl_xor((int)emin, o)); }
+    if ((threadIdx.x & 63) == 0) { smax[threadIdx.x >> 6] = emax; smin[threadIdx.x >> 6] = emin; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        atomicMax(out, max(max(smax[0], smax[1]), max(smax[2], smax[3])));
+        atomicMin(out + 1, min(min(smin[0], smin[1]), min(smin[2], smin[3])));
+    }
+}
+void launch_range_f32(hipStream_t s, const float *p, size_t n, unsigned *out)
+{
+    const unsigned blocks = (unsigned)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
+    hipLaunchKernelGGL(k_range_f32, dim3(blocks ? blocks : 1), dim3(256), 0, s, p, n, out);
+}
+
+// ------------------------------------------------------------------------------------------
 // guidance precompute (CVF::preprocess, src/CVF.cpp:44-70, + the d-invariant part of the solve,
 // src/CVF.cpp:120-132): 9 channels I0,I1,I2,I0I0,I0I1,I0I2,I1I1,I1I2,I2I2.  One wave marches a 56-column strip down a
 // segment of rows with nine sliding trees - the same machinery as the volume kernels.  (Round 1's two-pass form

@@ -792,7 +792,7 @@ static int pc_blocks(const PcPlan &pl, int chunks) { return pl.nxcd * ((pl.ngrou
 
 // Storing form (MODE 0): vin (or, cvc_mode 1 / 2, the costs built on the fly) -> vout, one slice per workgroup.
 void launch_cvf_fused(hipStream_t s, March m, const float *vin, float *vout, Guidance gd, int W, int H, int Dloc,
-                      int ybeg, int yend, const float4 *g1_other, int d_begin, int cvc_mode)
+                      int ybeg, int yend, const float4 *g1_other, int d_begin, int cvc_mode, unsigned long long *ts)
 {
     if (yend <= ybeg) return;
     const PcPlan pl = pc_plan(W, yend - ybeg, Dloc, m.seg_rows, PC_STORE);
@@ -800,7 +800,7 @@ void launch_cvf_fused(hipStream_t s, March m, const float *vin, float *vout, Gui
 #define PSM_LAUNCH_PC(V4, CV)                                                                                              \
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_cvf_pc<V4, CV, 0>), grid, blk, 0, s, vin, vout, (const float4 *)gd.g1,            \
                        (const float4 *)gd.g2, (const float4 *)gd.g3, (const float2 *)gd.g4, W, H, Dloc, pl.ngroups, pl.nsegs, \
-                       pl.seg_rows, ybeg, yend, g1_other, d_begin, 1, (float *)nullptr, (unsigned *)nullptr, 0, PcSide{}, PcSel{0, 1, pl.nxcd, 0, Dloc, 0}, (unsigned long long *)nullptr, (const PcPair *)nullptr)
+                       pl.seg_rows, ybeg, yend, g1_other, d_begin, 1, (float *)nullptr, (unsigned *)nullptr, 0, PcSide{}, PcSel{0, 1, pl.nxcd, 0, Dloc, 0}, ts, (const PcPair *)nullptr)
     const bool v4 = (W & 3) == 0;
     if (cvc_mode == 1) { if (v4) PSM_LAUNCH_PC(true, 1); else PSM_LAUNCH_PC(false, 1); }
     else if (cvc_mode == 2) { if (v4) PSM_LAUNCH_PC(true, 2); else PSM_LAUNCH_PC(false, 2); }

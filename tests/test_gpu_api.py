@@ -238,3 +238,67 @@ def test_async_download_is_not_raced_by_later_map_writers(psm, oracle):
             assert np.array_equal(lm, raw[0]) and np.array_equal(rm, raw[1]), writer
             after = [m.copy() for m in de.download_maps()]
             assert not (np.array_equal(after[0], raw[0]) and np.array_equal(after[1], raw[1])), writer   # the writer did run
+
+
+def _forms(de):
+    return sorted({f for _, f in de.filter_launch_times()})
+
+
+@pytest.mark.parametrize("k,stored", [(-120, True), (100, True), (58, False), (-55, False)])
+def test_scaled_sums_guard_on_uploaded_volumes(psm, oracle, k, stored):
+    """Round-3 verdict: the select forms' scaled window sums have a domain; a volume outside it (2^-120, 2^100) must run the
+    storing form - the oracle's arithmetic at any scale - instead of silently disagreeing with it."""
+    from primestereomatch_amd import capi
+    rng = np.random.default_rng(3)
+    H, W, D = 40, 130, 6
+    l = rng.integers(0, 256, size=(H, W, 3), dtype=np.uint8)
+    r = rng.integers(0, 256, size=(H, W, 3), dtype=np.uint8)
+    vol = ((rng.random((D, H, W), dtype=np.float32) * 2.7 + 0.1) * np.float32(2.0 ** k)).astype(np.float32)
+    q = []
+    for img in (l, r):
+        rgb, mean, var = oracle.cvf_preprocess(oracle.u8_to_f32(img))
+        q.append(np.stack([oracle.guided_filter(rgb, mean, var, vol[d]) for d in range(D)]))
+    with psm.DispEst(l, r, D) as de:
+        de.set_option(capi.PSM_OPT_PROFILE, 2)
+        de.upload_volume(0, vol); de.upload_volume(1, vol)
+        de.filter_launch_times()
+        de.CostFilter_GPU(); de.DispSelect_GPU()
+        forms = _forms(de)
+        assert (forms == [0]) == stored, forms                         # 0 = storing form, 1 / 2 = select forms
+        assert np.array_equal(de.download_volume(0), q[0]) and np.array_equal(de.download_volume(1), q[1])
+        assert np.array_equal(de.lDisMap, oracle.wta(q[0])) and np.array_equal(de.rDisMap, oracle.wta(q[1]))
+        de.CostConst_GPU(); de.filter_launch_times()                   # new costs from the images: the guard is lifted
+        de.CostFilter_GPU(); de.DispSelect_GPU()
+        assert 0 not in _forms(de)
+
+
+def test_scaled_sums_guard_on_float_images(psm, oracle):
+    """Float images as the reference hands them over (x 1/255, src/StereoMatch.cpp:195-198) stay on the select path and give
+    the u8 upload's maps; images far outside [2^-10, 2^10] go through the storing form - blocking and asynchronous upload."""
+    from primestereomatch_amd import capi, synth
+    W, H, D = 150, 70, 12
+    l, r, _ = synth.make_pair(W, H, D, seed=8)
+    ref = oracle.pipeline_f32(l, r, D, threads=4)
+    lf, rf = oracle.u8_to_f32(l), oracle.u8_to_f32(r)
+    big = np.float32(2.0 ** 14)
+    with psm.DispEst(lf, rf, D) as de:
+        de.set_option(capi.PSM_OPT_PROFILE, 2)
+        de.CostConst_GPU(); de.CostFilter_GPU(); de.DispSelect_GPU()
+        assert 0 not in _forms(de)
+        assert np.array_equal(de.lDisMap, ref["ldisp"]) and np.array_equal(de.rDisMap, ref["rdisp"])
+        de.setInputImages(lf * big, rf * big)                          # outside: storing form
+        de.CostConst_GPU(); de.CostFilter_GPU(); de.DispSelect_GPU()
+        assert _forms(de) == [0]
+        scaled_maps = [de.lDisMap.copy(), de.rDisMap.copy()]
+        de.setInputImages_async(lf, rf)                                # next frame inside again, staged asynchronously
+        de.CostConst_GPU(); de.CostFilter_GPU(); de.DispSelect_GPU()
+        assert 0 not in _forms(de)
+        assert np.array_equal(de.lDisMap, ref["ldisp"]) and np.array_equal(de.rDisMap, ref["rdisp"])
+        de.setInputImages_async(lf * big, rf * big)
+        de.CostConst_GPU(); de.CostFilter_GPU(); de.DispSelect_GPU()
+        assert _forms(de) == [0]
+        assert np.array_equal(de.lDisMap, scaled_maps[0]) and np.array_equal(de.rDisMap, scaled_maps[1])
+    with psm.DispEst(lf * big, rf * big, D) as de:                     # (the explicit storing flag gives the same maps)
+        de.set_option(capi.PSM_OPT_FLAGS, capi.PSM_FLAG_STORE_FILTERED)
+        de.CostConst_GPU(); de.CostFilter_GPU(); de.DispSelect_GPU()
+        assert np.array_equal(de.lDisMap, scaled_maps[0]) and np.array_equal(de.rDisMap, scaled_maps[1])
