@@ -584,9 +584,18 @@ def main():
     algb = dict(alg)
     if select_mode:
         algb["cvf_fused"] = alg["pipeline"]
-    if args.fgf:   # per launch pair (setup + model + smooth + apply of one side): cost read at 1/s^2, model planes, q write
-        algb["cvf_fgf"] = 4.0 + 68.0 / (args.fgf * args.fgf)
-    dom = max(("cvf_fgf",) if args.fgf else ("cvf_fused", "cvf_a"), key=lambda k: kern.get(k, {"avg_ms": 0})["avg_ms"])
+    pipe_alg = alg["pipeline"]
+    if args.fgf:
+        # Algorithmic bytes of the STAGED Fast Guided Filter pipeline per full-resolution voxel, as SURVEY.md 8d counts the main
+        # path's (every stage reads its input and writes its output once; FastGuidedFilterColor, src/fastguidedfilter.cpp:124-209,
+        # between CostConst and DispSelect): cost volume 4 W; sub-sampling 4/s^2 R + 4/s^2 W; model stage 4/s^2 R + 16/s^2 W; smoothing
+        # 16/s^2 R + 16/s^2 W; up-sampling + q = a.I + b: 16/s^2 R + 4 W; WTA 4 R  =  12 + 76/s^2.  Per kernel class of this
+        # implementation: "cvf_fgf" (setup, sub-sampled costs, models, smoothing of one side) 60/s^2; "wta" (up-sample + apply +
+        # argmin of one side: the q write and the WTA read of the staged form) 8 + 16/s^2 - both below 1 by construction of a
+        # machine that cannot beat its HBM on the bytes a staged pipeline must move.
+        s2_ = float(args.fgf * args.fgf)
+        algb["cvf_fgf"], algb["wta"], pipe_alg = 60.0 / s2_, 8.0 + 16.0 / s2_, 12.0 + 76.0 / s2_
+    dom = max(("cvf_fgf", "wta") if args.fgf else ("cvf_fused", "cvf_a"), key=lambda k: kern.get(k, {"avg_ms": 0})["avg_ms"])
     lps = max(1, round(kern[dom]["launches_per_step"]))
     vox_per_launch = 2.0 * W * (y1 - y0) * (d1 - d0) * B / lps                    # (this rank's rows and slices; all pairs of a batch)
     dom_ms = kern[dom]["avg_ms"]
@@ -601,8 +610,13 @@ def main():
                 "note": "achieved / frac credit the fused kernel with the staged pipeline's ALGORITHMIC bytes (SURVEY.md 8d); they are "
                         "an algorithmic-equivalent rate, not bandwidth utilisation: the kernel's physical HBM rate is traffic_GBs "
                         "(traffic_frac of peak) and what bounds it is VALU issue (valu)",
-                "pipeline_alg_GBs": round(alg["pipeline"] * value / 1e9, 1),
-                "pipeline_frac": round(alg["pipeline"] * value / 1e9 / HBM_PEAK_GBS, 4)}
+                "pipeline_alg_bytes_per_voxel": pipe_alg,
+                "pipeline_alg_GBs": round(pipe_alg * value / 1e9, 1),
+                "pipeline_frac": round(pipe_alg * value / 1e9 / HBM_PEAK_GBS, 4)}
+    if args.fgf:
+        roofline["note"] = ("Fast Guided Filter row: algorithmic bytes of the staged pipeline (12 + 76/s^2 per voxel; per kernel class "
+                            "60/s^2 and 8 + 16/s^2 - bench.py); the sub-sampled costs are built on the fly and the filtered volume stays "
+                            "virtual, so the physical traffic is far below these figures")
     traffic_file = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(traffic_file) and world == 1 and not args.shard_sim and select_mode:
         try:
@@ -639,7 +653,7 @@ def main():
     oracle_maps = None
     O = None
     sim = args.shard_sim > 1
-    want_oracle = rank == 0 and not args.fgf and \
+    want_oracle = rank == 0 and not (args.fgf and dtype == "u8") and \
         ((world == 1 and not sim and not args.no_cpu_baseline) or ((world > 1 or sim) and not args.no_oracle_check))
     if want_oracle:
         from oracle import psm_oracle_py as O   # checker / baseline only - never on the GPU path
@@ -650,7 +664,10 @@ def main():
         if world > 1 or sim:
             sd, threads = D, min(32, cores)     # N > 1 / --shard-sim: a checker run only (no cpu_baseline in the line)
         tcpu = time.perf_counter()
-        res = (O.pipeline_u8 if dtype == "u8" else O.pipeline_f32)(l, r, sd, threads=threads)
+        if args.fgf:      # DispEst::CostFilter_FGF, the reference's live CPU branch (src/DispEst.cpp:281-296)
+            res = O.pipeline_fgf(l, r, sd, s=args.fgf, threads=threads)
+        else:
+            res = (O.pipeline_u8 if dtype == "u8" else O.pipeline_f32)(l, r, sd, threads=threads)
         tcpu = time.perf_counter() - tcpu
         if sd == D:
             oracle_maps = [res["ldisp"], res["rdisp"]]
@@ -660,7 +677,7 @@ def main():
                 with O.variant(O.VAR_F32_L1):
                     rm_ = O.pipeline_f32(l, r, sd, threads=min(32, cores))
                 tol_model_maps = [rm_["ldisp"], rm_["rdisp"]]
-        elif dtype == "f32" and not args.no_oracle_check:
+        elif dtype == "f32" and not args.no_oracle_check and not args.fgf:
             # (larger than 1080p x 256: the timed cpu_baseline is a sample of the disparities; the maps come from the oracle's
             # streaming form - same jobs and arithmetic, no volumes held - on up to 32 threads, outside every timed region)
             rs = O.pipeline_f32_maps(l, r, D, threads=min(32, cores))
@@ -677,7 +694,8 @@ def main():
             # context only, the contract's cpu_baseline is the 8-thread figure above
             wide = min(64, cores)
             if not args.no_cpu_wide and wide > threads:
-                resw = (O.pipeline_u8 if dtype == "u8" else O.pipeline_f32)(l, r, sd, threads=wide)
+                resw = O.pipeline_fgf(l, r, sd, s=args.fgf, threads=wide) if args.fgf else \
+                    (O.pipeline_u8 if dtype == "u8" else O.pipeline_f32)(l, r, sd, threads=wide)
                 sw = (resw["cvc_ms"] + resw["cvf_ms"] + resw["dispsel_ms"]) * 1e-3
                 cpu["wide"] = {"value": round(2.0 * W * H * sd / sw, 1), "cores": wide}
 

@@ -1,7 +1,7 @@
 #!/bin/bash
 # One full GPU-box session of a round: parity tests, smoke, benches of every config, the torch.distributed path on
 # one GPU, rocprofv3 kernel trace + PMC passes (each in its own run).  Usage (via gpurun): bash scripts/gpu_round.sh r03
-TAG=${1:-r03}
+TAG=${1:-r04}
 OUT=$GRAFT_REPO_ROOT/gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
@@ -13,7 +13,7 @@ echo "== smoke"; timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 
 echo "== pytest -m gpu"
 timeout 2400 python -m pytest tests -m gpu -q -s -p no:cacheprovider --timeout=1200 > $OUT/pytest_gpu.log 2>&1
 tail -3 $OUT/pytest_gpu.log
-grep -E "^\.?\[wmf\]|^\.?\[ocv-order\]" $OUT/pytest_gpu.log > $OUT/pytest_gpu_reports.txt
+grep -E "^\.?\[wmf\]|^\.?\[ocv-order\]|^\.?\[tol\]" $OUT/pytest_gpu.log > $OUT/pytest_gpu_reports.txt
 echo "== PMC passes first (own runs; kernel trace only): the headline line below then carries THIS session's traffic figure"
 cd /tmp
 for dt in f32 u8; do
@@ -37,16 +37,25 @@ timeout 900 python bench.py --box-bench --verify --pp > $OUT/bench_c4_n1.json 2>
 B="timeout 600 python bench.py"
 $B --config c3 --verify --pp > $OUT/bench_c3_n1.json 2>> $OUT/bench_var.err
 $B --config c2 --steps 30 --verify --pp > $OUT/bench_c2_n1.json 2>> $OUT/bench_var.err
-$B --config c5 --steps 4 --warmup 1 --verify > $OUT/bench_c5_n1.json 2>> $OUT/bench_var.err
+$B --config c5 --steps 4 --warmup 1 --verify --no-cpu-wide > $OUT/bench_c5_n1.json 2>> $OUT/bench_var.err
 $B --config c1 --steps 30 --verify > $OUT/bench_c1_u8_n1.json 2>> $OUT/bench_var.err
 $B --config c1x --steps 30 --verify > $OUT/bench_c1x_u8_n1.json 2>> $OUT/bench_var.err
 $B --config c4 --dtype u8 --verify > $OUT/bench_c4_u8_n1.json 2>> $OUT/bench_var.err
 $B --flags 2097152 --no-cpu-baseline --verify > $OUT/bench_c4_single_phase_n1.json 2>> $OUT/bench_var.err
 $B --flags 8192 --no-cpu-baseline --verify > $OUT/bench_c4_store_mode_n1.json 2>> $OUT/bench_var.err
-for s in 2 4 8; do $B --fgf $s --no-cpu-baseline > $OUT/bench_c4_fgf_s${s}_n1.json 2>> $OUT/bench_var.err; done
-for g in 2 4 8; do $B --shard-sim $g --steps 40 --no-cpu-baseline > $OUT/bench_c4_shardsim_1of$g.json 2>> $OUT/bench_var.err; done
-for g in 2 4 8; do $B --shard-sim $g --shard disp --steps 40 --no-cpu-baseline > $OUT/bench_c4_shardsim_disp_1of$g.json 2>> $OUT/bench_var.err; done
-$B --config c5 --shard-sim 8 --steps 6 --warmup 2 --no-cpu-baseline > $OUT/bench_c5_shardsim_1of8.json 2>> $OUT/bench_var.err
+for s in 2 4 8; do $B --fgf $s --no-cpu-wide > $OUT/bench_c4_fgf_s${s}_n1.json 2>> $OUT/bench_var.err; done
+echo "== tolerance form (PSM_FLAG_F32_TOL), same box, alternating with the default"
+for rep in 1 2; do
+  $B --steps 20 --warmup 5 --no-cpu-baseline --frame-loop 0 > $OUT/bench_c4_exact_ab$rep.json 2>> $OUT/bench_var.err
+  $B --steps 20 --warmup 5 --flags 33554432 --no-cpu-wide --frame-loop 0 > $OUT/bench_c4_tol_ab$rep.json 2>> $OUT/bench_var.err
+done
+echo "== batches of Middlebury-size pairs (psm_compute_batch)"
+for cfg in c2 c1 c1x; do for b in 2 4 8 16; do $B --config $cfg --batch $b --steps 30 --warmup 5 --no-cpu-wide > $OUT/bench_${cfg}_batch$b.json 2>> $OUT/bench_var.err; done; done
+$B --config c2 --batch 8 --graph --steps 30 --warmup 5 --no-cpu-baseline > $OUT/bench_c2_batch8_graph.json 2>> $OUT/bench_var.err
+$B --config c2 --batch -1 --graph --steps 30 --warmup 5 --no-cpu-baseline > $OUT/bench_c2_batch1_graph.json 2>> $OUT/bench_var.err
+for g in 2 4 8; do $B --shard-sim $g --steps 40 > $OUT/bench_c4_shardsim_1of$g.json 2>> $OUT/bench_var.err; done
+for g in 2 4 8; do $B --shard-sim $g --shard disp --steps 40 > $OUT/bench_c4_shardsim_disp_1of$g.json 2>> $OUT/bench_var.err; done
+$B --config c5 --shard-sim 8 --steps 6 --warmup 2 > $OUT/bench_c5_shardsim_1of8.json 2>> $OUT/bench_var.err
 echo "== weighted median timing (hybrid sweeps form / dataflow form)"
 timeout 300 python scripts/dbg_wmf.py big > $OUT/wmf_timing.txt 2>&1; WM_FLAGS=4194304 timeout 300 python scripts/dbg_wmf.py >> $OUT/wmf_timing.txt 2>&1; tail -22 $OUT/wmf_timing.txt
 echo "== torch.distributed path on 1 GPU (RCCL, world_size 1): both sharding axes per invocation"
@@ -54,6 +63,12 @@ D="timeout 600 python bench.py --gpus 1 --force-dist --steps 10 --warmup 3 --no-
 $D > $OUT/bench_c4_dist_world1.json 2> $OUT/bench_dist1.err
 $D --shard disp > $OUT/bench_c4_dist_world1_disp.json 2>> $OUT/bench_dist1.err
 $D --no-frame-pipeline > $OUT/bench_c4_dist_world1_nopipeline.json 2>> $OUT/bench_dist1.err
+echo "== the N > 1 protocol with TWO ranks on this one GPU (RCCL first; gloo-staged exchange when RCCL refuses the duplicate device)"
+W2="timeout 900 python bench.py --gpus 2 --same-device --steps 10 --warmup 3"
+$W2 > $OUT/bench_c4_world2_same_device.json 2> $OUT/bench_world2.err
+$W2 --shard disp > $OUT/bench_c4_world2_same_device_disp.json 2>> $OUT/bench_world2.err
+$W2 --no-frame-pipeline > $OUT/bench_c4_world2_same_device_nopipeline.json 2>> $OUT/bench_world2.err
+grep -h "RCCL with" $OUT/bench_world2.err | head -3
 python - <<PY
 import json,glob
 for f in sorted(glob.glob("$OUT/bench_*.json")):
@@ -70,8 +85,6 @@ f=$(find $OUT/prof -name "*kernel_trace.csv" | head -1); [ -n "$f" ] && python $
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_s8 -o trace -- python $GRAFT_REPO_ROOT/bench.py --shard-sim 8 --steps 40 --warmup 3 --no-cpu-baseline > $OUT/rocprof_s8_stdout.log 2>&1
 f=$(find $OUT/prof_s8 -name "*kernel_trace.csv" | head -1); [ -n "$f" ] && python $GRAFT_REPO_ROOT/scripts/trace_gaps.py $f 20 > $OUT/trace_gaps_shard8.txt 2>&1
 cd $GRAFT_REPO_ROOT
-echo "== per-role cycle counters (debug build, if present)"
-if [ -f primestereomatch_amd/lib/libprimesm_hip_dbg.so ]; then PRIMESM_HIP_LIB=$GRAFT_REPO_ROOT/primestereomatch_amd/lib/libprimesm_hip_dbg.so python scripts/dbg_pc_timing.py > $OUT/role_cycles.txt 2>&1; cat $OUT/role_cycles.txt; fi
 find $OUT -name "*.db" -delete; find $OUT -name "*kernel_trace.csv" -size +3M -delete
 f=$(find $OUT/prof -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && head -12 "$f"
 echo "== done"

@@ -48,7 +48,7 @@ def main():
     }
     for dt, u8 in (("f32", "false"), ("u8", "true")):
         pre = "pmc_" if dt == "f32" else "pmc_u8_"
-        ks = {"planes": f"k_cvf_pc<false, 3, 1, {u8}>", "keys": f"k_cvf_pc<false, 3, 2, {u8}>"}
+        ks = {"planes": f"k_cvf_pc<false, 3, 1, {u8}, false, false>", "keys": f"k_cvf_pc<false, 3, 2, {u8}, false, false>"}
         try:
             parts = {n: fabric_bytes(d, pre, k) for n, k in ks.items()}
             insts = {n: counters(os.path.join(d, f"{pre}sq.summary.txt"), k)["SQ_INSTS_VALU"] for n, k in ks.items()}
