@@ -1226,6 +1226,18 @@ void psmo_fill_inv(uint8_t *dis, const uint8_t *valid, int H, int W)
 #define SIG_CLR 0.1 /* include/PP.h:13 (double) */
 #define SIG_DIS 9   /* include/PP.h:14 (int) */
 
+/* one bilateral weight exactly as the loop below forms it (src/PP.cpp:169-175 left / 216-224 right): lets a test compare the
+ * device's weights with the host's operand by operand (roots and exp are the two places a toolchain can differ) */
+float psmo_wm_weight(const float *p3, const float *q3, int wx, int wy, int right)
+{
+    float disWgt = (float)(wx * wx + wy * wy);
+    if (right) disWgt = sqrtf(disWgt);
+    float d0 = p3[0] - q3[0], d1 = p3[1] - q3[1], d2 = p3[2] - q3[2];
+    float clrWgt = d0 * d0 + d1 * d1 + d2 * d2;
+    if (right) clrWgt = sqrtf(clrWgt);
+    return (float)exp((double)(-disWgt / (SIG_DIS * SIG_DIS)) - (double)clrWgt / (SIG_CLR * SIG_CLR));
+}
+
 void psmo_wgt_median(const float *img, uint8_t *dis, const uint8_t *valid, int H, int W, int maxDis, int right)
 {
     /* src/PP.cpp:155-196 (left map) / 199-245 (right map: the two distances go through sqrt, :218,:223).

@@ -177,6 +177,7 @@ void psmo_fill_inv(uint8_t *dis, const uint8_t *valid, int H, int W);
  * img: H x W x 3 float (the CV_32FC3 image PP::processDM receives), dis: H x W, updated IN PLACE in raster order
  * (later pixels see earlier results - the sequential semantics of the reference's single-threaded form).
  * exp is the host libm's double exp, narrowed to float, as in the reference. */
+float psmo_wm_weight(const float *p3, const float *q3, int wx, int wy, int right);   /* one weight of the loop below */
 void psmo_wgt_median(const float *img, uint8_t *dis, const uint8_t *valid, int H, int W, int maxDis, int right);
 
 /* ---- evaluation recipe of the harness (src/StereoMatch.cpp:275-311) -------------- */

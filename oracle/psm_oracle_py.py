@@ -160,6 +160,17 @@ def pipeline_f32_maps(l_bgr, r_bgr, D, threads=8):
     return {"ldisp": ld, "rdisp": rd}
 
 
+def wm_weights(p3, q3, wx, wy, right):
+    """wgtMedian's bilateral weights for n operand tuples (p3, q3: n x 3 float32 colours; wx, wy: n ints), as the host forms them."""
+    p3, q3 = _f32(p3), _f32(q3)
+    fn = lib().psmo_wm_weight
+    fn.restype = C.c_float
+    out = np.empty(len(p3), np.float32)
+    for i in range(len(p3)):
+        out[i] = fn(_p(p3[i]), _p(q3[i]), int(wx[i]), int(wy[i]), int(bool(right)))
+    return out
+
+
 def gray_grad_u8(img_u8):
     img = _u8(img_u8)
     H, W, _ = img.shape

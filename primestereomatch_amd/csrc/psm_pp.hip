@@ -708,3 +708,29 @@ void launch_wgt_median(hipStream_t s, uint8_t *dis, const uint8_t *valid, const 
 }
 
 }  // namespace psm
+
+// debug / test hook (not in include/primesm_hip.h): wgtMedian's bilateral weight for n operand tuples on the device - pq: n x 8
+// floats {p.xyz, -, q.xyz, -}, wxy: n x 2 ints, out: n floats (host pointers).  tests/test_gpu_pp_ocv.py compares them bit for bit
+// with the host's (roots through double, exp as glibc forms it: the two places where device and host could part).
+namespace psm {
+template <bool RIGHT>
+__global__ __launch_bounds__(256) void k_wm_weight_probe(const float4 *pq, const int2 *wxy, int n, float *out)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = wm_weight<RIGHT>(pq[2 * i], pq[2 * i + 1], wxy[i].x, wxy[i].y);
+}
+}  // namespace psm
+extern "C" int psm_debug_wm_weights(const float *pq, const int *wxy, int n, int right, float *out)
+{
+    float4 *dpq = nullptr; int2 *dw = nullptr; float *dout = nullptr;
+    int rc = 1;
+    if (hipMalloc((void **)&dpq, (size_t)n * 32) == hipSuccess && hipMalloc((void **)&dw, (size_t)n * 8) == hipSuccess &&
+        hipMalloc((void **)&dout, (size_t)n * 4) == hipSuccess &&
+        hipMemcpy(dpq, pq, (size_t)n * 32, hipMemcpyHostToDevice) == hipSuccess && hipMemcpy(dw, wxy, (size_t)n * 8, hipMemcpyHostToDevice) == hipSuccess) {
+        if (right) hipLaunchKernelGGL(psm::k_wm_weight_probe<true>, dim3((n + 255) / 256), dim3(256), 0, 0, dpq, dw, n, dout);
+        else hipLaunchKernelGGL(psm::k_wm_weight_probe<false>, dim3((n + 255) / 256), dim3(256), 0, 0, dpq, dw, n, dout);
+        rc = hipMemcpy(out, dout, (size_t)n * 4, hipMemcpyDeviceToHost) == hipSuccess ? 0 : 1;
+    }
+    (void)hipFree(dpq); (void)hipFree(dw); (void)hipFree(dout);
+    return rc;
+}

@@ -164,6 +164,21 @@ int DispEst::finishFrames()
     return hipUtil::api().download_maps_wait(ctx[0], lDisMap.data, rDisMap.data, lDisMap.step);
 }
 
+int DispEst::computeBatch(DispEst *const *des, int n)
+{
+    if (!des || n < 1) return 1;
+    std::vector<psm_ctx *> cs;
+    for (int i = 0; i < n; ++i) {
+        if (!des[i] || des[i]->ctx.size() != 1) return 1;      // (a multi-device object shards ONE pair; batches are per device)
+        cs.push_back(des[i]->ctx[0]);
+    }
+    const HipApi &api = hipUtil::api();
+    int rc = api.compute_batch(cs.data(), n);
+    for (int i = 0; i < n && !rc; ++i)
+        rc |= api.download_maps(cs[i], des[i]->lDisMap.data, des[i]->rDisMap.data, des[i]->lDisMap.step);
+    return rc;
+}
+
 double DispEst::stageTimeUs(int stage) const
 {
     double us = 0;

@@ -85,6 +85,11 @@ public:
     int computeFrame(const Mat *nextL, const Mat *nextR, bool have_prev);
     int finishFrames();
 
+    // Several pairs of one geometry per launch (the reference loops over pairs / datasets, src/main.cpp:64-73,
+    // src/StereoMatch.cpp:556-607): CostConst_GPU + CostFilter_GPU + DispSelect_GPU of n single-device DispEst objects in shared
+    // launches (psm_compute_batch); every object's lDisMap / rDisMap receive its maps.
+    static int computeBatch(DispEst *const *des, int n);
+
     bool ok() const { return !ctx.empty(); }
     double stageTimeUs(int stage) const;
 

@@ -48,7 +48,8 @@ bool hipUtil::load(const char *path)
               bind(g_api.disp_merge_ctx, "psm_disp_merge_ctx") && bind(g_api.set_rows, "psm_set_rows") && bind(g_api.gather_rows_ctx, "psm_gather_rows_ctx") &&
               bind(g_api.lr_check, "psm_lr_check") && bind(g_api.fill_invalid, "psm_fill_invalid") &&
               bind(g_api.wgt_median, "psm_wgt_median") &&
-              bind(g_api.stage_time_us, "psm_stage_time_us");
+              bind(g_api.stage_time_us, "psm_stage_time_us") && bind(g_api.compute_batch, "psm_compute_batch") &&
+              bind(g_api.download_maps, "psm_download_maps");
     if (!ok) {
         fprintf(stderr, "%s\n", g_error.c_str());
         dlclose(g_handle);

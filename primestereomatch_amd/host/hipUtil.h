@@ -34,6 +34,8 @@ struct HipApi {
     int (*fill_invalid)(psm_ctx *, uint8_t *, uint8_t *, size_t) = nullptr;
     int (*wgt_median)(psm_ctx *, uint8_t *, uint8_t *, size_t) = nullptr;
     int (*stage_time_us)(psm_ctx *, int, double *) = nullptr;
+    int (*compute_batch)(psm_ctx *const *, int) = nullptr;
+    int (*download_maps)(psm_ctx *, uint8_t *, uint8_t *, size_t) = nullptr;
 };
 
 class hipUtil {

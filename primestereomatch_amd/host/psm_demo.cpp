@@ -1,6 +1,8 @@
 // psm_demo - headless counterpart of the reference's StereoMatch::compute accelerator branch
 // (src/StereoMatch.cpp:193-262): raw B,G,R uint8 pair in, four timed stages, raw uint8 maps out.
-//   psm_demo <left.raw> <right.raw> <W> <H> <maxDis> <out_prefix> [ndev] [f32|u8] [float_input] [fgf_rate] [pp] [frames]
+//   psm_demo <left.raw> <right.raw> <W> <H> <maxDis> <out_prefix> [ndev] [f32|u8] [float_input] [fgf_rate] [pp] [frames] [batch]
+// batch > 1: additionally run that many copies of the pair as ONE batch (DispEst::computeBatch -> psm_compute_batch: the
+// reference's loop over pairs as shared launches), check every copy's maps against the single-pair run, dump <out>_ldisp_batch.raw
 // frames > 0: additionally run that many frames of the pair through DispEst::computeFrame (asynchronous upload of the next
 // pair / download of the previous maps: the frame loop of src/main.cpp:64-73), dump its last maps as <out>_ldisp_loop.raw and
 // print the time per frame
@@ -36,7 +38,7 @@ static bool dump(const std::string &path, const unsigned char *p, size_t n)
 int main(int argc, char **argv)
 {
     if (argc < 7) {
-        fprintf(stderr, "usage: %s left.raw right.raw W H maxDis out_prefix [ndev] [f32|u8] [float_input] [fgf_rate] [pp] [frames]\n", argv[0]);
+        fprintf(stderr, "usage: %s left.raw right.raw W H maxDis out_prefix [ndev] [f32|u8] [float_input] [fgf_rate] [pp] [frames] [batch]\n", argv[0]);
         return 2;
     }
     const int W = atoi(argv[3]), H = atoi(argv[4]), D = atoi(argv[5]);
@@ -47,6 +49,7 @@ int main(int argc, char **argv)
     const int fgf_rate = argc > 10 ? atoi(argv[10]) : 0;
     const bool pp = argc > 11 && atoi(argv[11]) != 0;
     const int frames = argc > 12 ? atoi(argv[12]) : 0;
+    const int batch = argc > 13 ? atoi(argv[13]) : 0;
     std::vector<unsigned char> lraw, rraw;
     if (!slurp(argv[1], lraw, (size_t)W * H * 3) || !slurp(argv[2], rraw, (size_t)W * H * 3)) {
         fprintf(stderr, "psm_demo: cannot read the input pair\n");
@@ -99,6 +102,22 @@ int main(int argc, char **argv)
         const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
         printf("Frame loop:	 %d frames, %4.3f ms per frame (H2D of every pair and D2H of every pair of maps included)\n", frames, ms / frames);
         ok = dump(out + "_ldisp_loop.raw", SMDE.lDisMap.data, (size_t)W * H) && dump(out + "_rdisp_loop.raw", SMDE.rDisMap.data, (size_t)W * H);
+    }
+    if (ok && batch > 1 && ndev == 1 && !fgf_rate) {
+        std::vector<std::vector<uint8_t>> keep(2);
+        keep[0].assign(SMDE.lDisMap.data, SMDE.lDisMap.data + (size_t)W * H);      // (frames > 0: the loop's maps = the same pair's)
+        keep[1].assign(SMDE.rDisMap.data, SMDE.rDisMap.data + (size_t)W * H);
+        std::vector<psm::DispEst *> des;
+        for (int b = 0; b < batch; ++b) des.push_back(new psm::DispEst(l, r, D, 8, true, 1, dtype));
+        const auto t0 = std::chrono::steady_clock::now();
+        const int rc = psm::DispEst::computeBatch(des.data(), batch);
+        const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        bool same = rc == 0;
+        for (int b = 0; b < batch && same && !pp; ++b)
+            same = !memcmp(des[b]->lDisMap.data, keep[0].data(), (size_t)W * H) && !memcmp(des[b]->rDisMap.data, keep[1].data(), (size_t)W * H);
+        printf("Batch:\t %d pairs in one set of launches, %4.3f ms (first call, maps downloaded), maps %s\n", batch, ms, same ? "equal the single-pair run's" : "DIFFER");
+        ok = same && dump(out + "_ldisp_batch.raw", des[batch - 1]->lDisMap.data, (size_t)W * H) && dump(out + "_rdisp_batch.raw", des[batch - 1]->rDisMap.data, (size_t)W * H);
+        for (auto *d : des) delete d;
     }
     return ok ? 0 : 6;
 }

@@ -459,9 +459,9 @@ def test_cpp_dispest_demo(psm, oracle, golden, tmp_path, mode, float_input):
     pair["r_bgr"].tofile(tmp_path / "r.raw")
     env = dict(os.environ, PRIMESM_HIP_LIB=psm.capi.LIB_PATH)
     p = subprocess.run([demo, str(tmp_path / "l.raw"), str(tmp_path / "r.raw"), str(W), str(H), "64",
-                        str(tmp_path / "o"), "1", mode, str(float_input), "0", "1", "5"], env=env, capture_output=True, text=True, timeout=300)
+                        str(tmp_path / "o"), "1", mode, str(float_input), "0", "1", "5", "3"], env=env, capture_output=True, text=True, timeout=300)
     assert p.returncode == 0, p.stderr
-    assert "CVF Time" in p.stdout and "Frame loop" in p.stdout
+    assert "CVF Time" in p.stdout and "Frame loop" in p.stdout and "Batch" in p.stdout
     ld = np.fromfile(tmp_path / "o_ldisp.raw", np.uint8).reshape(H, W)
     rd = np.fromfile(tmp_path / "o_rdisp.raw", np.uint8).reshape(H, W)
     key = ("ldisp", "rdisp") if mode == "f32" else ("ldisp_u8mode", "rdisp_u8mode")
@@ -476,6 +476,10 @@ def test_cpp_dispest_demo(psm, oracle, golden, tmp_path, mode, float_input):
     ll = np.fromfile(tmp_path / "o_ldisp_loop.raw", np.uint8).reshape(H, W)
     rl = np.fromfile(tmp_path / "o_rdisp_loop.raw", np.uint8).reshape(H, W)
     assert np.array_equal(ll, gold[key[0]]) and np.array_equal(rl, gold[key[1]])
+    # batch = 3: DispEst::computeBatch (psm_compute_batch: three pairs through one set of launches): same maps
+    lb = np.fromfile(tmp_path / "o_ldisp_batch.raw", np.uint8).reshape(H, W)
+    rb = np.fromfile(tmp_path / "o_rdisp_batch.raw", np.uint8).reshape(H, W)
+    assert np.array_equal(lb, gold[key[0]]) and np.array_equal(rb, gold[key[1]])
 
 
 @pytest.mark.parametrize("flags", [0, 128, 4096, 8192, 8192 + 128, 1048576, 1048576 + 128, 2097152])

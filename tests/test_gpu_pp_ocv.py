@@ -231,3 +231,29 @@ def test_hip_vs_opencv_order_oracle_full_size_band(psm, oracle, W, H, D, band):
             print(f"[ocv-order] {W}x{H} d={d}: max|dq|={dd.max():.3e}  voxels>1e-4: {int((dd > TOL).sum())}  "
                   f"bit-different: {int((q[d - d_lo] != qq).sum())} of {qq.size}")
             assert dd.max() <= TOL
+
+
+def test_device_wm_weights_equal_the_host(psm, oracle):
+    """Round-3 advisor finding: the weighted median's parity rests on the device forming every weight as the host does - roots
+    (the right map's two sqrtf; __fsqrt_rn is NOT correctly rounded on this ROCm, so they go through the double root) and
+    glibc's exp.  Operand by operand, both forms, including sqrt(162.0f) (wx = wy = 9) and colour distances from u8 images."""
+    import ctypes as C
+    lib = psm.capi.load()
+    rng = np.random.default_rng(11)
+    n = 200000
+    p3 = (rng.integers(0, 256, size=(n, 3)).astype(np.float32) * np.float32(1 / 255.0)).astype(np.float32)
+    q3 = (rng.integers(0, 256, size=(n, 3)).astype(np.float32) * np.float32(1 / 255.0)).astype(np.float32)
+    q3[: n // 4] = p3[: n // 4] + rng.integers(-3, 4, size=(n // 4, 3)).astype(np.float32) * np.float32(1 / 255.0)   # near colours: weights far from 0
+    wxy = rng.integers(-9, 10, size=(n, 2)).astype(np.int32)
+    wxy[0] = (9, 9); wxy[1] = (-9, 9)                      # disWgt = 162
+    pq = np.zeros((n, 8), np.float32)
+    pq[:, 0:3], pq[:, 4:7] = p3, q3
+    fn = lib.psm_debug_wm_weights
+    fn.restype = C.c_int
+    for right in (0, 1):
+        dev = np.empty(n, np.float32)
+        assert fn(pq.ctypes.data_as(C.c_void_p), wxy.ctypes.data_as(C.c_void_p), n, right, dev.ctypes.data_as(C.c_void_p)) == 0
+        host = oracle.wm_weights(p3[:20000], q3[:20000], wxy[:20000, 0], wxy[:20000, 1], right)
+        bad = np.flatnonzero(dev[:20000].view(np.uint32) != host.view(np.uint32))
+        assert bad.size == 0, (right, bad[:5], dev[bad[:5]], host[bad[:5]])
+        assert np.isfinite(dev).all() and (dev[: n // 4] > 0).any()
