@@ -211,7 +211,7 @@ def main():
     import numpy as np
     import primestereomatch_amd as P
     from primestereomatch_amd import capi, stripes, synth
-    from primestereomatch_amd.dispest import compute_batch
+    from primestereomatch_amd.dispest import compute_batch, share_streams
 
     W, H, D, desc = CONFIGS[args.config]
     dtype = args.dtype or ("u8" if args.config.startswith("c1") else "f32")
@@ -278,6 +278,8 @@ def main():
             if args.flags >= 0:
                 o_.set_option(capi.PSM_OPT_FLAGS, args.flags)
             batch_all.append(o_)
+        if len(batch_all) > 1:
+            share_streams(batch_all)         # one compute stream and one copy stream each way for the whole batch
         if rows_mode:
             de.set_rows(y0, y1)
         if args.fgf:
@@ -497,6 +499,7 @@ def main():
                 for o_, (pl_, pr_) in zip(batch_all, batch_pairs):
                     if not last:
                         o_.setInputImages_async(pl_, pr_)
+                for o_ in batch_all:
                     if i > 0:
                         o_.download_maps_wait()
                     o_.download_maps_async()
@@ -613,6 +616,8 @@ def main():
                 "pipeline_alg_bytes_per_voxel": pipe_alg,
                 "pipeline_alg_GBs": round(pipe_alg * value / 1e9, 1),
                 "pipeline_frac": round(pipe_alg * value / 1e9 / HBM_PEAK_GBS, 4)}
+    if args.shard_sim > 1:      # (value of a --shard-sim line is the whole job over ONE share's time: not a throughput)
+        roofline["pipeline_alg_GBs"] = roofline["pipeline_frac"] = None
     if args.fgf:
         roofline["note"] = ("Fast Guided Filter row: algorithmic bytes of the staged pipeline (12 + 76/s^2 per voxel; per kernel class "
                             "60/s^2 and 8 + 16/s^2 - bench.py); the sub-sampled costs are built on the fly and the filtered volume stays "

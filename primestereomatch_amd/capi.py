@@ -52,6 +52,7 @@ SYMBOLS = [
     ("psm_disp_merge", _i, [_vp, _vp, _i, _vp, _vp, _sz]),
     ("psm_disp_merge_ctx", _i, [_vp, C.POINTER(_vp), _i, _vp, _vp, _sz]),
     ("psm_compute_batch", _i, [C.POINTER(_vp), _i]),
+    ("psm_share_streams", _i, [C.POINTER(_vp), _i]),
     ("psm_download_maps", _i, [_vp, _vp, _vp, _sz]),
     ("psm_download_maps_async", _i, [_vp]),
     ("psm_download_maps_wait", _i, [_vp, _vp, _vp, _sz]),

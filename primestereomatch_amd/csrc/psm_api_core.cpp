@@ -99,6 +99,7 @@ void free_all(psm_ctx *c)
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->copy_stream) (void)hipStreamSynchronize(c->copy_stream);
+    if (c->down_stream) (void)hipStreamSynchronize(c->down_stream);
     for (int s = 0; s < 2; ++s) {
         (void)hipFree(c->raw[s]);
         (void)hipFree(c->raw_next[s]);
@@ -140,7 +141,12 @@ void free_all(psm_ctx *c)
     for (auto e : c->event_pool) (void)hipEventDestroy(e);
     for (hipEvent_t e : {c->ev_up, c->ev_maps, c->ev_down, c->ev_free, c->ev_stage[0], c->ev_stage[1]})
         if (e) (void)hipEventDestroy(e);
-    if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
+    if (c->shared) {
+        if (--c->shared->refs == 0) {
+            (void)hipStreamDestroy(c->shared->main); (void)hipStreamDestroy(c->shared->up); (void)hipStreamDestroy(c->shared->down);
+            delete c->shared;
+        }
+    } else if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
 }
 
@@ -347,6 +353,7 @@ int psm_set_stream(psm_ctx *c, void *hip_stream)
 {
     if (!c) return 1;
     if (bind(c)) return 1;
+    if (c->shared) return fail(c, "psm_set_stream: the context shares its streams with a batch (psm_share_streams)");
     PSM_HIP(c, hipStreamSynchronize(c->stream));
     c->stream = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
     return 0;
@@ -358,6 +365,40 @@ int psm_synchronize(psm_ctx *c)
     if (bind(c)) return 1;
     PSM_HIP(c, hipStreamSynchronize(c->stream));
     if (c->copy_stream) PSM_HIP(c, hipStreamSynchronize(c->copy_stream));
+    if (c->down_stream && c->down_stream != c->copy_stream) PSM_HIP(c, hipStreamSynchronize(c->down_stream));
+    return 0;
+}
+
+int psm_share_streams(psm_ctx *const *ctxs, int n)
+{
+    if (!ctxs || n < 1 || !ctxs[0]) return fail(nullptr, "psm_share_streams: bad arguments");
+    psm_ctx *c0 = ctxs[0];
+    for (int i = 0; i < n; ++i) {
+        if (!ctxs[i] || ctxs[i]->device != c0->device) return fail(c0, "psm_share_streams: context %d is NULL or on another device", i);
+        if (ctxs[i]->shared) return fail(c0, "psm_share_streams: context %d already shares streams", i);
+        if (ctxs[i]->stream != ctxs[i]->own_stream) return fail(c0, "psm_share_streams: context %d runs on a caller's stream (psm_set_stream)", i);
+    }
+    if (bind(c0)) return 1;
+    StreamSet *set = new StreamSet();
+    hipError_t e = hipStreamCreateWithFlags(&set->main, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&set->up, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&set->down, hipStreamNonBlocking);
+    if (e != hipSuccess) {
+        if (set->main) (void)hipStreamDestroy(set->main);
+        if (set->up) (void)hipStreamDestroy(set->up);
+        delete set;
+        return fail(c0, "psm_share_streams: %s", hipGetErrorString(e));
+    }
+    for (int i = 0; i < n; ++i) {
+        psm_ctx *c = ctxs[i];
+        (void)hipStreamSynchronize(c->stream);                  // nothing of this context is in flight on the old streams
+        if (c->copy_stream) { (void)hipStreamSynchronize(c->copy_stream); (void)hipStreamDestroy(c->copy_stream); }
+        c->shared = set;
+        ++set->refs;
+        c->stream = set->main;
+        c->copy_stream = set->up;
+        c->down_stream = set->down;
+    }
     return 0;
 }
 
@@ -398,7 +439,8 @@ int psm_upload_pair_async(psm_ctx *c, const void *l, const void *r, int channels
     if (!c->copy_stream) PSM_HIP(c, hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
     for (hipEvent_t *e : {&c->ev_up, &c->ev_free})
         if (!*e) PSM_HIP(c, hipEventCreateWithFlags(e, hipEventDisableTiming));
-    if (!c->pin_up) PSM_HIP(c, hipHostMalloc((void **)&c->pin_up, 4 * c->raw_bytes, hipHostMallocDefault));
+    const size_t sstride = (c->raw_bytes + 15) & ~(size_t)15;      // (image slots of the staging memory: 16-byte aligned for the copy kernel)
+    if (!c->pin_up) PSM_HIP(c, hipHostMalloc((void **)&c->pin_up, 4 * sstride, hipHostMallocDefault));
     for (int s = 0; s < 2; ++s)
         if (!c->raw_next[s]) PSM_HIP(c, hipMalloc(&c->raw_next[s], c->raw_bytes));
     // two staging slots, used alternately: the host only waits for the copy issued TWO uploads ago (the previous one may still
@@ -406,17 +448,23 @@ int psm_upload_pair_async(psm_ctx *c, const void *l, const void *r, int channels
     const int slot = c->stage_slot ^= 1;
     if (!c->ev_stage[slot]) PSM_HIP(c, hipEventCreateWithFlags(&c->ev_stage[slot], hipEventDisableTiming));
     else PSM_HIP(c, hipEventSynchronize(c->ev_stage[slot]));
-    uint8_t *stage = c->pin_up + (size_t)slot * 2 * c->raw_bytes;
+    uint8_t *stage = c->pin_up + (size_t)slot * 2 * sstride;
     const void *src[2] = {l, r};
     for (int s = 0; s < 2; ++s) {
-        uint8_t *dst = stage + s * c->raw_bytes;
+        uint8_t *dst = stage + s * sstride;
         if (stride_bytes == row) memcpy(dst, src[s], img);
         else for (int y = 0; y < c->H; ++y) memcpy(dst + (size_t)y * row, (const uint8_t *)src[s] + (size_t)y * stride_bytes, row);
     }
     // raw_next was the current pair two frames ago: its k_prep (recorded as ev_free by psm_cost_construct) must be over
     PSM_HIP(c, hipStreamWaitEvent(c->copy_stream, c->ev_free, 0));
-    for (int s = 0; s < 2; ++s)
-        PSM_HIP(c, hipMemcpyAsync(c->raw_next[s], stage + s * c->raw_bytes, img, hipMemcpyHostToDevice, c->copy_stream));
+    // Small images (Middlebury size: 0.5 MB) travel through a kernel that reads the page-locked slot - submitting a copy-engine
+    // transfer behind a stream wait costs 0.2 - 0.4 ms of HOST time on this stack, more than such a pair takes to compute; large
+    // ones keep the copy engines, which overlap a 12 MB pair with the filter without taking CU slots (1080p: +0.10 vs +0.27 ms).
+    for (int s = 0; s < 2; ++s) {
+        if (img <= PSM_COPY_KERNEL_MAX) launch_copy_bytes(c->copy_stream, c->raw_next[s], stage + s * sstride, img);
+        else PSM_HIP(c, hipMemcpyAsync(c->raw_next[s], stage + s * sstride, img, hipMemcpyHostToDevice, c->copy_stream));
+    }
+    if (check_launch(c, "upload (copy kernel)")) return 1;
     c->range_next_pending = false;
     if (depth == PSM_IMG_F32) {         // (measured behind the copy on the copy stream; read when the pair is adopted)
         const size_t nf = (size_t)c->W * c->H * 3;

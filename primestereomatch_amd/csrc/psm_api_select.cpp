@@ -332,13 +332,17 @@ int psm_download_maps_async(psm_ctx *c)
     if (bind(c)) return 1;
     const size_t HW = (size_t)c->W * c->H;
     if (!c->copy_stream) PSM_HIP(c, hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+    if (!c->down_stream) c->down_stream = c->copy_stream;
     for (hipEvent_t *e : {&c->ev_maps, &c->ev_down})
         if (!*e) PSM_HIP(c, hipEventCreateWithFlags(e, hipEventDisableTiming));
     if (!c->pinned2) PSM_HIP(c, hipHostMalloc((void **)&c->pinned2, 2 * HW, hipHostMallocDefault));
     PSM_HIP(c, hipEventRecord(c->ev_maps, c->stream));
-    PSM_HIP(c, hipStreamWaitEvent(c->copy_stream, c->ev_maps, 0));
-    PSM_HIP(c, hipMemcpyAsync(c->pinned2, c->maps, 2 * HW, hipMemcpyDeviceToHost, c->copy_stream));
-    PSM_HIP(c, hipEventRecord(c->ev_down, c->copy_stream));
+    PSM_HIP(c, hipStreamWaitEvent(c->down_stream, c->ev_maps, 0));
+    if (((uintptr_t)c->maps & 15) == 0 && 2 * HW <= PSM_COPY_KERNEL_MAX) {     // small maps: a kernel writing page-locked host memory (k_copy16; see psm_upload_pair_async)
+        launch_copy_bytes(c->down_stream, c->pinned2, c->maps, 2 * HW);
+        if (check_launch(c, "download (copy kernel)")) return 1;
+    } else PSM_HIP(c, hipMemcpyAsync(c->pinned2, c->maps, 2 * HW, hipMemcpyDeviceToHost, c->down_stream));
+    PSM_HIP(c, hipEventRecord(c->ev_down, c->down_stream));
     return 0;
 }
 

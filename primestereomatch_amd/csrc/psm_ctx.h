@@ -25,10 +25,22 @@ struct KernelTimer {
 
 }  // namespace psm
 
+namespace psm {
+// psm_share_streams: the contexts of a batch run on ONE main stream and ONE copy stream each way instead of three streams per
+// context (the runtime multiplexes streams onto a few hardware queues; with 8 contexts' 24 streams every asynchronous copy cost
+// 0.2 ms of host time).  Owned jointly: the last context to go destroys the streams.
+struct StreamSet {
+    hipStream_t main = nullptr, up = nullptr, down = nullptr;
+    int refs = 0;
+};
+}  // namespace psm
+
 struct psm_ctx {
     int W = 0, H = 0, D = 0, d0 = 0, d1 = 0, Dloc = 0, dtype = PSM_F32, device = 0;
     hipStream_t own_stream = nullptr, stream = nullptr;
     hipStream_t copy_stream = nullptr;  // psm_upload_pair_async / psm_download_maps_async: PCIe legs next to the kernels
+    hipStream_t down_stream = nullptr;  // ... the D2H leg's stream: copy_stream unless the context shares a StreamSet
+    psm::StreamSet *shared = nullptr;   // psm_share_streams
     hipEvent_t ev_up = nullptr, ev_maps = nullptr, ev_down = nullptr, ev_free = nullptr;
 
     // device memory (DESIGN.md "HBM layout")
@@ -193,6 +205,7 @@ int range_enqueue(psm_ctx *c, hipStream_t stream, int slot, const float *p0, siz
 bool range_inside(const psm_ctx *c, int slot, int lo_exp, int hi_exp);     // after the stream has been synchronised
 inline bool scaled_forms_ok(const psm_ctx *c) { return c->img_domain_ok && c->vol_domain_ok[0] && c->vol_domain_ok[1]; }
 constexpr int PSM_IMG_EXP = 10, PSM_VOL_EXP = 60;
+constexpr size_t PSM_COPY_KERNEL_MAX = (size_t)2 << 20;     // asynchronous PCIe legs up to this size go through k_copy16 instead of the copy engines
 unsigned long long *next_pc_stamp(psm_ctx *c);   // slot of the next k_cvf_pc launch (NULL unless PSM_OPT_PROFILE 2)
 
 // psm_api_select.cpp

@@ -43,6 +43,8 @@ void launch_prep_batch(hipStream_t s, const PcPair *tab, int npairs, size_t pitc
 void launch_guidance_batch(hipStream_t s, const PcPair *tab, int npairs, int W, int H);
 void launch_merge_batch(hipStream_t s, const PcPair *tab, int npairs, int W, int H);   // keys -> maps of every pair
 
+// device <-> page-locked host copy as a kernel (both pointers 16-byte aligned)
+void launch_copy_bytes(hipStream_t s, void *dst, const void *src, size_t bytes);
 // biased-exponent range of n floats: out[0] = max, out[1] = min over the non-zero values (initialise out to {0, 255})
 void launch_range_f32(hipStream_t s, const float *p, size_t n, unsigned *out);
 // image -> g1 (planarise, scale, gray, x-gradient).  src: device copy of the interleaved image.

@@ -90,6 +90,23 @@ __global__ __launch_bounds__(256) void k_range_f32(const float *__restrict__ p, 
         atomicMin(out + 1, min(min(smin[0], smin[1]), min(smin[2], smin[3])));
     }
 }
+// Copy n bytes (n % 16 == 0, 16-byte aligned) between device memory and page-locked host memory with a kernel instead of the
+// copy engines: the asynchronous PCIe legs of a frame loop (psm_upload_pair_async, psm_download_maps_async).  A kernel behind a
+// hipStreamWaitEvent is ordered by the command processor; the runtime's asynchronous copies behind such a wait cost 0.2 - 0.4 ms
+// of HOST time each on this stack (measured with 8 contexts per frame), which tied the host to the device's pace.
+__global__ __launch_bounds__(256) void k_copy16(uint4 *__restrict__ dst, const uint4 *__restrict__ src, size_t n16, int tail)
+{
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (size_t)gridDim.x * blockDim.x) dst[i] = src[i];
+    if (blockIdx.x == 0 && (int)threadIdx.x < tail)     // the last bytes % 16, one by one
+        reinterpret_cast<uint8_t *>(dst + n16)[threadIdx.x] = reinterpret_cast<const uint8_t *>(src + n16)[threadIdx.x];
+}
+void launch_copy_bytes(hipStream_t s, void *dst, const void *src, size_t bytes)
+{   // dst and src 16-byte aligned
+    const size_t n16 = bytes / 16;
+    const unsigned blocks = (unsigned)((n16 + 255) / 256 < 64 ? (n16 + 255) / 256 : 64);     // a few workgroups saturate the link
+    hipLaunchKernelGGL(k_copy16, dim3(blocks ? blocks : 1), dim3(256), 0, s, (uint4 *)dst, (const uint4 *)src, n16, (int)(bytes % 16));
+}
+
 void launch_range_f32(hipStream_t s, const float *p, size_t n, unsigned *out)
 {
     const unsigned blocks = (unsigned)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);

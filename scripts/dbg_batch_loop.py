@@ -4,11 +4,12 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import primestereomatch_amd as P
 from primestereomatch_amd import capi, synth
-from primestereomatch_amd.dispest import compute_batch
+from primestereomatch_amd.dispest import compute_batch, share_streams
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 W, H, D = 450, 375, 64
 pairs = [synth.make_pair(W, H, D, seed=b)[:2] for b in range(B)]
 des = [P.DispEst(l, r, D) for l, r in pairs]
+if len(sys.argv) > 2: share_streams(des)
 des[0].set_option(capi.PSM_OPT_ASYNC, 1)
 acc = {}
 def T(name, fn, *a):
@@ -17,6 +18,7 @@ def frame(i, last, up=True, down=True):
     T("compute", compute_batch, des)
     for o, (l, r) in zip(des, pairs):
         if up and not last: T("upload_async", o.setInputImages_async, l, r)
+    for o in des:
         if down and i > 0: T("down_wait", o.download_maps_wait)
         if down: T("down_async", o.download_maps_async)
 for mode in ("both", "up only", "down only", "none"):

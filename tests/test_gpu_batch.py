@@ -94,6 +94,10 @@ def test_batch_of_disparity_shards_and_async_frames(psm, oracle):
     pairs = [synth.make_pair(W, H, D, seed=20 + b)[:2] for b in range(6)]
     des = [psm.DispEst(*pairs[b], D) for b in range(3)]
     try:
+        from primestereomatch_amd.dispest import share_streams
+        share_streams(des)                                      # one compute stream, one copy stream each way for the batch
+        with pytest.raises(psm.capi.PsmError):
+            share_streams(des[:2])                              # (once per context)
         compute_batch(des)
         for b in range(3):
             des[b].setInputImages_async(*pairs[3 + b])          # the next frame's pairs travel ...
