@@ -123,6 +123,9 @@ void free_all(psm_ctx *c)
     (void)hipFree(c->wm);
     (void)hipFree(c->wm_par);
     (void)hipFree(c->wm_wts);
+    if (c->wm_pin) (void)hipHostFree(c->wm_pin);
+    for (hipEvent_t e : {c->ev_wm[0], c->ev_wm[1]})
+        if (e) (void)hipEventDestroy(e);
     (void)hipFree(c->gf_scratch);
     (void)hipFree(c->pc_ts);
     (void)hipFree(c->fgf);

@@ -103,7 +103,6 @@ int psm_wgt_median(psm_ctx *c, uint8_t *lmap, uint8_t *rmap, size_t stride)
             PSM_HIP(c, hipMemsetAsync(cnt[s], 0, ncnt * sizeof(int), c->stream));
             launch_wm_seed(c->stream, c->valid + s * HW, c->W, c->H, inv[s], cnt[s]);     // all invalid pixels = the first sweep's list
         }
-        std::vector<int> hc(2 * ncnt);
         // Weight cache: the 19 x 19 weights of an invalid pixel depend on the image only, and the sweeps evaluate it ~5 times.
         // For sides with at least WM_LANE_MIN invalid pixels one pass forms them all (1.5 KB per invalid pixel; beyond
         // WM_CACHE_MAX bytes for the pair the evaluations form their weights themselves, as they do for short lists).
@@ -138,14 +137,23 @@ int psm_wgt_median(psm_ctx *c, uint8_t *lmap, uint8_t *rmap, size_t stride)
                 }
             }
         }
-        int sw = 0;
+        // Sweeps are launched in groups of `chk`; the host looks at a group's counters (did a sweep change nothing? how long is the
+        // next list?) while the NEXT group is already queued - the device never idles behind a host round trip (round 3: ~65 us
+        // of idle per check, 0.7 ms of the 4.0 on the 1080p bench pair).  A group launched for a map that had already reached
+        // its fixed point is a handful of launches over empty lists.
+        const size_t snap = 2 * ncnt;                      // ints per counter snapshot (both maps)
+        if (!c->wm_pin) PSM_HIP(c, hipHostMalloc((void **)&c->wm_pin, 2 * snap * sizeof(int), hipHostMallocDefault));
+        for (hipEvent_t *e : {&c->ev_wm[0], &c->ev_wm[1]})
+            if (!*e) PSM_HIP(c, hipEventCreateWithFlags(e, hipEventDisableTiming));
+        int sw = 0;                        // sweeps launched
         bool tail[2] = {false, false};     // the list going into the next sweep is short: two launches per sweep, more sweeps per check
-        while (sw < CAP && !(done[0] && done[1])) {
+        int upto[2] = {0, 0};              // sweeps covered by the snapshot in slot g & 1
+        auto launch_group = [&](int slot) -> int {
             const int chk = ((tail[0] || done[0]) && (tail[1] || done[1])) ? 2 * CHK : CHK;
-            const int upto = sw + chk < CAP ? sw + chk : CAP;
+            const int end = sw + chk < CAP ? sw + chk : CAP;
             {
                 Prof p(c, PSM_K_WMF);
-                for (; sw < upto; ++sw)
+                for (; sw < end; ++sw)
                     for (int s = 0; s < 2; ++s)
                         if (!done[s])
                             launch_wm_sweep(c->stream, c->maps + s * HW, orig[s], c->valid + s * HW, c->g[s].g1, c->W, c->H, c->D, s,
@@ -153,23 +161,34 @@ int psm_wgt_median(psm_ctx *c, uint8_t *lmap, uint8_t *rmap, size_t stride)
                                             list[s][sw & 1], cnt[s] + 2 * (sw + 1), wts[s], slot_of[s], inv[s], cnt[s], chgb[s], rowany[s], tail[s]);
             }
             if (check_launch(c, "wgt_median (sweeps)")) return 1;
-            for (int s = 0; s < 2; ++s)
-                PSM_HIP(c, hipMemcpyAsync(hc.data() + s * ncnt, cnt[s], ncnt * sizeof(int), hipMemcpyDeviceToHost, c->stream));
-            PSM_HIP(c, hipStreamSynchronize(c->stream));
+            for (int s = 0; s < 2; ++s)      // (a kernel writing the page-locked snapshot: a copy-engine transfer in the stream stalls it for ~60 us)
+                launch_copy_bytes(c->stream, c->wm_pin + slot * snap + s * ncnt, cnt[s], ncnt * sizeof(int));
+            PSM_HIP(c, hipEventRecord(c->ev_wm[slot], c->stream));
+            upto[slot] = sw;
+            return 0;
+        };
+        if (launch_group(0)) return 1;
+        for (int g = 0;; ++g) {
+            const bool more = sw < CAP;
+            if (more && launch_group((g + 1) & 1)) return 1;          // (queued before this group's counters are looked at)
+            PSM_HIP(c, hipEventSynchronize(c->ev_wm[g & 1]));
+            const int *h = c->wm_pin + (g & 1) * snap;
+            const int seen = upto[g & 1];
             for (int s = 0; s < 2; ++s) {
                 if (done[s]) continue;
                 long long ev = 0;
-                for (int k = 0; k < sw; ++k) {
-                    ev += hc[s * ncnt + 2 * k];
-                    if (hc[s * ncnt + 2 * k + 1] == 0) {      // sweep k changed nothing: fixed point
+                for (int k = 0; k < seen; ++k) {
+                    ev += h[s * ncnt + 2 * k];
+                    if (h[s * ncnt + 2 * k + 1] == 0) {      // sweep k changed nothing: fixed point
                         done[s] = true;
                         c->wm_sweeps[s] = k + 1;
                         c->wm_evals[s] = ev;
                         break;
                     }
                 }
-                tail[s] = sw < CAP && hc[s * ncnt + 2 * sw] <= 2048;      // (the count the last sweep left for the next one)
+                tail[s] = seen < CAP && h[s * ncnt + 2 * seen] <= 2048;      // (the count the last sweep of the group left for the next one)
             }
+            if ((done[0] && done[1]) || !more) break;
         }
         // no fixed point within CAP sweeps (long chains of pixels that keep flipping each other): start over from the input
         // with the dataflow form, which is exact for any input

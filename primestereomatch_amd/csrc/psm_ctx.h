@@ -78,6 +78,8 @@ struct psm_ctx {
                                         // slot_of, the list of all invalid pixels, counters
     float *wm_wts = nullptr;            // ... the 19 x 19 window weights of every invalid pixel (formed once per call, read by every evaluation)
     size_t wm_wts_n = 0;
+    int *wm_pin = nullptr;              // page-locked snapshots of the sweep counters (two slots: a group's counters are read while the next group runs)
+    hipEvent_t ev_wm[2] = {nullptr, nullptr};
     int wm_sweeps[2] = {0, 0};          // last call: sweeps until the fixed point (-1: dataflow form), evaluations
     long long wm_evals[2] = {0, 0};
     uint8_t *p4[2] = {nullptr, nullptr};  // PSM_U8 only: {c0,c1,c2,grad} words
