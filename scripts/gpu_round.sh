@@ -29,6 +29,11 @@ for pass in "ft:FETCH_SIZE" "sqb:SQ_INSTS_SALU SQ_INSTS_VMEM SQ_ACTIVE_INST_LDS 
   timeout 300 rocprofv3 --kernel-trace --pmc $c -d $OUT/pmc_$n -o $n -- python $GRAFT_REPO_ROOT/scripts/prof_run.py c4 > $OUT/pmc_$n.log 2>&1 || echo "pmc pass $n failed"
   fdb=$(find $OUT/pmc_$n -name "*.db" | head -1); [ -n "$fdb" ] && python $GRAFT_REPO_ROOT/scripts/rocpd_summary.py $fdb > $OUT/pmc_$n.summary.txt 2>&1
 done
+for v in exact tol; do
+  fl=0; [ $v = tol ] && fl=33554432
+  PSM_FLAGS=$fl timeout 300 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_BUSY_CYCLES -d $OUT/pmc_sq_$v -o sq -- python $GRAFT_REPO_ROOT/scripts/prof_run.py c4 > $OUT/pmc_sq_$v.log 2>&1 || echo "pmc $v failed"
+  fdb=$(find $OUT/pmc_sq_$v -name "*.db" | head -1); [ -n "$fdb" ] && python $GRAFT_REPO_ROOT/scripts/rocpd_summary.py $fdb > $OUT/pmc_sq_$v.summary.txt 2>&1
+done
 cd $GRAFT_REPO_ROOT
 python scripts/make_traffic.py $OUT $TAG > $OUT/traffic.log 2>&1; tail -12 $OUT/traffic.log
 cp profiles/traffic.json $OUT/traffic.json
@@ -78,6 +83,8 @@ for f in sorted(glob.glob("$OUT/bench_*.json")):
     except Exception as e:
         print(f, "ERR", e)
 PY
+echo "== randomised soaks of the C ABI (batches included) and of the context state machine against the oracle"
+timeout 300 python scripts/soak.py 150 $RANDOM > $OUT/soak.txt 2>&1; timeout 200 python scripts/soak_state.py 90 $RANDOM >> $OUT/soak.txt 2>&1; tail -3 $OUT/soak.txt
 echo "== rocprofv3 kernel trace (same command as the bench)"
 cd /tmp
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -o trace -- python $GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 3 --no-cpu-baseline --frame-loop 0 > $OUT/rocprof_stdout.log 2>&1

@@ -1,7 +1,8 @@
 """Randomised soak of the whole C ABI against the CPU oracle (not part of the test suite: minutes of GPU time).
     python scripts/soak.py [seconds] [seed]
 Every case: random geometry / disparity range / dtype / tuning flags / segment rows, then one of: whole image, disparity
-shards, row stripes, both; maps (and sometimes the filtered volumes, the L-R check, fill and the weighted median) must be
+shards, row stripes, both, or a BATCH of 2-6 different pairs through psm_compute_batch (round 4; sometimes with float images,
+shared streams, a hipGraph replay, a second frame staged asynchronously); maps (and sometimes the filtered volumes, the L-R check, fill and the weighted median) must be
 bit-identical to the oracle.  Prints one line per failure and a summary."""
 import os
 import sys
@@ -14,6 +15,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "oracle"))
 import primestereomatch_amd as P          # noqa: E402
 from primestereomatch_amd import capi, synth   # noqa: E402
+from primestereomatch_amd.dispest import compute_batch, share_streams   # noqa: E402
 import psm_oracle_py as O                 # noqa: E402
 
 FLAGS = [0, 0, 0, 0, 1048576, 1048576, 2097152, 128, 8192, 8192 | 128, 1048576 | 128]
@@ -33,7 +35,7 @@ def one(rng, idx):
         a, b = sorted(int(v) for v in rng.integers(0, H, 2)); c, d = sorted(int(v) for v in rng.integers(0, W, 2))
         l[a:b + 1, c:d + 1] = int(rng.integers(0, 256)); r[a:b + 1, c:d + 1] = l[a, c]
     ref = (O.pipeline_u8 if dtype == "u8" else O.pipeline_f32)(l, r, D, threads=8, want_volumes=(dtype == "f32" and D <= 24))
-    mode = rng.choice(["whole", "whole", "shards", "stripes", "both"])
+    mode = rng.choice(["whole", "whole", "shards", "stripes", "both", "batch"])
     desc = f"case {idx}: {W}x{H} D={D} {dtype} flags={flags} seg={seg} mode={mode}"
 
     def setup(c):
@@ -42,6 +44,41 @@ def one(rng, idx):
             c.set_option(capi.PSM_OPT_SEG_ROWS, seg)
 
     ok = True
+    if mode == "batch":
+        # B different pairs of this geometry in shared launches; every pair against its own oracle run.  Only the select
+        # forms batch (flags 0 / two-phase on / off).
+        fl = flags if flags in (0, 1048576, 2097152) else 0
+        B = int(rng.integers(2, 7))
+        as_float = dtype == "f32" and rng.random() < 0.3          # images as the reference hands them over (x 1/255)
+        pairs = [(l, r)] + [synth.make_pair(W, H, D, seed=int(rng.integers(0, 1 << 16)))[:2] for _ in range(B - 1)]
+        conv = (lambda a: O.u8_to_f32(a)) if as_float else (lambda a: a)
+        des = [P.DispEst(conv(a), conv(b), D, dtype=dtype) for a, b in pairs]
+        try:
+            for de in des:
+                de.set_option(capi.PSM_OPT_FLAGS, fl)
+                if seg > 0:
+                    de.set_option(capi.PSM_OPT_SEG_ROWS, seg)
+            if rng.random() < 0.5:
+                share_streams(des)
+            if rng.random() < 0.3:
+                des[0].set_option(capi.PSM_OPT_GRAPH, 1)
+            refs = [ref] + [(O.pipeline_u8 if dtype == "u8" else O.pipeline_f32)(a, b, D, threads=8) for a, b in pairs[1:]]
+            frames = 2 if rng.random() < 0.4 else 1
+            for f in range(frames):
+                compute_batch(des)
+                if f + 1 < frames:                                  # next frame: the pairs rotate by one, staged asynchronously
+                    for k, de in enumerate(des):
+                        a, b = pairs[(k + 1) % B]
+                        de.setInputImages_async(conv(a), conv(b))
+            rot = frames - 1
+            for k, de in enumerate(des):
+                lm, rm = de.download_maps()
+                e = refs[(k + rot) % B]
+                ok &= np.array_equal(lm, e["ldisp"]) and np.array_equal(rm, e["rdisp"])
+        finally:
+            for de in des:
+                de.close()
+        return ok, desc + f" B={B} flags={fl} float={as_float}"
     if mode == "whole":
         with P.DispEst(l, r, D, dtype=dtype) as de:
             setup(de)
