@@ -119,7 +119,10 @@ int psm_wgt_median(psm_ctx *c, uint8_t *lmap, uint8_t *rmap, size_t stride)
             for (int s = 0; s < 2; ++s) PSM_HIP(c, hipMemcpyAsync(&n0[s], cnt[s], sizeof(int), hipMemcpyDeviceToHost, c->stream));
             PSM_HIP(c, hipStreamSynchronize(c->stream));
             size_t need[2], tot = 0;
-            for (int s = 0; s < 2; ++s) { need[s] = n0[s] >= WM_LANE_MIN ? (size_t)n0[s] * WM_WPIX : 0; tot += need[s]; }
+            for (int s = 0; s < 2; ++s) {      // (whole blocks of 64 pixels: the cache is laid out in such blocks)
+                need[s] = n0[s] >= WM_LANE_MIN ? (size_t)((n0[s] + 63) / 64 * 64) * WM_WPIX : 0;
+                tot += need[s];
+            }
             if (tot && tot * sizeof(float) <= WM_CACHE_MAX && !(c->march.flags & PSM_FLAG_WMF_NO_CACHE)) {
                 if (c->wm_wts_n < tot) {
                     (void)hipFree(c->wm_wts);

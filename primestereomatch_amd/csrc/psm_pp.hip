@@ -28,6 +28,7 @@
 #define PSM_EXP_FN __device__ __forceinline__
 #define PSM_EXP_FMA(a, b, c) __fma_rn(a, b, c)
 #include "psm_exp.h"
+#include "psm_wm_tab.h"
 
 namespace psm {
 
@@ -57,24 +58,44 @@ __global__ __launch_bounds__(64) void k_wm_next(const uint8_t *__restrict__ vali
 
 __device__ const unsigned long long wm_exp_tab[256] = PSM_EXP_TAB_INIT;
 
+// The spatial term -disWgt / (SIG_DIS * SIG_DIS) depends on the tap only: a table of its 361 float values per map (psm_wm_tab.h,
+// generated with the reference's float arithmetic) instead of a division - and for the right map a root - per weight.
+__device__ const unsigned wm_sp_left[WM_TAPS] = PSM_WM_SP_TAB_LEFT;
+__device__ const unsigned wm_sp_right[WM_TAPS] = PSM_WM_SP_TAB_RIGHT;
+
+// clrWgt / (SIG_CLR * SIG_CLR) (float / double -> double, src/PP.cpp:175,224) without the division: one Newton step on
+// x * RN(1 / c) with fused multiply-adds.  Bit-identical to __ddiv_rn((double)x, 0.1 * 0.1) for EVERY non-negative finite float x -
+// checked exhaustively, 2^31 operands, by scripts/exp/wm_arith.hip on the device (a double division is ~35 instructions).
+__device__ __forceinline__ double wm_div_sig_clr(float xf)
+{
+    const double c = 0.1 * 0.1, r = 1.0 / (0.1 * 0.1);
+    const double x = (double)xf;
+    const double q0 = __dmul_rn(x, r);
+    return __fma_rn(__fma_rn(-q0, c, x), r, q0);
+}
+// sqrt(float) of <cmath>, correctly rounded.  __fsqrt_rn of this ROCm is NOT (one ulp low for sqrt(162.0f) and for 15 % of random
+// operands, scripts/exp/sq.hip - which made one pixel of a 230 x 110 map come out 46 where the oracle says 48 in round 3); the
+// double-precision root narrowed to float is (53 >= 2 x 24 + 2 bits) and was round 3's form.  From 2^-100 up the classic
+// refinement of the hardware's reciprocal root - s = x r; s' = fma(fma(-s, s, x), r / 2, s) - gives the same float for EVERY
+// operand (exhaustive, scripts/exp/wm_arith.hip); below (and for 0) the double root stays.
+__device__ __forceinline__ float wm_sqrtf(float x)
+{
+    if (!(x >= 0x1p-100f)) return (float)sqrt((double)x);
+    const float r = __builtin_amdgcn_rsqf(x);
+    const float s = __fmul_rn(x, r);
+    return __fmaf_rn(__fmaf_rn(-s, s, x), __fmul_rn(0.5f, r), s);
+}
+
 template <bool RIGHT>
 __device__ __forceinline__ float wm_weight(float4 p, float4 q, int wx, int wy)
 {
     // src/PP.cpp:169-175 (left) / 216-224 (right)
-    float disWgt = (float)(wx * wx + wy * wy);
+    const float sp = __uint_as_float((RIGHT ? wm_sp_right : wm_sp_left)[(wy + WM_R) * WM_K + (wx + WM_R)]);   // -disWgt / 81 (float / int -> float)
     const float d0 = __fsub_rn(p.x, q.x), d1 = __fsub_rn(p.y, q.y), d2 = __fsub_rn(p.z, q.z);
     float clrWgt = __fadd_rn(__fadd_rn(__fmul_rn(d0, d0), __fmul_rn(d1, d1)), __fmul_rn(d2, d2));
-    if (RIGHT) {
-        // sqrt(float) of <cmath>, correctly rounded - through the double-precision root, whose narrowing to float is exact rounding
-        // (53 >= 2 x 24 + 2 bits).  __fsqrt_rn of this ROCm is NOT correctly rounded: one ulp low for sqrt(162.0f) and for 15 % of
-        // random operands (scripts/exp/sq.hip), and sqrtf is only with -fhip-fp32-correctly-rounded-divide-sqrt and can be merged
-        // with a less exact root of the same operand.  That ulp is what made one pixel of a 230 x 110 map come out 46 where the
-        // oracle says 48 (a running sum one ulp from the threshold; found by round 3's long-list test).
-        disWgt = (float)sqrt((double)disWgt);
-        clrWgt = (float)sqrt((double)clrWgt);
-    }
-    // -disWgt / (SIG_DIS*SIG_DIS): float / int -> float;  clrWgt / (SIG_CLR*SIG_CLR): float / double -> double
-    const double arg = __dsub_rn((double)__fdiv_rn(-disWgt, 81.0f), __ddiv_rn((double)clrWgt, 0.1 * 0.1));
+    if (RIGHT) clrWgt = wm_sqrtf(clrWgt);
+    // clrWgt / (SIG_CLR*SIG_CLR): float / double -> double
+    const double arg = __dsub_rn((double)sp, wm_div_sig_clr(clrWgt));
     return (float)psm_exp_nonpos(arg, wm_exp_tab);     // the host libm's exp, bit for bit (psm_exp.h): arg <= 0 or NaN
 }
 
@@ -265,6 +286,10 @@ __global__ __launch_bounds__(256) void k_wm_seed(const uint8_t *__restrict__ val
 // hist[dep] += w in a private column of an LDS histogram laid out [bin][lane] (bank = lane: conflict free) - every float sum is
 // formed in exactly the reference's order (src/PP.cpp:164-192), a bin sees its taps in raster order.  Then the threshold scan
 // over the bins some lane touched, in ascending d (adding an empty bin is the identity), which also zeroes them again.
+// (Round 4 tried a compact histogram - WM_RB = 32 bins from the window's smallest voting disparity, found by a first pass over the
+// disparities, 8 KB of LDS and 16 waves per CU instead of 2, the 13 % of pixels with a wider window handed to this full-size form:
+// bit-exact, and only 1.5 x faster on the 87 % it takes (265 vs 400 us for the first sweep of a 1080p map) - the extra pass, the
+// hand-over launches and maps with random disparities (every window wide: 9.4 -> 12.6 ms) made it a net loss.  Not occupancy.)
 // LDS: maxDis x 256 bytes per wave (64 KB at D = 256: two waves per CU) - the kernel runs at the pace ONE wave issues
 // instructions, so what counts is the length of its instruction stream: no data-dependent branches per tap, window rows read
 // as five dwords, the scan four bins at a time (1080p, 20 % invalid, random disparities: 24.9 -> 9.6 ms for both maps).
@@ -273,13 +298,31 @@ __global__ __launch_bounds__(256) void k_wm_seed(const uint8_t *__restrict__ val
 // histograms) - rows of 20 floats, pixel-major, slot = position in the list of invalid pixels, slot_of[pix] remembers it -
 // and every evaluation (CACHED) loads them: five float4 per window row instead of 19 g1 loads, 19 colour distances,
 // divisions and double-precision exps.  !CACHED: weights formed here (few invalid pixels, or the cache would not fit).
+// Cache layout (round 4): blocks of 64 consecutive invalid pixels, structure of arrays - float4 index
+//   wm_widx(slot, row, j) = ((slot / 64) * 19 + row) * 5 * 64 + j * 64 + slot % 64        (j-th float4 of the 20-float window row)
+// so that 64 lanes working on 64 consecutive pixels of the list (the weights kernel, and the first sweep's lane-per-pixel
+// evaluation, whose list IS the invalid list) read and write whole contiguous kilobytes.  The list is in raster order within
+// blocks of 1 024 pixels (k_wm_seed), and invalid pixels come in runs along x: consecutive lanes are mostly consecutive x of one
+// image row, so the 19 g1 loads of a window row coalesce as well.  (Round 3: one thread per (pixel, window row), 80-byte rows
+// pixel-major - every load and store instruction walked 64 cache lines: 0.47 ms per 1080p map at 17 % invalid, bound by the
+// address path, not by the double-precision exp.)
+__device__ __forceinline__ size_t wm_widx(int slot, int row, int j)
+{
+    return ((size_t)(slot >> 6) * WM_K + row) * (WM_WROW / 4) * 64 + (size_t)j * 64 + (slot & 63);
+}
+
 template <bool RIGHT>
 __global__ __launch_bounds__(256) void k_wm_weights(const float4 *__restrict__ g1, const int *__restrict__ inv, const int *n_inv,
                                                    float4 *__restrict__ wts, int *__restrict__ slot_of, int W, int H)
-{   // one thread per (invalid pixel, window row): consecutive threads write consecutive 80-byte rows
-    const long long total = (long long)*n_inv * WM_K;
+{   // one thread per (window row, invalid pixel): a wave = 64 consecutive pixels of the list, one window row
+    const int n = *n_inv;
+    const long long nblk = (n + 63) / 64, total = nblk * WM_K * 64;
     for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long long)gridDim.x * blockDim.x) {
-        const int slot = (int)(t / WM_K), r = (int)(t - (long long)slot * WM_K), wy = r - WM_R;
+        const int lane = (int)(t & 63);
+        const long long q = t >> 6;
+        const int r = (int)(q % WM_K), wy = r - WM_R;
+        const int slot = (int)(q / WM_K) * 64 + lane;
+        if (slot >= n) continue;
         const int pix = inv[slot];
         const int y = pix / W, x = pix - y * W;
         if (r == 0) slot_of[pix] = slot;
@@ -295,7 +338,7 @@ __global__ __launch_bounds__(256) void k_wm_weights(const float4 *__restrict__ g
         }
         wk[WM_WROW - 1] = 0.0f;
 #pragma unroll
-        for (int k = 0; k < WM_WROW / 4; ++k) wts[t * (WM_WROW / 4) + k] = make_float4(wk[4 * k], wk[4 * k + 1], wk[4 * k + 2], wk[4 * k + 3]);
+        for (int k = 0; k < WM_WROW / 4; ++k) wts[wm_widx(slot, r, k)] = make_float4(wk[4 * k], wk[4 * k + 1], wk[4 * k + 2], wk[4 * k + 3]);
     }
 }
 
@@ -316,8 +359,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2))) void
         const int y = pix / W, x = pix - y * W;
         const float4 p = g1[pix];
         // this pixel's row of the weight cache (WM_WROW / 4 float4 per window row)
-        const float4 *wrow = nullptr;
-        if constexpr (CACHED) wrow = wts + (size_t)slot_of[pix] * (WM_WPIX / 4);
+        int wslot = 0;
+        if constexpr (CACHED) wslot = slot_of[pix];
         unsigned dlo = (unsigned)maxDis, dhi = 0u;   // range of the bins this evaluation touches: dlo + 1 .. dhi (zeroed again after the scan)
         float tot = 0.0f;
         // One window row at a time: its loads (five dwords of disparities and five float4 of cached weights, or the 19 g1 values
@@ -365,7 +408,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2))) void
             }
             if constexpr (CACHED) {
 #pragma unroll
-                for (int k = 0; k < WM_WROW / 4; ++k) gq[slot][k] = wrow[(wy + WM_R) * (WM_WROW / 4) + k];
+                for (int k = 0; k < WM_WROW / 4; ++k) gq[slot][k] = wts[wm_widx(wslot, wy + WM_R, k)];
             }
         };
         auto take_row = [&](int slot, int wy) __attribute__((always_inline)) {
@@ -497,7 +540,10 @@ __global__ __launch_bounds__(64) void k_wm_eval_w(const uint8_t *__restrict__ cu
             const int t = min(lane + 64 * k, WM_TAPS - 1);
             const int wy = t / WM_K - WM_R, wx = t % WM_K - WM_R;
             float w;
-            if constexpr (CACHED) w = wts[(size_t)slot_of[pix] * WM_WPIX + (wy + WM_R) * WM_WROW + wx + WM_R];   // (the first sweep stored it)
+            if constexpr (CACHED) {             // (the weights kernel stored it; float index inside the float4 array)
+                const int k_ = wx + WM_R;
+                w = wts[4 * wm_widx(slot_of[pix], wy + WM_R, k_ >> 2) + (k_ & 3)];
+            }
             else w = wm_weight<RIGHT>(p, g1[off[k]], wx, wy);
             const bool live = lane + 64 * k < WM_TAPS;
             if (NB == 1) {
@@ -642,7 +688,7 @@ __global__ __launch_bounds__(64) void k_wm_apply(uint8_t *__restrict__ cur, cons
 // the 19 x 19 weights of the n_inv invalid pixels of `inv` (n = an upper bound of *n_inv, for the grid) -> wts, slot_of
 void launch_wm_weights(hipStream_t s, const float4 *g1, int W, int H, int right, const int *inv, const int *n_inv, int n, float *wts, int *slot_of)
 {
-    const long long threads = (long long)n * WM_K;
+    const long long threads = (long long)((n + 63) / 64) * WM_K * 64;
     const int blocks = (int)((threads + 255) / 256 < 65536 ? (threads + 255) / 256 : 65536);
     if (right) hipLaunchKernelGGL(k_wm_weights<true>, dim3(blocks), dim3(256), 0, s, g1, inv, n_inv, (float4 *)wts, slot_of, W, H);
     else hipLaunchKernelGGL(k_wm_weights<false>, dim3(blocks), dim3(256), 0, s, g1, inv, n_inv, (float4 *)wts, slot_of, W, H);
