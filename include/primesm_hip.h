@@ -227,7 +227,10 @@ int psm_fill_invalid(psm_ctx *ctx, uint8_t *lmap, uint8_t *rmap, size_t stride);
  * Needs W, H >= 9 (the reference's modulo wrap is undefined below that).  lmap/rmap (optional) receive the maps.
  * Device memory: from 8192 invalid pixels per map the 19 x 19 window weights of every invalid pixel are formed once and kept
  * for the sweeps - 1.5 KB per invalid pixel (0.6 GB per 1080p map at 20 % invalid), held by the context until psm_destroy;
- * above 12 GB for the pair, or when the allocation fails, the evaluations form their weights themselves (slower, same maps). */
+ * above 12 GB (or half of the device's free memory) for the pair, or when the allocation fails, the evaluations form their
+ * weights themselves (slower, same maps).
+ * Always synchronises with the host, PSM_OPT_ASYNC or not: the number of sweeps depends on the data (the host reads the
+ * device's per-sweep counters), so the call returns with the filtered maps complete. */
 int psm_wgt_median(psm_ctx *ctx, uint8_t *lmap, uint8_t *rmap, size_t stride);
 /* What the last psm_wgt_median did, per map {left, right}: sweeps until the fixed point (-1: dataflow form) and pixel
  * evaluations in total.  Either pointer may be NULL. */
