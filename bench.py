@@ -594,8 +594,8 @@ def main():
         # between CostConst and DispSelect): cost volume 4 W; sub-sampling 4/s^2 R + 4/s^2 W; model stage 4/s^2 R + 16/s^2 W; smoothing
         # 16/s^2 R + 16/s^2 W; up-sampling + q = a.I + b: 16/s^2 R + 4 W; WTA 4 R  =  12 + 76/s^2.  Per kernel class of this
         # implementation: "cvf_fgf" (setup, sub-sampled costs, models, smoothing of one side) 60/s^2; "wta" (up-sample + apply +
-        # argmin of one side: the q write and the WTA read of the staged form) 8 + 16/s^2 - both below 1 by construction of a
-        # machine that cannot beat its HBM on the bytes a staged pipeline must move.
+        # argmin of one side: the q write and the WTA read of the staged form) 8 + 16/s^2.  (Measured 0.4 - 0.8 per kernel class; the
+        # whole step on the staged bytes - pipeline_frac - can exceed 1 at s = 8: the path never builds a full-resolution volume.)
         s2_ = float(args.fgf * args.fgf)
         algb["cvf_fgf"], algb["wta"], pipe_alg = 60.0 / s2_, 8.0 + 16.0 / s2_, 12.0 + 76.0 / s2_
     dom = max(("cvf_fgf", "wta") if args.fgf else ("cvf_fused", "cvf_a"), key=lambda k: kern.get(k, {"avg_ms": 0})["avg_ms"])
