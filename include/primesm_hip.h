@@ -294,7 +294,8 @@ int psm_upload_volume(psm_ctx *ctx, int side, int d0, int d1, const void *host);
 int psm_filter_stage_a(psm_ctx *ctx, int side);
 int psm_download_ab(psm_ctx *ctx, int d0, int d1, float *host);
 /* guidance planes of `side` after psm_cost_filter/psm_filter_stage_a: host receives
- * [14][H][W] floats: I0,I1,I2,grad, mI0,mI1,mI2,invDET, A00,A01,A02,A11,A12,A22. */
+ * [14][H][W] floats: I0,I1,I2,grad, mI0,mI1,mI2,invDET, A00,A01,A02,A11,A12,A22.  (PSM_U8 contexts: `grad` is the 8-bit
+ * gradient of assets/cvc.cl's preprocessing as a float - the float x-gradient is not kept in that mode.) */
 int psm_download_guidance(psm_ctx *ctx, int side, float *host);
 /* The north-star kernel in isolation: cv::boxFilter(Size(8,8)) semantics applied to every
  * slice of volume `side`, result left in the scratch buffer; host (optional) receives

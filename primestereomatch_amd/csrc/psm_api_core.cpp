@@ -546,6 +546,10 @@ int psm_download_guidance(psm_ctx *c, int side, float *host)
     PSM_HIP(c, hipMemcpy(b4.data(), c->g[side].g4, HW * sizeof(float2), hipMemcpyDeviceToHost));
     for (size_t i = 0; i < HW; ++i) {
         host[0 * HW + i] = b1[i].x; host[1 * HW + i] = b1[i].y; host[2 * HW + i] = b1[i].z; host[3 * HW + i] = b1[i].w;
+        if (c->dtype == PSM_U8) {   // 8-bit contexts carry the pixel's {c0,c1,c2,grad} bytes in that slot: hand out the 8-bit gradient
+            unsigned w; memcpy(&w, &b1[i].w, 4);
+            host[3 * HW + i] = (float)(w >> 24);
+        }
         host[4 * HW + i] = b2[i].x; host[5 * HW + i] = b2[i].y; host[6 * HW + i] = b2[i].z; host[7 * HW + i] = b2[i].w;
         host[8 * HW + i] = b3[i].x; host[9 * HW + i] = b3[i].y; host[10 * HW + i] = b3[i].z; host[11 * HW + i] = b3[i].w;
         host[12 * HW + i] = b4[i].x; host[13 * HW + i] = b4[i].y;

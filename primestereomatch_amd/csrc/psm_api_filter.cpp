@@ -29,7 +29,7 @@ int run_prep(psm_ctx *c, int ya, int yb)
     }
     for (int s = 0; s < 2 && c->dtype == PSM_U8; ++s) {
         Prof p(c, PSM_K_PREP);
-        launch_prep_u8(c->stream, (const uint8_t *)c->raw[s] + ya * row, row, c->W, yb - ya, c->p4[s] + 4 * o);
+        launch_prep_u8(c->stream, (const uint8_t *)c->raw[s] + ya * row, row, c->W, yb - ya, c->p4[s] + 4 * o, c->g[s].g1 + o);
     }
     if (check_launch(c, "prep")) return 1;
     c->have_guid[0] = c->have_guid[1] = false;

@@ -147,7 +147,8 @@ void launch_fgf_apply_wta(hipStream_t s, const float4 *g1, int W, int H, int Dlo
                           long long *keys);
 
 // ---- 8-bit char mode ----
-void launch_prep_u8(hipStream_t s, const uint8_t *src, size_t pitch, int W, int H, uint8_t *planes4);
+// ({c0,c1,c2,grad} byte planes; the same word also into g1[..].w - bit pattern - of the image's g1 plane: launch_prep first)
+void launch_prep_u8(hipStream_t s, const uint8_t *src, size_t pitch, int W, int H, uint8_t *planes4, float4 *g1);
 void launch_cvc_u8(hipStream_t s, const uint8_t *base4, const uint8_t *other4, uint8_t *vol, int W, int H,
                    int d_begin, int Dloc, int right);
 void launch_u8_to_f32(hipStream_t s, const uint8_t *src, float *dst, size_t n);

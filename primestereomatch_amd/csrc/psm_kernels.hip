@@ -853,20 +853,27 @@ __device__ __forceinline__ int gray_u8(const uint8_t *p)
 }
 
 // planes4[y][x] = {c0, c1, c2, grad} as one 32-bit word per pixel
-__global__ __launch_bounds__(256) void k_prep_u8(const uint8_t *src, size_t pitch, int W, int H, uchar4 *out, const PcPair *__restrict__ tab)
+__global__ __launch_bounds__(256) void k_prep_u8(const uint8_t *src, size_t pitch, int W, int H, uchar4 *out, const PcPair *__restrict__ tab, float4 *g1)
 {
     int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
-    if (tab) { src = (const uint8_t *)tab[blockIdx.z >> 1].raw[blockIdx.z & 1]; out = (uchar4 *)tab[blockIdx.z >> 1].p4[blockIdx.z & 1]; }
+    if (tab) {
+        src = (const uint8_t *)tab[blockIdx.z >> 1].raw[blockIdx.z & 1]; out = (uchar4 *)tab[blockIdx.z >> 1].p4[blockIdx.z & 1];
+        g1 = tab[blockIdx.z >> 1].g[blockIdx.z & 1].g1;
+    }
     if (x >= W) return;
     const uint8_t *row = src + (size_t)y * pitch;
     const uint8_t *p = row + 3 * x;
     int g = gray_u8(row + 3 * r101(x + 1, W)) - gray_u8(row + 3 * r101(x - 1, W));
     g = g < 0 ? 0 : (g > 255 ? 255 : g);
-    out[(size_t)y * W + x] = make_uchar4(p[0], p[1], p[2], (uint8_t)g);
+    const uchar4 w = make_uchar4(p[0], p[1], p[2], (uint8_t)g);
+    out[(size_t)y * W + x] = w;
+    // 8-bit char mode: the fused kernel's producer waves load g1 of their own pixel anyway (the I.p products) and never use its
+    // float gradient - the pixel's four bytes ride in that slot (bit pattern), which saves them a load instruction per step
+    reinterpret_cast<uchar4 *>(&g1[(size_t)y * W + x])[3] = w;
 }
-void launch_prep_u8(hipStream_t s, const uint8_t *src, size_t pitch, int W, int H, uint8_t *planes4)
+void launch_prep_u8(hipStream_t s, const uint8_t *src, size_t pitch, int W, int H, uint8_t *planes4, float4 *g1)
 {
-    hipLaunchKernelGGL(k_prep_u8, dim3((W + 255) / 256, H), dim3(256), 0, s, src, pitch, W, H, (uchar4 *)planes4, (const PcPair *)nullptr);
+    hipLaunchKernelGGL(k_prep_u8, dim3((W + 255) / 256, H), dim3(256), 0, s, src, pitch, W, H, (uchar4 *)planes4, (const PcPair *)nullptr, g1);
 }
 void launch_prep_batch(hipStream_t s, const PcPair *tab, int npairs, size_t pitch, int depth_f32, int W, int H, bool u8_planes)
 {
@@ -876,7 +883,7 @@ void launch_prep_batch(hipStream_t s, const PcPair *tab, int npairs, size_t pitc
     else
         hipLaunchKernelGGL(k_prep<false>, grid, dim3(256), 0, s, (const void *)nullptr, pitch, W, H, (float4 *)nullptr, (const void *)nullptr, (float4 *)nullptr, tab);
     if (u8_planes)
-        hipLaunchKernelGGL(k_prep_u8, grid, dim3(256), 0, s, (const uint8_t *)nullptr, pitch, W, H, (uchar4 *)nullptr, tab);
+        hipLaunchKernelGGL(k_prep_u8, grid, dim3(256), 0, s, (const uint8_t *)nullptr, pitch, W, H, (uchar4 *)nullptr, tab, (float4 *)nullptr);
 }
 
 __device__ __forceinline__ uint8_t cost_u8(int clr3, int grd)

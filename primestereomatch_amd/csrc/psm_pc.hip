@@ -313,9 +313,8 @@ void k_cvf_pc(
         const __amdgpu_buffer_rsrc_t rGo = pc_rsrc(CVC == 0 ? G1 : Gother, (unsigned)HW * 16u);
         const __amdgpu_buffer_rsrc_t rV = pc_rsrc(CVC == 0 ? (const void *)vd : (const void *)G1, (unsigned)HW * 4u);
         // U8: byte planes {c0,c1,c2,grad} of this side's / the other side's image (swapped for the right volume of a two-side launch)
-        const __amdgpu_buffer_rsrc_t rP = pc_rsrc(U8 ? (s1 ? (const void *)vout : (const void *)vin) : (const void *)G1, (unsigned)HW * 4u);
         const __amdgpu_buffer_rsrc_t rPo = pc_rsrc(U8 ? (s1 ? (const void *)vin : (const void *)vout) : (const void *)G1, (unsigned)HW * 4u);
-        unsigned pu[2], po[2];
+        unsigned po[2];
         const int vci = ci * 16, vcp = cpart * 16, vxa = xac * 16;
 #define PSM_ISSUE_PA(SLOT, STEP)                                                        \
     {                                                                                   \
@@ -324,8 +323,7 @@ void k_cvf_pc(
         ya_ = ya_ < 0 ? 0 : (ya_ > H - 1 ? H - 1 : ya_);                                \
         const int oa_ = ya_ * W;                                                        \
         if (CVC == 0) pin[SLOT] = pc_load1(rV, vci >> 2, row_ * 4);                     \
-        else if (U8) {                                                                  \
-            pu[SLOT] = __builtin_amdgcn_raw_buffer_load_b32(rP, vci >> 2, row_ * 4, 0); \
+        else if (U8) {   /* (this pixel's own bytes ride in gin.w: k_prep_u8) */         \
             po[SLOT] = __builtin_amdgcn_raw_buffer_load_b32(rPo, vcp >> 2, row_ * 4, 0); \
         } else if (!LEANA) oth[SLOT] = pc_load4(rGo, vcp, row_ * 16);                   \
         gin[SLOT] = pc_load4(rG1, vci, row_ * 16);                                      \
@@ -353,11 +351,12 @@ void k_cvf_pc(
         if (CVC == 0) p = pin[K & 1];                                                               \
         else if (U8) {                                                                              \
             const unsigned b_ = inb ? po[K & 1] : 0xffffffffu;        /* border: the other image reads as 255 */ \
+            const unsigned pu_ = __float_as_uint(gin[K & 1].w);       /* this pixel's {c0,c1,c2,grad} bytes */ \
             /* |gradient difference| and colour sum from two SADs (all four bytes, then the gradient byte alone); clr / 3 as a   \
                24-bit multiply (clr <= 765: floor(clr * 21846 / 65536) == clr / 3); the truncating cast to uchar of a value in    \
                [0, 256) as v_trunc_f32 - integer arithmetic and exact conversions only, same bits as oracle cost_u8 */           \
-            const unsigned grd_ = __builtin_amdgcn_sad_u8(pu[K & 1] & 0xff000000u, b_ & 0xff000000u, 0u); \
-            const unsigned clr_ = __builtin_amdgcn_sad_u8(pu[K & 1], b_, 0u) - grd_;                \
+            const unsigned grd_ = __builtin_amdgcn_sad_u8(pu_ & 0xff000000u, b_ & 0xff000000u, 0u); \
+            const unsigned clr_ = __builtin_amdgcn_sad_u8(pu_, b_, 0u) - grd_;                      \
             const float f_ = __fadd_rn(__fmul_rn(0.9f, (float)(__umul24(clr_, 21846u) >> 16)), __fmul_rn(__fsub_rn(1.0f, 0.9f), (float)grd_)); \
             p = __fmul_rn(__builtin_truncf(f_), 1 / 255.0f);                                        \
         } else {                                                                                    \
