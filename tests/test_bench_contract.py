@@ -153,3 +153,42 @@ def test_round3_lines():
         q = _line_r("r03", name)
         assert q["verified_vs_single_gpu"] is True and q["scaling"] == "strong", name
         assert q["alt_shard"]["verified_vs_single_gpu"] is True and q["alt_shard"]["shard"] != q["config"]["shard"], name
+
+
+def test_round4_lines():
+    """profiles/r04: the headline still carries the contract; the new kinds of line say what they are - batches per pair and
+    verified per pair, the world-2 protocol run on one device (not a scaling claim), shard-sim lines verified, FGF lines with a
+    CPU baseline and kernel-class fractions below 1, the tolerance form pinned against its model."""
+    j = _line_r("r04", "bench_c4_n1.json")
+    W, H, D = j["config"]["W"], j["config"]["H"], j["config"]["D"]
+    assert (W, H, D) == (1920, 1080, 256) and j["dtype"] == "f32" and j["n_gpus"] == 1 and j["vs_baseline"] is None
+    assert abs(j["value"] - 2.0 * W * H * D / (j["ms_per_step"] * 1e-3)) / j["value"] < 1e-6
+    assert j["oracle_maps_equal"] is True and j["verified_vs_single_gpu"] is True
+    assert j["kernels_sum_ms_per_step"] <= 1.005 * j["ms_per_step"]
+    c = j["cpu_baseline"]
+    assert c["kind"] == "port" and c["cores"] == 8 and c["wide"]["cores"] > 8 and c["wide"]["value"] > 0      # 8 threads AND the wide run
+    r = j["roofline"]
+    assert r["bound"] == "hbm" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and 0 < r["traffic"] < r["alg_bytes_per_launch"]
+    assert _line_r("r04", "bench_c5_n1.json")["oracle_maps_equal"] is True            # 3840 x 2160 x 256, whole disparity range
+    for cfg, dt in (("c2", "f32"), ("c1", "u8"), ("c1x", "u8")):
+        for b in (2, 4, 8, 16):
+            k = _line_r("r04", f"bench_{cfg}_batch{b}.json")
+            assert k["config"]["batch"] == b and k["dtype"] == dt and abs(k["ms_per_pair"] * b - k["ms_per_step"]) < 1e-9
+            assert k["verified_vs_single_gpu"] is True and k["oracle_maps_equal"] is True, (cfg, b)
+            assert abs(k["value"] - k["config"]["voxels_per_step"] / (k["ms_per_step"] * 1e-3)) / k["value"] < 1e-6
+        assert _line_r("r04", f"bench_{cfg}_batch8.json")["ms_per_pair"] < _line_r("r04", f"bench_{cfg}_batch2.json")["ms_per_pair"]
+    for name in ("bench_c4_world2_same_device.json", "bench_c4_world2_same_device_disp.json", "bench_c4_world2_same_device_nopipeline.json"):
+        k = _line_r("r04", name)
+        assert k["config"]["ranks"] == 2 and k["config"]["same_device"] is True and "NOT a scaling measurement" in k["same_device_note"]
+        assert k["verified_vs_single_gpu"] is True and k["oracle_maps_equal"] is True
+        assert k["alt_shard"]["verified_vs_single_gpu"] is True and k["alt_shard"]["oracle_maps_equal"] is True
+    for name in ("bench_c4_shardsim_1of8.json", "bench_c4_shardsim_disp_1of8.json", "bench_c5_shardsim_1of8.json"):
+        k = _line_r("r04", name)
+        assert k["verified_vs_single_gpu"] is True and k["oracle_maps_equal"] is True and k["roofline"]["pipeline_frac"] is None
+    for s_ in (2, 4, 8):
+        k = _line_r("r04", f"bench_c4_fgf_s{s_}_n1.json")
+        assert k["roofline"]["frac"] <= 1.0 and k["cpu_baseline"]["value"] > 0 and k["oracle_maps_equal"] is True
+        assert abs(k["roofline"]["pipeline_alg_bytes_per_voxel"] - (12.0 + 76.0 / (s_ * s_))) < 1e-9
+    t = _line_r("r04", "bench_c4_tol_ab1.json")
+    assert t["tolerance_form"]["maps_equal_its_oracle_model"] is True and sum(t["tolerance_form"]["pixels_differing_from_the_canonical_oracle"]) < 50
+    assert t["ms_per_step"] < _line_r("r04", "bench_c4_exact_ab1.json")["ms_per_step"]
