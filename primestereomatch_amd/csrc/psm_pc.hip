@@ -725,8 +725,9 @@ PcDev pc_dev()
 
 #ifdef PSM_EXPERIMENTS   // tuning knobs of experiment builds only (none changes a result); the product reads no environment
 static int pc_env(const char *name) { const char *e = getenv(name); return e ? atoi(e) : 0; }
+#define PSM_KNOB(NAME, DEFAULT) (pc_env(NAME) > 0 ? pc_env(NAME) : (DEFAULT))
 #else
-static int pc_env(const char *) { return 0; }
+#define PSM_KNOB(NAME, DEFAULT) (DEFAULT)
 #endif
 
 // Segment count k (and, for the plane form, slices per chunk DC): every segment re-walks 14 halo rows, and the launch runs in
@@ -747,8 +748,8 @@ PcPlan pc_plan(int W, int rows, int Dloc, int seg_rows_opt, int form, int batch)
     const int kmax = rows / 64 > 1 ? rows / 64 : 1;
     int dcs[5] = {1, 2, 4, 8, 16};
     int ndc = planes ? 5 : 1;
-    if (planes && pc_env("PSM_PC_DC") > 0) { dcs[0] = pc_env("PSM_PC_DC"); ndc = 1; }
-    const long slots = pc_env("PSM_PC_SLOTS") > 0 ? pc_env("PSM_PC_SLOTS") : (long)dev.cus_per_xcd * (keys ? 4 : 3);   // resident workgroups per XCD
+    if (planes && PSM_KNOB("PSM_PC_DC", 0) > 0) { dcs[0] = PSM_KNOB("PSM_PC_DC", 0); ndc = 1; }
+    const long slots = PSM_KNOB("PSM_PC_SLOTS", (long)dev.cus_per_xcd * (keys ? 4 : 3));   // resident workgroups per XCD
     auto cost_of = [&](int dc, int kk) -> long {
         const int nch = (Dloc + dc - 1) / dc;
         const long per_xcd = ((long)sides * pl.ngroups * kk * nch + dev.nxcd - 1) / dev.nxcd;
@@ -783,7 +784,7 @@ constexpr int PC_KEY_SPREAD = 4;    // passes of the key form's slice order (pc_
 
 int pc_seed_stride(int W, int H)
 {   // every S-th slice goes through the minima planes and seeds the key plane: 5, 4 from 4 Mpixel up
-    const int e = pc_env("PSM_PC_S");
+    const int e = PSM_KNOB("PSM_PC_S", 0);
     return e > 1 ? e : ((size_t)W * H >= ((size_t)1 << 22) ? 4 : 5);
 }
 
@@ -888,7 +889,7 @@ void launch_cvf_select_keys2(hipStream_t s, March m, const Guidance *g, int W, i
                              unsigned long long *ts, const uint8_t *const *p4, int init, int sel, int step)
 {
     const PcPlan pl = pc_plan(W, m.rows(H), Dloc, m.seg_rows, PC_KEYS | PC_BOTH);
-    const PcSel ps = {sel, step, pl.nxcd, pc_env("PSM_PC_SPREAD") > 0 ? pc_env("PSM_PC_SPREAD") : PC_KEY_SPREAD, Dloc, 0};
+    const PcSel ps = {sel, step, pl.nxcd, PSM_KNOB("PSM_PC_SPREAD", PC_KEY_SPREAD), Dloc, 0};
     const size_t HW = (size_t)W * H;
     if (init) hipLaunchKernelGGL(k_fill_keys, dim3((unsigned)((2 * HW + 255) / 256)), dim3(256), 0, s, keys, 2 * HW);
     const dim3 grid(pc_blocks(pl, Dloc), 2), blk(64 * (PcLayout<2>::NA + PcLayout<2>::NB));

@@ -705,7 +705,8 @@ void launch_wm_sweep(hipStream_t s, uint8_t *cur, const uint8_t *orig, const uin
                      int right, const int *act, const int *n_act, uint8_t *newv, int *chg, int *n_chg, int *stamp, int mark,
                      int *next, int *n_next, const float *wts, const int *slot_of, const int *inv, const int *n_inv, uint8_t *chgb, uint8_t *rowany, bool tail)
 {   // tail: the host has seen a short list going into this sweep - only the one-wave-per-pixel evaluation and the scatter form of
-    // the dependents are launched (both made to take whatever the list turns out to be): two launches instead of four   // wts / slot_of: the weight cache (launch_wm_weights) or null; inv / n_inv: the list of all invalid pixels (the first sweep's
+    // the dependents are launched (both made to take whatever the list turns out to be): two launches instead of four
+    // wts / slot_of: the weight cache (launch_wm_weights) or null; inv / n_inv: the list of all invalid pixels (the first sweep's
     // list); chgb, rowany: byte maps of the gather form (zero at the start)
     const bool cached = wts != nullptr;
     const dim3 ga(2048);
