@@ -57,7 +57,7 @@ enum {
                                    kernel stamps its own start / end instead (psm_filter_launch_times) */
     PSM_OPT_SEG_ROWS = 3,       /* rows per y-segment of the marching kernels (0 = auto)      */
     PSM_OPT_WAVES = 4,          /* waves (disparity slices) per workgroup: 1,2,4,8            */
-    PSM_OPT_FLAGS = 5,          /* PSM_FLAG_* bits below; no flag but PSM_FLAG_F32_TOL changes any result */
+    PSM_OPT_FLAGS = 5,          /* PSM_FLAG_* bits below; no flag but PSM_FLAG_F32_TOL / PSM_FLAG_FMA_SOLVE changes any result */
     PSM_OPT_GRAPH = 6           /* 1: psm_compute_batch captures its launches once as a hipGraph and replays it while the batch
                                    (contexts, geometry, options) stays the same; ignored while PSM_OPT_PROFILE is on */
 };
@@ -86,7 +86,15 @@ enum psm_flag {
                                            the default form's (measured: <= 4e-5, no disparity changed on the test pairs), not
                                            bit-identical.  The storing form (psm_download_volume ...) stays exact; 8-bit mode
                                            ignores the flag.  Off by default. */
-    PSM_FLAGS_ALL = 128 | 4096 | 8192 | 1048576 | 2097152 | 4194304 | 8388608 | 16777216 | 33554432
+    PSM_FLAG_FMA_SOLVE = 67108864,      /* float mode: the 3x3 solve of the guided filter (src/CVF.cpp:129-147) with the fused
+                                           multiply-adds GCC's default -ffp-contract=fast forms on an FMA target (the ARM boards
+                                           the reference ran on): every x*y - z*w of the minors and of DET and every s + x*y of
+                                           the three accumulations is one fma.  Bit-identical to the oracle's reading
+                                           PSMO_VAR_FMA_SOLVE of those lines (maps, minima and filtered volumes); within 4e-4 of
+                                           the default (the canon: the same lines compiled without contraction, e.g. x86-64).
+                                           Applies to psm_cost_filter (select and storing forms); psm_compute_batch, the FGF
+                                           variant and 8-bit mode refuse / ignore it.  Off by default. */
+    PSM_FLAGS_ALL = 128 | 4096 | 8192 | 1048576 | 2097152 | 4194304 | 8388608 | 16777216 | 33554432 | 67108864
 };
 
 /* Number of usable HIP devices; 0 if none.  Replaces openCLdevicepoll()

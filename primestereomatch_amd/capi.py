@@ -25,6 +25,7 @@ PSM_FLAG_MATERIALISE_COSTS, PSM_FLAG_FGF_STORE, PSM_FLAG_STORE_FILTERED = 128, 4
 PSM_FLAG_TWO_PHASE_ON, PSM_FLAG_TWO_PHASE_OFF = 1048576, 2097152
 PSM_FLAG_WMF_DATAFLOW, PSM_FLAG_WMF_TWO_SWEEPS, PSM_FLAG_WMF_NO_CACHE = 4194304, 8388608, 16777216
 PSM_FLAG_F32_TOL = 33554432
+PSM_FLAG_FMA_SOLVE = 67108864
 
 # every symbol include/primesm_hip.h declares: (name, restype, argtypes)
 _vp, _i, _sz = C.c_void_p, C.c_int, C.c_size_t

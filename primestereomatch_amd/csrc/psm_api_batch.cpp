@@ -27,6 +27,10 @@ extern "C" int psm_compute_batch(psm_ctx *const *ctxs, int n)
             return fail(c0, "psm_compute_batch: context %d asks for a storing form (the batch runs the default select path)", i);
         if (c->march.flags != c0->march.flags || c->march.seg_rows != c0->march.seg_rows)
             return fail(c0, "psm_compute_batch: context %d has other options than context 0", i);
+        // the batched launches exist in the bit-exact form only: a silently ignored flag would break "same maps as the three
+        // single-pair calls" (which DO run the tolerance form with this flag)
+        if (c->march.flags & (PSM_FLAG_F32_TOL | PSM_FLAG_FMA_SOLVE))
+            return fail(c0, "psm_compute_batch: context %d asks for PSM_FLAG_F32_TOL / PSM_FLAG_FMA_SOLVE (single-pair entry points only)", i);
         if (c->march.yend > c->march.ybeg) return fail(c0, "psm_compute_batch: context %d is restricted to a row stripe", i);
         if (!c->have_images && c->next_depth < 0) return fail(c0, "psm_compute_batch: context %d has no image pair", i);
         if (c->next_depth >= 0 ? c->next_depth != (c0->next_depth >= 0 ? c0->next_depth : c0->raw_depth)
@@ -40,9 +44,9 @@ extern "C" int psm_compute_batch(psm_ctx *const *ctxs, int n)
         if (c->next_depth >= 0 && c->range_next_pending) {
             PSM_HIP(c0, hipEventSynchronize(c->ev_up));
             if (!range_inside(c, 1, -PSM_IMG_EXP, PSM_IMG_EXP)) return fail(c0, "psm_compute_batch: the float images of context %d are outside the select forms' domain (2^-10 .. 2^10)", i);
-        } else if (c->next_depth < 0 && !scaled_forms_ok(c))
+        } else if (c->next_depth < 0 && !c->img_domain_ok)      // (only the IMAGES matter: the batch rebuilds the costs from them,
             return fail(c0, "psm_compute_batch: the float images of context %d are outside the select forms' domain (2^-10 .. 2^10); use the single-pair entry points", i);
-    }
+    }                                                           //  as psm_cost_construct does before it forgets an uploaded volume's range)
     const int W = c0->W, H = c0->H, Dloc = c0->Dloc;
     hipStream_t s = c0->stream;
     if (!c0->ev_batch) PSM_HIP(c0, hipEventCreateWithFlags(&c0->ev_batch, hipEventDisableTiming));
@@ -89,6 +93,7 @@ extern "C" int psm_compute_batch(psm_ctx *const *ctxs, int n)
             c0->batch_tab = nullptr;
             c0->batch_pin = nullptr;
             c0->batch_cap = 0;
+            c0->batch_host.clear();          // (should an allocation below fail, the next call must not take the old table for current)
             PSM_HIP(c0, hipMalloc((void **)&c0->batch_tab, tab.size() * sizeof(PcPair)));
             PSM_HIP(c0, hipHostMalloc((void **)&c0->batch_pin, 2 * tab.size() * sizeof(PcPair), hipHostMallocDefault));
             c0->batch_cap = tab.size();
@@ -180,6 +185,7 @@ extern "C" int psm_compute_batch(psm_ctx *const *ctxs, int n)
         c->raw_rows[0] = c->raw_rows[1] = psm_ctx::RAW_NONE;
         c->gf_virtual[0] = c->gf_virtual[1] = true;
         c->have_cost = true;
+        c->vol_domain_ok[0] = c->vol_domain_ok[1] = true;      // (the costs are those of the images again, as after psm_cost_construct)
         c->have_keys = c->have_keys_side[0] = c->have_keys_side[1] = !whole;   // (a disparity shard: its minima are what psm_disp_merge_ctx takes)
         c->have_maps = whole;
         c->have_valid = false;

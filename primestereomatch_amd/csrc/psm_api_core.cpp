@@ -379,6 +379,8 @@ int psm_share_streams(psm_ctx *const *ctxs, int n)
     for (int i = 0; i < n; ++i) {
         if (!ctxs[i] || ctxs[i]->device != c0->device) return fail(c0, "psm_share_streams: context %d is NULL or on another device", i);
         if (ctxs[i]->shared) return fail(c0, "psm_share_streams: context %d already shares streams", i);
+        for (int j = 0; j < i; ++j)      // (a second visit would destroy the set's own upload stream and count the reference twice)
+            if (ctxs[j] == ctxs[i]) return fail(c0, "psm_share_streams: context %d appears twice", i);
         if (ctxs[i]->stream != ctxs[i]->own_stream) return fail(c0, "psm_share_streams: context %d runs on a caller's stream (psm_set_stream)", i);
     }
     if (bind(c0)) return 1;

@@ -38,39 +38,14 @@
 #include "psm_dev.h"
 #include "../../include/primesm_hip.h"
 
-#include <cstdlib>
 #include <mutex>
 
-#ifndef PSM_PC_TIMING
-#define PSM_PC_TIMING 0   // 1: every wave accumulates its cycles between barriers (work) and inside them (wait) per role
-#endif
+#include "psm_pc_debug.inc"   // PSM_PC_TIMING per-workgroup traces and the PSM_EXPERIMENTS knobs: all compiled out of the product
 
 namespace psm {
 
-#if PSM_PC_TIMING
-__device__ unsigned long long g_pc_dbg[8];   // work cycles of waves A0, A1, B0, B1, then their barrier-wait cycles
-// per workgroup of the LAST launch (scripts/dbg_pc_trace.py, dbg_pc_clock.py): start and end on the constant 100 MHz counter and
-// on the shader-clock counter, the hardware id (XCC, SE, CU), and the SIMD each of its four waves runs on
-constexpr int PC_TRACE_N = 1 << 16;
-__device__ unsigned long long g_pc_trace[3 * PC_TRACE_N];
-__device__ unsigned long long g_pc_clk[2 * PC_TRACE_N];
-__device__ unsigned char g_pc_simd[4 * PC_TRACE_N];
-#define PC_SYNC()                                                                \
-    {                                                                            \
-        const unsigned long long a_ = __builtin_readcyclecounter();              \
-        __syncthreads();                                                         \
-        const unsigned long long b_ = __builtin_readcyclecounter();              \
-        q_work += a_ - q_mark; q_wait += b_ - a_; q_mark = b_;                   \
-    }
-#else
-#define PC_SYNC() __syncthreads()
-#endif
-
 typedef float f4v __attribute__((ext_vector_type(4)));
 
-#ifndef PSM_PC_ATTR
-#define PSM_PC_ATTR
-#endif
 // Occupancy of the key form (MODE 2, 4/5 of the slices of a 256-slice volume): four workgroups per CU instead of three.
 // The kernel is latency-sensitive at 3 waves per SIMD (barrier waits, LDS round trips); 128 VGPRs need a shorter load
 // look-ahead - consumer: G1 / keys two rows ahead instead of a batch, selection row by row inside the steps; producer: guidance
@@ -79,21 +54,15 @@ typedef float f4v __attribute__((ext_vector_type(4)));
 // per frame).  The plane form (MODE 1) stays at three workgroups per CU: its own diet got it from 159 to 139 registers / 9
 // spills under the cap, but there the shorter look-ahead costs what the fourth workgroup gains.
 constexpr int PC_RING = 4;   // batches of four model rows kept in LDS
-#ifndef PSM_PC_NT
-#define PSM_PC_NT 1          // MODE 0: nontemporal stores of the output rows (the volume is next read long after it left the L2)
-#endif
 
 template <int MODE> struct PcLayout;
 template <> struct PcLayout<0> { static constexpr int NA = 2, NB = 2, OUT_A = 52, OUT_B = 48, COLS = 96; };
 template <> struct PcLayout<1> { static constexpr int NA = 2, NB = 2, OUT_A = 57, OUT_B = 54, COLS = 107; };
 template <> struct PcLayout<2> : PcLayout<1> {};
-#ifndef PSM_K_LD_AUX
-#define PSM_K_LD_AUX 0       // cache policy of MODE 1's record loads.  A record is only ever read by the lane that wrote it
-#endif                       // (one slice earlier), and a thread always observes its own stores: plain cached loads are
-                             // coherent here.  (16 = sc1 bypasses the L2 as well: measured 25 % slower kernel.)
-#ifndef PSM_KEY_LD_AUX
-#define PSM_KEY_LD_AUX 16    // cache policy of MODE 2's key loads: 16 = sc1 (agent scope: never from this CU's L1)
-#endif
+constexpr int PC_K_LD_AUX = 0;     // cache policy of MODE 1's record loads.  A record is only ever read by the lane that wrote it
+                                   // (one slice earlier), and a thread always observes its own stores: plain cached loads are
+                                   // coherent here.  (16 = sc1 bypasses the L2 as well: measured 25 % slower kernel.)
+constexpr int PC_KEY_LD_AUX = 16;  // cache policy of MODE 2's key loads: 16 = sc1 (agent scope: never from this CU's L1)
 
 typedef unsigned pc_u2 __attribute__((ext_vector_type(2)));
 typedef unsigned pc_u4 __attribute__((ext_vector_type(4)));
@@ -180,7 +149,7 @@ __device__ __forceinline__ int pc_slice(const PcSel &o, int i)
 // TOL (PSM_FLAG_F32_TOL, float mode only): level 1 of the horizontal trees of both roles in fp32 (psm_dev.h: hsum8<true>) - within
 // the 1e-4 BASELINE.json states for float mode, not the oracle's bits; the default stays the bit-exact form.
 template <bool VEC4, int CVC, int MODE, bool U8 = false, bool BATCH = false, bool TOL = false>
-__global__ __launch_bounds__(64 * (PcLayout<MODE>::NA + PcLayout<MODE>::NB)) PSM_PC_ATTR
+__global__ __launch_bounds__(64 * (PcLayout<MODE>::NA + PcLayout<MODE>::NB))
 __attribute__((amdgpu_waves_per_eu(MODE == 2 ? 4 : 1, MODE == 2 ? 4 : 8)))   // the key form capped at 128 VGPRs = four workgroups per CU
 void k_cvf_pc(
     const float *__restrict__ vin, float *__restrict__ vout, const float4 *__restrict__ G1a, const float4 *__restrict__ G2a,
@@ -221,10 +190,7 @@ void k_cvf_pc(
     // form 4096 x q and one fp32 multiply by 2^-12 (exact) restores q - bit-identical to the per-sum scaling while no intermediate
     // of a voxel is subnormal or beyond 2^115 (costs are O(1); tests/test_gpu_parity.py::test_scaled_sums_domain).  The storing
     // form (MODE 0) keeps the per-sum scaling, i.e. the oracle's arithmetic op for op.
-#ifndef PSM_PC_SCALED
-#define PSM_PC_SCALED 1
-#endif
-    constexpr bool SCALED = PSM_PC_SCALED && MODE != 0;
+    constexpr bool SCALED = MODE != 0;
     constexpr float QSCALE = SCALED ? 0x1p-12f : 1.0f;
 #define PSM_BOX(N) (SCALED ? (float)(N) : box_out(N))
     static_assert(PC_MCOLS >= PC_COLS + 7 && PC_OUT_A <= 57 && PC_OUT_B <= 57 && (MODE != 0 || (PC_COLS % 4) == 0), "bad producer/consumer layout");
@@ -270,18 +236,7 @@ void k_cvf_pc(
     (void)i1;
     const size_t HW = (size_t)H * W;
 
-#if PSM_PC_TIMING
-    unsigned long long q_work = 0, q_wait = 0, q_mark = __builtin_readcyclecounter();
-    const unsigned trace_id = blockIdx.y * gridDim.x + blockIdx.x;
-    if ((threadIdx.x & 63) == 0 && trace_id < PC_TRACE_N)
-        g_pc_simd[4 * trace_id + (threadIdx.x >> 6)] = (unsigned char)__builtin_amdgcn_s_getreg((4 << 0) | (4 << 6) | (1 << 11));   // HW_ID.SIMD_ID
-    if (threadIdx.x == 0 && trace_id < PC_TRACE_N) {
-        g_pc_trace[3 * trace_id] = wall_clock64();
-        g_pc_clk[2 * trace_id] = __builtin_readcyclecounter();
-        g_pc_trace[3 * trace_id + 2] = ((unsigned long long)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11)) << 32) |   // XCC_ID[3:0]
-                                       __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));                                // HW_ID
-    }
-#endif
+    PC_TRACE_BEGIN()
     const int nds = MODE == 1 ? DC : 1;               // MODE 0 / 2 always run with DC == 1 (one slice per workgroup)
     bool first = true;                                // no slice processed yet: the plane holds nothing
     for (int ds = 0; ds < nds; ++ds) {                // the slices of this chunk, ascending d
@@ -316,22 +271,37 @@ void k_cvf_pc(
         const __amdgpu_buffer_rsrc_t rPo = pc_rsrc(U8 ? (s1 ? (const void *)vin : (const void *)vout) : (const void *)G1, (unsigned)HW * 4u);
         unsigned po[2];
         const int vci = ci * 16, vcp = cpart * 16, vxa = xac * 16;
-#define PSM_ISSUE_PA(SLOT, STEP)                                                        \
+        // The loads of a step come in two groups with different life times: the PIXELS (this column's g1 entry and its partner's /
+        // the stored cost / the partner's bytes) are consumed at the START of their step (cost, three products, conversions), the
+        // d-invariant GUIDANCE (means, 1/DET, adjugate: 40 B) at its END (the solve).  Guidance is issued at the start of the step
+        // before (two step lengths in flight).  The pixels were issued at the same point - one step length in flight - and are what
+        // a producer wave waits for when a line comes from the MALL / HBM instead of the L2 (short launches: several (column group,
+        // segment) pairs share an XCD and every line is a compulsory miss for the first of the workgroups that march in step).
+        // DEEP: a slot's pixels are dead once the products are formed, so the loads of step S + 2 are issued right there, into the
+        // slot step S just read - nearly two step lengths in flight at no register cost.
+        constexpr bool DEEP = !LEANA;
+#define PSM_ISSUE_PIX(SLOT, STEP)                                                       \
     {                                                                                   \
         const int row_ = r101c(mstart - 5 + (STEP), H) * W;                             \
-        int ya_ = mstart - 8 + (STEP);                                                  \
-        ya_ = ya_ < 0 ? 0 : (ya_ > H - 1 ? H - 1 : ya_);                                \
-        const int oa_ = ya_ * W;                                                        \
         if (CVC == 0) pin[SLOT] = pc_load1(rV, vci >> 2, row_ * 4);                     \
         else if (U8) {   /* (this pixel's own bytes ride in gin.w: k_prep_u8) */         \
             po[SLOT] = __builtin_amdgcn_raw_buffer_load_b32(rPo, vcp >> 2, row_ * 4, 0); \
         } else if (!LEANA) oth[SLOT] = pc_load4(rGo, vcp, row_ * 16);                   \
         gin[SLOT] = pc_load4(rG1, vci, row_ * 16);                                      \
-        if (!LEANA) {                                                                   \
-            o2[SLOT] = pc_load4(rG2, vxa, oa_ * 16);                                    \
-            o3[SLOT] = pc_load4(rG3, vxa, oa_ * 16);                                    \
-            o4[SLOT] = pc_load2(rG4, vxa >> 1, oa_ * 8);                                \
-        }                                                                               \
+    }
+#define PSM_ISSUE_GUI(SLOT, STEP)                                                       \
+    {                                                                                   \
+        int ya_ = mstart - 8 + (STEP);                                                  \
+        ya_ = ya_ < 0 ? 0 : (ya_ > H - 1 ? H - 1 : ya_);                                \
+        const int oa_ = ya_ * W;                                                        \
+        o2[SLOT] = pc_load4(rG2, vxa, oa_ * 16);                                        \
+        o3[SLOT] = pc_load4(rG3, vxa, oa_ * 16);                                        \
+        o4[SLOT] = pc_load2(rG4, vxa >> 1, oa_ * 8);                                    \
+    }
+#define PSM_ISSUE_PA(SLOT, STEP)                                                        \
+    {                                                                                   \
+        if (!DEEP) PSM_ISSUE_PIX(SLOT, STEP)                                            \
+        if (!LEANA) PSM_ISSUE_GUI(SLOT, STEP)                                           \
     }
 #define PSM_ISSUE_PA2(STEP)   /* key form: the guidance planes of step STEP, issued when the step starts */ \
     {                                                                                   \
@@ -368,16 +338,19 @@ void k_cvf_pc(
                 p = inb ? p : cb_;                                                                  \
             }                                                                                       \
         }                                                                                           \
+        const float m1_ = __fmul_rn(gin[K & 1].x, p), m2_ = __fmul_rn(gin[K & 1].y, p), m3_ = __fmul_rn(gin[K & 1].z, p); \
+        if (DEEP) PSM_ISSUE_PIX(K & 1, (S) + 2)       /* this slot's pixels are dead: those of step S + 2 take their place */ \
         double h0 = hsum8<TOL>(p, i1, i2, i4);                                                      \
-        double h1 = hsum8<TOL>(__fmul_rn(gin[K & 1].x, p), i1, i2, i4);                             \
-        double h2 = hsum8<TOL>(__fmul_rn(gin[K & 1].y, p), i1, i2, i4);                             \
-        double h3 = hsum8<TOL>(__fmul_rn(gin[K & 1].z, p), i1, i2, i4);                             \
+        double h1 = hsum8<TOL>(m1_, i1, i2, i4);                                                    \
+        double h2 = hsum8<TOL>(m2_, i1, i2, i4);                                                    \
+        double h3 = hsum8<TOL>(m3_, i1, i2, i4);                                                    \
         double n0 = vstep<K>(t0, h0), n1 = vstep<K>(t1, h1), n2 = vstep<K>(t2, h2), n3 = vstep<K>(t3, h3); \
         float4 r = solve_ab(PSM_BOX(n0), PSM_BOX(n1), PSM_BOX(n2), PSM_BOX(n3), o2[LEANA ? 0 : (K & 1)], o3[LEANA ? 0 : (K & 1)], o4[LEANA ? 0 : (K & 1)]); \
         if ((DST) != nullptr && mvalid) (DST)[K * PC_MCOLS] = r;                                    \
         __builtin_amdgcn_sched_barrier(0);                                                          \
     }
         PSM_ISSUE_PA(0, 0)
+        if (DEEP) { PSM_ISSUE_PIX(0, 0) PSM_ISSUE_PIX(1, 1) }
         if (LEANA && CVC != 0 && !U8) oth[0] = pc_load4(rGo, vcp, r101c(mstart - 5, H) * W * 16);
         __builtin_amdgcn_sched_barrier(0);
         {   // warm-up: 8 rows fill the tree (loop bodies stay free of conditionals around the tree updates:
@@ -395,17 +368,16 @@ void k_cvf_pc(
         }
         // two batches per iteration: the s4 slots of the vertical trees change registers with every update, so only after eight
         // steps is every value back in the register the loop header expects (one batch per iteration: 16 v_mov_b64 at the latch)
-#ifndef PSM_PC_UNROLL2
-#define PSM_PC_UNROLL2 1
-#endif
-        for (int b = 0; b < nbA; b += PSM_PC_UNROLL2 ? 2 : 1) {
+        for (int b = 0; b < nbA; b += 2) {
             PSM_BATCH_PA(b)
-            if (PSM_PC_UNROLL2 && __builtin_expect(b + 1 < nbA, 1)) PSM_BATCH_PA(b + 1)
+            if (__builtin_expect(b + 1 < nbA, 1)) PSM_BATCH_PA(b + 1)
         }
 #undef PSM_BATCH_PA
         for (int b = nbA; b < iters; ++b) PC_SYNC();
 #undef PSM_STEP_PA
 #undef PSM_ISSUE_PA
+#undef PSM_ISSUE_PIX
+#undef PSM_ISSUE_GUI
 #undef PSM_ISSUE_PA2
     } else {
         // ---------------- consumer: stage B ----------------
@@ -431,9 +403,9 @@ void k_cvf_pc(
         const __amdgpu_buffer_rsrc_t rKd = pc_rsrc(MODE == 1 ? (const void *)(kdisp + krec) : (const void *)G1, (unsigned)nbmax * PC_COLS * 4u);
 #define PSM_K_LOAD(C)                                                                              \
     {                                                                                              \
-        const pc_u4 v_ = __builtin_amdgcn_raw_buffer_load_b128(rKc, lane * 16, (C) * (PC_COLS * 16), PSM_K_LD_AUX); \
+        const pc_u4 v_ = __builtin_amdgcn_raw_buffer_load_b128(rKc, lane * 16, (C) * (PC_COLS * 16), PC_K_LD_AUX); \
         kq = make_float4(__uint_as_float(v_.x), __uint_as_float(v_.y), __uint_as_float(v_.z), __uint_as_float(v_.w)); \
-        kd4 = __builtin_amdgcn_raw_buffer_load_b32(rKd, lane * 4, (C) * (PC_COLS * 4), PSM_K_LD_AUX); \
+        kd4 = __builtin_amdgcn_raw_buffer_load_b32(rKd, lane * 4, (C) * (PC_COLS * 4), PC_K_LD_AUX); \
     }
         float4 kq = make_float4(__builtin_inff(), __builtin_inff(), __builtin_inff(), __builtin_inff());   // running minima of the current batch
         unsigned kd4 = 0;                                                                                  // and their disparities
@@ -445,7 +417,7 @@ void k_cvf_pc(
     {                                                                                              \
         int yk_ = y0 + (J) - 7;                                                                    \
         yk_ = yk_ < 0 ? 0 : (yk_ > H - 1 ? H - 1 : yk_);                                           \
-        const pc_u2 v_ = __builtin_amdgcn_raw_buffer_load_b64(rKy, xbc * 8, yk_ * W * 8, PSM_KEY_LD_AUX); \
+        const pc_u2 v_ = __builtin_amdgcn_raw_buffer_load_b64(rKy, xbc * 8, yk_ * W * 8, PC_KEY_LD_AUX); \
         kcur[SLOT] = (long long)(((unsigned long long)v_.y << 32) | v_.x);                         \
     }
         const __amdgpu_buffer_rsrc_t rG1 = pc_rsrc(G1, (unsigned)HW * 16u);
@@ -478,11 +450,8 @@ void k_cvf_pc(
                     if (VEC4) {
                         const int cc = lane * 4;
                         if (lane < PC_COLS / 4 && xg + cc < W) {
-#if PSM_PC_NT
+                            // (nontemporal: the volume is next read long after it left the L2)
                             __builtin_nontemporal_store(*reinterpret_cast<const f4v *>(src + cc), reinterpret_cast<f4v *>(row + cc));
-#else
-                            *reinterpret_cast<float4 *>(row + cc) = *reinterpret_cast<const float4 *>(src + cc);
-#endif
                         }
                     } else {
 #pragma unroll
@@ -558,11 +527,8 @@ void k_cvf_pc(
                         dn = better_ ? ((dn & ~(0xffu << (8 * k))) | ((unsigned)dg << (8 * k))) : dn;
                         any |= better_;
                     }
-#ifndef PSM_PC_MASKED_STORES
-#define PSM_PC_MASKED_STORES 1
-#endif
-                    // (per lane: only lanes with an improved row rewrite their record; 0: the whole wave whenever any lane improved)
-                    if (lane < bwidth && (first || (PSM_PC_MASKED_STORES ? any : __builtin_amdgcn_ballot_w64(any) != 0))) {
+                    // (per lane: only lanes with an improved row rewrite their record)
+                    if (lane < bwidth && (first || any)) {
                         const pc_u4 kv = {__float_as_uint(kn[0]), __float_as_uint(kn[1]), __float_as_uint(kn[2]), __float_as_uint(kn[3])};
                         __builtin_amdgcn_raw_buffer_store_b128(kv, rKc, lane * 16, c * (PC_COLS * 16), 0);
                         __builtin_amdgcn_raw_buffer_store_b32(dn, rKd, lane * 4, c * (PC_COLS * 4), 0);
@@ -572,9 +538,9 @@ void k_cvf_pc(
             }
             PC_SYNC();
         };
-        for (int c = 0; c < nbB; c += PSM_PC_UNROLL2 ? 2 : 1) {
+        for (int c = 0; c < nbB; c += 2) {
             batch_b(c);
-            if (PSM_PC_UNROLL2 && __builtin_expect(c + 1 < nbB, 1)) batch_b(c + 1);
+            if (__builtin_expect(c + 1 < nbB, 1)) batch_b(c + 1);
         }
         store_batch(nbB - 1);                          // iteration nbB+2
         PC_SYNC();
@@ -588,13 +554,7 @@ void k_cvf_pc(
 #undef PSM_BOX
     if (ts != nullptr && threadIdx.x == 0)            // ... and when did the last one end (all waves have passed the last barrier)
         (void)__hip_atomic_fetch_max(ts + PC_TS_SLOTS, (unsigned long long)wall_clock64(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#if PSM_PC_TIMING
-    if (threadIdx.x == 0 && trace_id < PC_TRACE_N) { g_pc_trace[3 * trace_id + 1] = wall_clock64(); g_pc_clk[2 * trace_id + 1] = __builtin_readcyclecounter(); }
-    if (lane == 0 && MODE == 1) {
-        atomicAdd(&g_pc_dbg[wave], q_work);
-        atomicAdd(&g_pc_dbg[4 + wave], q_wait);
-    }
-#endif
+    PC_TRACE_END()
 }
 
 // chunk planes -> packed WTA key and / or final map per pixel (minimum over the chunks; pack_key_f32 makes the signed
@@ -661,38 +621,6 @@ __global__ __launch_bounds__(256) void k_chunk_min(const float4 *kcost, const un
 
 }  // namespace psm
 
-// debug: read and clear the per-wave cycle counters of k_cvf_pc (all zero unless built with -DPSM_PC_TIMING=1)
-extern "C" int psm_debug_pc_cycles(unsigned long long *out8)
-{
-    for (int i = 0; i < 8; ++i) out8[i] = 0;
-#if PSM_PC_TIMING
-    if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(psm::g_pc_dbg), 8 * sizeof(unsigned long long)) != hipSuccess) return 1;
-    unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    if (hipMemcpyToSymbol(HIP_SYMBOL(psm::g_pc_dbg), z, sizeof z) != hipSuccess) return 1;
-#endif
-    return 0;
-}
-
-// debug: the per-workgroup trace of the last k_cvf_pc launch - out3: (start, end, hardware id) x n, clk2: shader-clock counter at
-// start and end x n, simd4: SIMD of the four waves x n; any pointer may be null (all zero unless built with -DPSM_PC_TIMING=1)
-extern "C" int psm_debug_pc_trace(unsigned long long *out3, unsigned long long *clk2, unsigned char *simd4, int n)
-{
-    for (int i = 0; i < n; ++i) {
-        if (out3) out3[3 * i] = out3[3 * i + 1] = out3[3 * i + 2] = 0;
-        if (clk2) clk2[2 * i] = clk2[2 * i + 1] = 0;
-        if (simd4) simd4[4 * i] = simd4[4 * i + 1] = simd4[4 * i + 2] = simd4[4 * i + 3] = 255;
-    }
-#if PSM_PC_TIMING
-    if (n > psm::PC_TRACE_N) n = psm::PC_TRACE_N;
-    if (out3 && hipMemcpyFromSymbol(out3, HIP_SYMBOL(psm::g_pc_trace), 3 * (size_t)n * sizeof(unsigned long long)) != hipSuccess) return 1;
-    if (clk2 && hipMemcpyFromSymbol(clk2, HIP_SYMBOL(psm::g_pc_clk), 2 * (size_t)n * sizeof(unsigned long long)) != hipSuccess) return 1;
-    if (simd4 && hipMemcpyFromSymbol(simd4, HIP_SYMBOL(psm::g_pc_simd), 4 * (size_t)n) != hipSuccess) return 1;
-    void *sym = nullptr;                                   // clear the start stamps: a smaller launch must not show stale workgroups
-    if (hipGetSymbolAddress(&sym, HIP_SYMBOL(psm::g_pc_trace)) == hipSuccess) (void)hipMemset(sym, 0, 3 * (size_t)psm::PC_TRACE_N * sizeof(unsigned long long));
-#endif
-    return 0;
-}
-
 namespace psm {
 
 // key plane(s) <- key(+inf, 0): the "no candidate yet" value of MODE 2
@@ -723,12 +651,6 @@ PcDev pc_dev()
     return d;
 }
 
-#ifdef PSM_EXPERIMENTS   // tuning knobs of experiment builds only (none changes a result); the product reads no environment
-static int pc_env(const char *name) { const char *e = getenv(name); return e ? atoi(e) : 0; }
-#define PSM_KNOB(NAME, DEFAULT) (pc_env(NAME) > 0 ? pc_env(NAME) : (DEFAULT))
-#else
-#define PSM_KNOB(NAME, DEFAULT) (DEFAULT)
-#endif
 
 // Segment count k (and, for the plane form, slices per chunk DC): every segment re-walks 14 halo rows, and the launch runs in
 // rounds of resident workgroups - per XCD ceil(pairs / nxcd) (column group, segment) pairs x chunks over cus_per_xcd CUs x 3

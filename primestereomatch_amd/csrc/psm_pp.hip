@@ -65,12 +65,14 @@ __device__ const unsigned wm_sp_right[WM_TAPS] = PSM_WM_SP_TAB_RIGHT;
 
 // clrWgt / (SIG_CLR * SIG_CLR) (float / double -> double, src/PP.cpp:175,224) without the division: one Newton step on
 // x * RN(1 / c) with fused multiply-adds.  Bit-identical to __ddiv_rn((double)x, 0.1 * 0.1) for EVERY non-negative finite float x -
-// checked exhaustively, 2^31 operands, by scripts/exp/wm_arith.hip on the device (a double division is ~35 instructions).
+// checked exhaustively, 2^31 operands, by scripts/exp/wm_arith.hip on the device (a double division is ~35 instructions);
+// +inf and NaN take the division itself.
 __device__ __forceinline__ double wm_div_sig_clr(float xf)
 {
     const double c = 0.1 * 0.1, r = 1.0 / (0.1 * 0.1);
     const double x = (double)xf;
-    const double q0 = __dmul_rn(x, r);
+    if (!(xf < __builtin_inff())) return __ddiv_rn(x, c);   // +inf (squared colour differences of float images overflow) / NaN: the fused
+    const double q0 = __dmul_rn(x, r);                      // form would turn inf into NaN (fma(-inf, c, inf)); the division gives the reference's inf
     return __fma_rn(__fma_rn(-q0, c, x), r, q0);
 }
 // sqrt(float) of <cmath>, correctly rounded.  __fsqrt_rn of this ROCm is NOT (one ulp low for sqrt(162.0f) and for 15 % of random
@@ -80,7 +82,7 @@ __device__ __forceinline__ double wm_div_sig_clr(float xf)
 // operand (exhaustive, scripts/exp/wm_arith.hip); below (and for 0) the double root stays.
 __device__ __forceinline__ float wm_sqrtf(float x)
 {
-    if (!(x >= 0x1p-100f)) return (float)sqrt((double)x);
+    if (!(x >= 0x1p-100f) || !(x < __builtin_inff())) return (float)sqrt((double)x);   // (+inf: rsq gives 0 and inf * 0 a NaN; sqrt gives inf)
     const float r = __builtin_amdgcn_rsqf(x);
     const float s = __fmul_rn(x, r);
     return __fmaf_rn(__fmaf_rn(-s, s, x), __fmul_rn(0.5f, r), s);

@@ -335,5 +335,7 @@ def share_streams(des):
     """The DispEst objects of a batch run on one compute stream and one copy stream each way (psm_share_streams) - call once
     before a frame loop over batches."""
     des = list(des)
+    if not des:
+        return
     arr = (C.c_void_p * len(des))(*[d._h for d in des])
     capi.check(des[0]._lib.psm_share_streams(arr, len(des)), des[0]._h, "share_streams")

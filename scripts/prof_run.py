@@ -9,7 +9,7 @@ sys.path.insert(0, ROOT)
 import primestereomatch_amd as P  # noqa: E402
 from primestereomatch_amd import capi, synth  # noqa: E402
 
-cfg = {"c4": (1920, 1080, 256), "c3": (1280, 720, 128), "c2": (450, 375, 64)}[sys.argv[1] if len(sys.argv) > 1 else "c4"]
+cfg = {"c4": (1920, 1080, 256), "c3": (1280, 720, 128), "c2": (450, 375, 64), "c5": (3840, 2160, 256)}[sys.argv[1] if len(sys.argv) > 1 else "c4"]
 W, H, D = cfg
 l, r, _ = synth.make_pair(W, H, D, seed=0)
 dr = tuple(int(v) for v in os.environ["PSM_DRANGE"].split(",")) if os.environ.get("PSM_DRANGE") else None   # disparity shard
