@@ -346,6 +346,13 @@ int psm_set_option(psm_ctx *c, int option, int value)
         c->march.waves = value; return 0;
     case PSM_OPT_FLAGS:
         if (value & ~PSM_FLAGS_ALL) return fail(c, "psm_set_option: unknown flag bits 0x%x", value & ~PSM_FLAGS_ALL);
+        if ((value & PSM_FLAG_F32_TOL) && (value & PSM_FLAG_FMA_SOLVE))
+            return fail(c, "psm_set_option: PSM_FLAG_F32_TOL and PSM_FLAG_FMA_SOLVE exclude each other (one arithmetic variant at a time)");
+        if (c->dtype == PSM_U8) value &= ~PSM_FLAG_FMA_SOLVE;       // float mode only: 8-bit mode ignores it (as it ignores PSM_FLAG_F32_TOL)
+        if ((value ^ c->march.flags) & PSM_FLAG_FMA_SOLVE) {       // the minors and 1/DET in the guidance planes are those of the other reading
+            c->have_guid[0] = c->have_guid[1] = false;
+            c->guid_y0 = c->guid_y1 = 0;
+        }
         c->march.flags = value; return 0;
     case PSM_OPT_GRAPH: c->opt_graph = value != 0; return 0;
     default: return fail(c, "psm_set_option: unknown option %d", option);

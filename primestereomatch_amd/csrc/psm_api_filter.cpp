@@ -152,7 +152,7 @@ int ensure_whole_planes(psm_ctx *c)
     if (!(c->have_guid[0] && c->have_guid[1])) {
         {
             Prof p(c, PSM_K_GUIDE);
-            launch_guidance(c->stream, c->g[0], c->W, c->H, &c->g[1]);
+            launch_guidance(c->stream, c->g[0], c->W, c->H, &c->g[1], 0, 0, fma_solve(c));
         }
         c->have_guid[0] = c->have_guid[1] = true;
         c->guid_y0 = 0;
@@ -240,7 +240,7 @@ int filter_side(psm_ctx *c, int side, bool stage_b)
     if (!c->have_guid[side]) {
         // the guidance of BOTH images in one launch the first time either side asks (the other side's call then finds it)
         Prof p(c, PSM_K_GUIDE);
-        launch_guidance(c->stream, c->g[0], W, H, &c->g[1]);
+        launch_guidance(c->stream, c->g[0], W, H, &c->g[1], 0, 0, fma_solve(c));
         c->have_guid[0] = c->have_guid[1] = true;
     }
     // Default: the fused kernel in "select" mode - the WTA over the local slices runs inside the filter, the filtered
@@ -273,6 +273,8 @@ int filter_side(psm_ctx *c, int side, bool stage_b)
         launch_u8_to_f32(c->stream, (const uint8_t *)c->vol[side], fv, V);
     }
     const bool fused = stage_b && c->opt_variant == 0;
+    if (!fused && fma_solve(c))
+        return fail(c, "PSM_FLAG_FMA_SOLVE: stage A alone (psm_filter_stage_a) and the direct kernel variant exist in the canonical arithmetic only");
     if (!fused && materialize(c, side)) return 1;   // stage A alone / the direct variant read a real cost volume
     if (fused) {
         if (c->raw_rows[side] != psm_ctx::RAW_ALL) {
@@ -340,7 +342,7 @@ int filter_both(psm_ctx *c)
         const int gy1 = striped ? (c->march.yend + 4 < c->H ? c->march.yend + 4 : c->H) : c->H;
         if (!(c->guid_y1 > c->guid_y0 && c->guid_y0 <= gy0 && c->guid_y1 >= gy1)) {
             Prof p(c, PSM_K_GUIDE);
-            launch_guidance(c->stream, c->g[0], c->W, c->H, &c->g[1], gy0, gy1);
+            launch_guidance(c->stream, c->g[0], c->W, c->H, &c->g[1], gy0, gy1, fma_solve(c));
             c->guid_y0 = gy0;
             c->guid_y1 = gy1;
             if (gy0 == 0 && gy1 == c->H) c->have_guid[0] = c->have_guid[1] = true;

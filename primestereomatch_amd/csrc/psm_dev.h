@@ -99,6 +99,11 @@ __device__ __forceinline__ double vstep(VTree &t, double hs)
 
 // The per-voxel linear-model solve of GuidedFilter_cv (src/CVF.cpp:91-155) with the d-invariant
 // adjugate entries and 1/DET taken from the guidance planes.
+// FMA (PSM_FLAG_FMA_SOLVE): the reading of src/CVF.cpp:129-147 a compiler with -ffp-contract=fast gives on an FMA target (GCC's
+// default; the ARM boards the reference ran on) - s + x*y of the three accumulations as one fma, left to right (oracle:
+// PSMO_VAR_FMA_SOLVE; the minors and 1/DET in the guidance planes are then the fused forms too, k_guide_march).  The covariance
+// and the b line are cv::Mat passes in the reference (src/CVF.cpp:91-95,152-155) - separate multiply and subtract either way.
+template <bool FMA = false>
 __device__ __forceinline__ float4 solve_ab(float mp, float mIp0, float mIp1, float mIp2, float4 g2,
                                            float4 g3, float2 g4)
 {
@@ -107,9 +112,16 @@ __device__ __forceinline__ float4 solve_ab(float mp, float mIp0, float mIp1, flo
     float c0 = __fsub_rn(mIp0, __fmul_rn(mI0, mp));
     float c1 = __fsub_rn(mIp1, __fmul_rn(mI1, mp));
     float c2 = __fsub_rn(mIp2, __fmul_rn(mI2, mp));
-    float a0 = __fmul_rn(inv, __fadd_rn(__fadd_rn(__fmul_rn(c0, A00), __fmul_rn(c1, A01)), __fmul_rn(c2, A02)));
-    float a1 = __fmul_rn(inv, __fadd_rn(__fadd_rn(__fmul_rn(c0, A01), __fmul_rn(c1, A11)), __fmul_rn(c2, A12)));
-    float a2 = __fmul_rn(inv, __fadd_rn(__fadd_rn(__fmul_rn(c0, A02), __fmul_rn(c1, A12)), __fmul_rn(c2, A22)));
+    float a0, a1, a2;
+    if (FMA) {
+        a0 = __fmul_rn(inv, __fmaf_rn(c2, A02, __fmaf_rn(c1, A01, __fmul_rn(c0, A00))));
+        a1 = __fmul_rn(inv, __fmaf_rn(c2, A12, __fmaf_rn(c1, A11, __fmul_rn(c0, A01))));
+        a2 = __fmul_rn(inv, __fmaf_rn(c2, A22, __fmaf_rn(c1, A12, __fmul_rn(c0, A02))));
+    } else {
+        a0 = __fmul_rn(inv, __fadd_rn(__fadd_rn(__fmul_rn(c0, A00), __fmul_rn(c1, A01)), __fmul_rn(c2, A02)));
+        a1 = __fmul_rn(inv, __fadd_rn(__fadd_rn(__fmul_rn(c0, A01), __fmul_rn(c1, A11)), __fmul_rn(c2, A12)));
+        a2 = __fmul_rn(inv, __fadd_rn(__fadd_rn(__fmul_rn(c0, A02), __fmul_rn(c1, A12)), __fmul_rn(c2, A22)));
+    }
     float b = __fsub_rn(__fsub_rn(__fsub_rn(mp, __fmul_rn(a0, mI0)), __fmul_rn(a1, mI1)), __fmul_rn(a2, mI2));
     return make_float4(a0, a1, a2, b);
 }

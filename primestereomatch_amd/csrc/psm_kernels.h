@@ -51,7 +51,8 @@ void launch_range_f32(hipStream_t s, const float *p, size_t n, unsigned *out);
 void launch_prep(hipStream_t s, const void *src, size_t pitch, int depth_f32, int W, int H, float4 *g1, const void *src1 = nullptr,
                  float4 *g11 = nullptr);
 // g1 -> g2,g3,g4 (second != NULL: both images in one launch; [ybeg, yend): rows of g2..g4 to produce, default all)
-void launch_guidance(hipStream_t s, Guidance g, int W, int H, const Guidance *second = nullptr, int ybeg = 0, int yend = 0);
+void launch_guidance(hipStream_t s, Guidance g, int W, int H, const Guidance *second = nullptr, int ybeg = 0, int yend = 0,
+                     bool fma = false);   // fma: PSM_FLAG_FMA_SOLVE - minors and DET in their fused forms
 // cost volume slices [d_begin, d_begin+Dloc) of one side.  base: g1 of the side's own image.
 void launch_cvc(hipStream_t s, const float4 *g1_base, const float4 *g1_other, float *vol, int W, int H,
                 int d_begin, int Dloc, int right, int ybeg, int yend);

@@ -120,7 +120,7 @@ void launch_range_f32(hipStream_t s, const float *p, size_t n, unsigned *out)
 // wrote and re-read 149 MB of fp64 row sums per side; this work does not shrink when the job is sharded over GPUs.)
 // ------------------------------------------------------------------------------------------
 struct GuideM { float m[9]; };
-__device__ __forceinline__ void guide_finish(const float *m, float4 &g2, float4 &g3, float2 &g4)
+__device__ __forceinline__ void guide_finish(const float *m, float4 &g2, float4 &g3, float2 &g4, bool fma)
 {   // var_k = box(I_c*I_c') - mean_c*mean_c' (src/CVF.cpp:58-68); Sigma + eps I, DET (src/CVF.cpp:120-132); adjugate entries as
     // written at src/CVF.cpp:133-147 (the matrix is symmetric, so the nine expressions take six distinct values bit for bit)
     const float eps = 0.0001f;  // GIF_EPS, include/ComFunc.h:50
@@ -144,6 +144,22 @@ __device__ __forceinline__ void guide_finish(const float *m, float4 &g2, float4 
     float A11 = __fsub_rn(__fmul_rn(a33, a11), __fmul_rn(a31, a13));
     float A12 = __fsub_rn(__fmul_rn(a31, a12), __fmul_rn(a32, a11));
     float A22 = __fsub_rn(__fmul_rn(a22, a11), __fmul_rn(a21, a12));
+    if (fma) {
+        // PSM_FLAG_FMA_SOLVE: x*y - z*w -> fma(x, y, -(z*w)) and s + x*y -> fma(x, y, s), the contraction GCC applies left to
+        // right to src/CVF.cpp:129-147 on an FMA target (oracle: PSMO_VAR_FMA_SOLVE).  Still six distinct values: the pairs of
+        // expressions that coincide in the canon (symmetric matrix) have the same fused / rounded product here as well.
+#define PSM_M2(x, y, z, w) __fmaf_rn((x), (y), -__fmul_rn((z), (w)))
+        const float m00 = PSM_M2(a33, a22, a32, a23), m01 = PSM_M2(a33, a12, a32, a13), m02 = PSM_M2(a23, a12, a22, a13);
+        det = __fmaf_rn(a31, m02, __fmaf_rn(-a21, m01, __fmul_rn(a11, m00)));
+        inv = __fdiv_rn(1.0f, det);
+        A00 = m00;
+        A01 = PSM_M2(a31, a23, a33, a21);
+        A02 = PSM_M2(a32, a21, a31, a22);
+        A11 = PSM_M2(a33, a11, a31, a13);
+        A12 = PSM_M2(a31, a12, a32, a11);
+        A22 = PSM_M2(a22, a11, a21, a12);
+#undef PSM_M2
+    }
     g2 = make_float4(m[0], m[1], m[2], inv);
     g3 = make_float4(A00, A01, A02, A11);
     g4 = make_float2(A12, A22);
@@ -156,7 +172,7 @@ __device__ __forceinline__ void guide_finish(const float *m, float4 &g2, float4 
 // i.e. the kernel took as long as ONE wave's serial march (54 us at 1080p, 19 us at 450 x 375).  Same arithmetic, same bits.
 __global__ __launch_bounds__(192) void k_guide_march(const float4 *g1, int W, int H, int nstrips, int seg_rows,
                                                     float4 *g2, float4 *g3, float2 *g4, Guidance second, int ybeg, int yend,
-                                                    const PcPair *__restrict__ tab)
+                                                    const PcPair *__restrict__ tab, int fma)
 {
     __shared__ float ms[2][4][9][64];            // [batch parity][row of the batch][channel][lane]
     if (tab) { const Guidance gg = tab[blockIdx.y >> 1].g[blockIdx.y & 1]; g1 = gg.g1; g2 = gg.g2; g3 = gg.g3; g4 = gg.g4; }   // batch: image y & 1 of pair y >> 1
@@ -203,7 +219,7 @@ __global__ __launch_bounds__(192) void k_guide_march(const float4 *g1, int W, in
 #pragma unroll
                 for (int c = 0; c < 9; ++c) m[c] = ms[b & 1][k][c][col];
                 float4 r2, r3; float2 r4;
-                guide_finish(m, r2, r3, r4);
+                guide_finish(m, r2, r3, r4, fma != 0);
                 const size_t o = (size_t)(ybase + step - 3) * W + xo;
                 g2[o] = r2; g3[o] = r3; g4[o] = r4;
             }
@@ -211,7 +227,7 @@ __global__ __launch_bounds__(192) void k_guide_march(const float4 *g1, int W, in
     }
 }
 
-void launch_guidance(hipStream_t s, Guidance g, int W, int H, const Guidance *second, int ybeg, int yend)
+void launch_guidance(hipStream_t s, Guidance g, int W, int H, const Guidance *second, int ybeg, int yend, bool fma)
 {   // second != NULL: the guidance of both images in one launch; [ybeg, yend) (yend <= ybeg: all rows): the rows of g2..g4
     // to produce - a row stripe of the filter needs its own rows + 4 either side
     if (yend <= ybeg) { ybeg = 0; yend = H; }
@@ -225,7 +241,7 @@ void launch_guidance(hipStream_t s, Guidance g, int W, int H, const Guidance *se
     while (seg_rows < 64 && nstrips * ((rows + seg_rows - 1) / seg_rows) > wgs) ++seg_rows;
     const int nsegs = (rows + seg_rows - 1) / seg_rows;
     hipLaunchKernelGGL(k_guide_march, dim3(nstrips * nsegs, second ? 2 : 1), dim3(192), 0, s, (const float4 *)g.g1, W, H, nstrips, seg_rows, g.g2, g.g3, g.g4,
-                       second ? *second : Guidance{}, ybeg, yend, (const PcPair *)nullptr);
+                       second ? *second : Guidance{}, ybeg, yend, (const PcPair *)nullptr, fma ? 1 : 0);
 }
 
 // ---- the same two kernels for every pair of a batch (psm_compute_batch): one launch each, images indexed through the table ----
@@ -238,7 +254,7 @@ void launch_guidance_batch(hipStream_t s, const PcPair *tab, int npairs, int W, 
     while (seg_rows < 64 && nstrips * ((H + seg_rows - 1) / seg_rows) > wgs) ++seg_rows;
     const int nsegs = (H + seg_rows - 1) / seg_rows;
     hipLaunchKernelGGL(k_guide_march, dim3(nstrips * nsegs, 2 * npairs), dim3(192), 0, s, (const float4 *)nullptr, W, H, nstrips, seg_rows,
-                       (float4 *)nullptr, (float4 *)nullptr, (float2 *)nullptr, Guidance{}, 0, H, tab);
+                       (float4 *)nullptr, (float4 *)nullptr, (float2 *)nullptr, Guidance{}, 0, H, tab, 0);
 }
 
 // ------------------------------------------------------------------------------------------

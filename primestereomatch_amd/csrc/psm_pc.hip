@@ -146,9 +146,12 @@ __device__ __forceinline__ int pc_slice(const PcSel &o, int i)
 // of oracle/psm_oracle.h, in one pass and without an 8-bit volume in memory.
 // BATCH (psm_compute_batch): blockIdx.z = stereo pair; every plane pointer of the pair comes from the device table `batch`
 // (uniform: scalar loads), so B Middlebury-size pairs fill the chip for many rounds of workgroups instead of 1.7.
-// TOL (PSM_FLAG_F32_TOL, float mode only): level 1 of the horizontal trees of both roles in fp32 (psm_dev.h: hsum8<true>) - within
-// the 1e-4 BASELINE.json states for float mode, not the oracle's bits; the default stays the bit-exact form.
-template <bool VEC4, int CVC, int MODE, bool U8 = false, bool BATCH = false, bool TOL = false>
+// VAR - the two opt-in arithmetic variants of float mode (0: the canon, bit-exact against the oracle):
+//   1 (PSM_FLAG_F32_TOL): level 1 of the horizontal trees of both roles in fp32 (psm_dev.h: hsum8<true>) - within the 1e-4
+//     BASELINE.json states for float mode, not the oracle's bits;
+//   2 (PSM_FLAG_FMA_SOLVE): the 3x3 solve as an FMA target compiles it (psm_dev.h: solve_ab<true>; minors / DET from
+//     k_guide_march in their fused forms) - the oracle's reading PSMO_VAR_FMA_SOLVE, bit for bit.
+template <bool VEC4, int CVC, int MODE, bool U8 = false, bool BATCH = false, int VAR = 0>
 __global__ __launch_bounds__(64 * (PcLayout<MODE>::NA + PcLayout<MODE>::NB))
 __attribute__((amdgpu_waves_per_eu(MODE == 2 ? 4 : 1, MODE == 2 ? 4 : 8)))   // the key form capped at 128 VGPRs = four workgroups per CU
 void k_cvf_pc(
@@ -157,7 +160,8 @@ void k_cvf_pc(
     int ybeg, int yend, const float4 *__restrict__ Gothera, int d_begin, int DC, float *__restrict__ kcosta, unsigned *__restrict__ kdispa, int nbmax,
     PcSide side1, PcSel dyn, unsigned long long *__restrict__ ts, const PcPair *__restrict__ batch)
 {
-    static_assert(!TOL || (!U8 && MODE != 0), "the tolerance form exists for the float select forms only");
+    constexpr bool TOL = VAR == 1, FMA = VAR == 2;
+    static_assert(VAR >= 0 && VAR <= 2 && !(TOL && (U8 || MODE == 0)) && !(FMA && (U8 || BATCH)), "tolerance form: float select forms; FMA solve: float mode, single pair");
     if constexpr (BATCH) {
         static_assert(CVC == 3 && MODE != 0, "batched launches: both volumes per launch, select forms");
         const PcPair pp = batch[blockIdx.z];
@@ -345,7 +349,7 @@ void k_cvf_pc(
         double h2 = hsum8<TOL>(m2_, i1, i2, i4);                                                    \
         double h3 = hsum8<TOL>(m3_, i1, i2, i4);                                                    \
         double n0 = vstep<K>(t0, h0), n1 = vstep<K>(t1, h1), n2 = vstep<K>(t2, h2), n3 = vstep<K>(t3, h3); \
-        float4 r = solve_ab(PSM_BOX(n0), PSM_BOX(n1), PSM_BOX(n2), PSM_BOX(n3), o2[LEANA ? 0 : (K & 1)], o3[LEANA ? 0 : (K & 1)], o4[LEANA ? 0 : (K & 1)]); \
+        float4 r = solve_ab<FMA>(PSM_BOX(n0), PSM_BOX(n1), PSM_BOX(n2), PSM_BOX(n3), o2[LEANA ? 0 : (K & 1)], o3[LEANA ? 0 : (K & 1)], o4[LEANA ? 0 : (K & 1)]); \
         if ((DST) != nullptr && mvalid) (DST)[K * PC_MCOLS] = r;                                    \
         __builtin_amdgcn_sched_barrier(0);                                                          \
     }
@@ -719,14 +723,16 @@ void launch_cvf_fused(hipStream_t s, March m, const float *vin, float *vout, Gui
     if (yend <= ybeg) return;
     const PcPlan pl = pc_plan(W, yend - ybeg, Dloc, m.seg_rows, PC_STORE);
     const dim3 grid(pc_blocks(pl, Dloc)), blk(64 * (PcLayout<0>::NA + PcLayout<0>::NB));
-#define PSM_LAUNCH_PC(V4, CV)                                                                                              \
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_cvf_pc<V4, CV, 0>), grid, blk, 0, s, vin, vout, (const float4 *)gd.g1,            \
+#define PSM_LAUNCH_PC(V4, CV, VR)                                                                                          \
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_cvf_pc<V4, CV, 0, false, false, VR>), grid, blk, 0, s, vin, vout, (const float4 *)gd.g1, \
                        (const float4 *)gd.g2, (const float4 *)gd.g3, (const float2 *)gd.g4, W, H, Dloc, pl.ngroups, pl.nsegs, \
                        pl.seg_rows, ybeg, yend, g1_other, d_begin, 1, (float *)nullptr, (unsigned *)nullptr, 0, PcSide{}, PcSel{0, 1, pl.nxcd, 0, Dloc, 0}, ts, (const PcPair *)nullptr)
+#define PSM_LAUNCH_PCV(V4, CV) { if (m.flags & PSM_FLAG_FMA_SOLVE) PSM_LAUNCH_PC(V4, CV, 2); else PSM_LAUNCH_PC(V4, CV, 0); }
     const bool v4 = (W & 3) == 0;
-    if (cvc_mode == 1) { if (v4) PSM_LAUNCH_PC(true, 1); else PSM_LAUNCH_PC(false, 1); }
-    else if (cvc_mode == 2) { if (v4) PSM_LAUNCH_PC(true, 2); else PSM_LAUNCH_PC(false, 2); }
-    else { if (v4) PSM_LAUNCH_PC(true, 0); else PSM_LAUNCH_PC(false, 0); }
+    if (cvc_mode == 1) { if (v4) PSM_LAUNCH_PCV(true, 1) else PSM_LAUNCH_PCV(false, 1) }
+    else if (cvc_mode == 2) { if (v4) PSM_LAUNCH_PCV(true, 2) else PSM_LAUNCH_PCV(false, 2) }
+    else { if (v4) PSM_LAUNCH_PCV(true, 0) else PSM_LAUNCH_PCV(false, 0) }
+#undef PSM_LAUNCH_PCV
 #undef PSM_LAUNCH_PC
 }
 
@@ -740,16 +746,17 @@ void launch_cvf_select(hipStream_t s, March m, const float *vin, Guidance gd, in
     float *kcost = (float *)scratch;                                           // nchunks * rec_per_chunk float4
     unsigned *kdisp = (unsigned *)(kcost + 4 * pl.rec_per_chunk * pl.nchunks);  // nchunks * rec_per_chunk uchar4
     const dim3 grid(pc_blocks(pl, pl.nchunks)), blk(64 * (PcLayout<1>::NA + PcLayout<1>::NB));
-#define PSM_LAUNCH_PC(CV, U8V, A0, A1)                                                                                      \
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_cvf_pc<false, CV, 1, U8V>), grid, blk, 0, s, A0, A1, (const float4 *)gd.g1,        \
+#define PSM_LAUNCH_PC(CV, U8V, VR, A0, A1)                                                                                  \
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_cvf_pc<false, CV, 1, U8V, false, VR>), grid, blk, 0, s, A0, A1, (const float4 *)gd.g1, \
                        (const float4 *)gd.g2, (const float4 *)gd.g3, (const float2 *)gd.g4, W, H, Dloc, pl.ngroups, pl.nsegs, \
                        pl.seg_rows, m.y0(H), m.y1(H), g1_other, d_begin, pl.DC, kcost, kdisp, pl.nbmax, PcSide{}, sel, ts, (const PcPair *)nullptr)
+    const bool fma = (m.flags & PSM_FLAG_FMA_SOLVE) != 0;      // (one volume per launch: the canon and the FMA reading; no tolerance form)
     if (p4_own && cvc_mode != 0) {
-        if (cvc_mode == 1) PSM_LAUNCH_PC(1, true, (const float *)p4_own, (float *)const_cast<uint8_t *>(p4_other));
-        else PSM_LAUNCH_PC(2, true, (const float *)p4_own, (float *)const_cast<uint8_t *>(p4_other));
-    } else if (cvc_mode == 1) PSM_LAUNCH_PC(1, false, vin, (float *)nullptr);
-    else if (cvc_mode == 2) PSM_LAUNCH_PC(2, false, vin, (float *)nullptr);
-    else PSM_LAUNCH_PC(0, false, vin, (float *)nullptr);
+        if (cvc_mode == 1) PSM_LAUNCH_PC(1, true, 0, (const float *)p4_own, (float *)const_cast<uint8_t *>(p4_other));
+        else PSM_LAUNCH_PC(2, true, 0, (const float *)p4_own, (float *)const_cast<uint8_t *>(p4_other));
+    } else if (cvc_mode == 1) { if (fma) PSM_LAUNCH_PC(1, false, 2, vin, (float *)nullptr); else PSM_LAUNCH_PC(1, false, 0, vin, (float *)nullptr); }
+    else if (cvc_mode == 2) { if (fma) PSM_LAUNCH_PC(2, false, 2, vin, (float *)nullptr); else PSM_LAUNCH_PC(2, false, 0, vin, (float *)nullptr); }
+    else { if (fma) PSM_LAUNCH_PC(0, false, 2, vin, (float *)nullptr); else PSM_LAUNCH_PC(0, false, 0, vin, (float *)nullptr); }
 #undef PSM_LAUNCH_PC
 }
 
@@ -770,7 +777,7 @@ void launch_chunk_min(hipStream_t s, March m, int W, int H, int Dloc, void *scra
 void launch_cvf_select2(hipStream_t s, March m, const Guidance *g, int W, int H, int Dloc, int d_begin, void *scratch,
                         unsigned long long *ts, const uint8_t *const *p4, int sel, int step)
 {
-    const bool tol = !p4 && (m.flags & PSM_FLAG_F32_TOL);
+    const bool tol = !p4 && (m.flags & PSM_FLAG_F32_TOL), fma = !p4 && (m.flags & PSM_FLAG_FMA_SOLVE);
     const PcPlan pl = pc_plan(W, m.rows(H), Dloc, m.seg_rows, PC_PLANES | PC_BOTH);
     const PcSel ps = {sel, step, pl.nxcd, 0, Dloc, 0};
     float *kcost0 = (float *)scratch;
@@ -783,14 +790,14 @@ void launch_cvf_select2(hipStream_t s, March m, const Guidance *g, int W, int H,
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_cvf_pc<false, 3, 1, true>), grid, blk, 0, s, (const float *)p4[0], (float *)const_cast<uint8_t *>(p4[1]),
                            (const float4 *)g[0].g1, (const float4 *)g[0].g2, (const float4 *)g[0].g3, (const float2 *)g[0].g4, W, H, Dloc, pl.ngroups,
                            pl.nsegs, pl.seg_rows, m.y0(H), m.y1(H), (const float4 *)g[1].g1, d_begin, pl.DC, kcost0, kdisp0, pl.nbmax, s1, ps, ts, (const PcPair *)nullptr);
-    else if (tol)
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_cvf_pc<false, 3, 1, false, false, true>), grid, blk, 0, s, (const float *)nullptr, (float *)nullptr, (const float4 *)g[0].g1,
-                           (const float4 *)g[0].g2, (const float4 *)g[0].g3, (const float2 *)g[0].g4, W, H, Dloc, pl.ngroups, pl.nsegs, pl.seg_rows, m.y0(H), m.y1(H),
-                           (const float4 *)g[1].g1, d_begin, pl.DC, kcost0, kdisp0, pl.nbmax, s1, ps, ts, (const PcPair *)nullptr);
-    else
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_cvf_pc<false, 3, 1>), grid, blk, 0, s, (const float *)nullptr, (float *)nullptr, (const float4 *)g[0].g1,
-                           (const float4 *)g[0].g2, (const float4 *)g[0].g3, (const float2 *)g[0].g4, W, H, Dloc, pl.ngroups, pl.nsegs, pl.seg_rows, m.y0(H), m.y1(H),
-                           (const float4 *)g[1].g1, d_begin, pl.DC, kcost0, kdisp0, pl.nbmax, s1, ps, ts, (const PcPair *)nullptr);
+    else {
+#define PSM_LAUNCH_PC(VR)                                                                                                    \
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_cvf_pc<false, 3, 1, false, false, VR>), grid, blk, 0, s, (const float *)nullptr, (float *)nullptr, (const float4 *)g[0].g1, \
+                           (const float4 *)g[0].g2, (const float4 *)g[0].g3, (const float2 *)g[0].g4, W, H, Dloc, pl.ngroups, pl.nsegs, pl.seg_rows, m.y0(H), m.y1(H), \
+                           (const float4 *)g[1].g1, d_begin, pl.DC, kcost0, kdisp0, pl.nbmax, s1, ps, ts, (const PcPair *)nullptr)
+        if (fma) PSM_LAUNCH_PC(2); else if (tol) PSM_LAUNCH_PC(1); else PSM_LAUNCH_PC(0);
+#undef PSM_LAUNCH_PC
+    }
 }
 
 void launch_chunk_min2sides(hipStream_t s, March m, int W, int H, int Dloc, void *scratch, long long *keys, uint8_t *map)
@@ -821,14 +828,14 @@ void launch_cvf_select_keys2(hipStream_t s, March m, const Guidance *g, int W, i
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_cvf_pc<false, 3, 2, true>), grid, blk, 0, s, (const float *)p4[0], (float *)const_cast<uint8_t *>(p4[1]),
                            (const float4 *)g[0].g1, (const float4 *)g[0].g2, (const float4 *)g[0].g3, (const float2 *)g[0].g4, W, H, Dloc, pl.ngroups,
                            pl.nsegs, pl.seg_rows, m.y0(H), m.y1(H), (const float4 *)g[1].g1, d_begin, 1, (float *)keys, (unsigned *)nullptr, 0, s1, ps, ts, (const PcPair *)nullptr);
-    else if (m.flags & PSM_FLAG_F32_TOL)
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_cvf_pc<false, 3, 2, false, false, true>), grid, blk, 0, s, (const float *)nullptr, (float *)nullptr,
-                           (const float4 *)g[0].g1, (const float4 *)g[0].g2, (const float4 *)g[0].g3, (const float2 *)g[0].g4, W, H, Dloc, pl.ngroups,
-                           pl.nsegs, pl.seg_rows, m.y0(H), m.y1(H), (const float4 *)g[1].g1, d_begin, 1, (float *)keys, (unsigned *)nullptr, 0, s1, ps, ts, (const PcPair *)nullptr);
-    else
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_cvf_pc<false, 3, 2, false>), grid, blk, 0, s, (const float *)nullptr, (float *)nullptr,
-                           (const float4 *)g[0].g1, (const float4 *)g[0].g2, (const float4 *)g[0].g3, (const float2 *)g[0].g4, W, H, Dloc, pl.ngroups,
-                           pl.nsegs, pl.seg_rows, m.y0(H), m.y1(H), (const float4 *)g[1].g1, d_begin, 1, (float *)keys, (unsigned *)nullptr, 0, s1, ps, ts, (const PcPair *)nullptr);
+    else {
+#define PSM_LAUNCH_PC(VR)                                                                                                    \
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_cvf_pc<false, 3, 2, false, false, VR>), grid, blk, 0, s, (const float *)nullptr, (float *)nullptr, \
+                           (const float4 *)g[0].g1, (const float4 *)g[0].g2, (const float4 *)g[0].g3, (const float2 *)g[0].g4, W, H, Dloc, pl.ngroups, \
+                           pl.nsegs, pl.seg_rows, m.y0(H), m.y1(H), (const float4 *)g[1].g1, d_begin, 1, (float *)keys, (unsigned *)nullptr, 0, s1, ps, ts, (const PcPair *)nullptr)
+        if (m.flags & PSM_FLAG_FMA_SOLVE) PSM_LAUNCH_PC(2); else if (m.flags & PSM_FLAG_F32_TOL) PSM_LAUNCH_PC(1); else PSM_LAUNCH_PC(0);
+#undef PSM_LAUNCH_PC
+    }
 }
 
 // ---- the same launches for `npairs` stereo pairs at once (psm_compute_batch): blockIdx.z = pair, pointers from the table ----

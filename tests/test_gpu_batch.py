@@ -135,3 +135,46 @@ def test_batch_refuses_what_it_cannot_run(psm):
     finally:
         for d in (a, b, c):
             d.close()
+
+
+def test_share_streams_rejects_duplicates_and_empty_lists_are_noops(psm):
+    """(advisor, round 4) a context listed twice made psm_share_streams destroy the set's own upload stream on the second visit."""
+    from primestereomatch_amd import synth
+    from primestereomatch_amd.dispest import compute_batch, share_streams
+    l, r, _ = synth.make_pair(128, 64, 16, seed=1)
+    des = [psm.DispEst(l, r, 16) for _ in range(2)]
+    try:
+        share_streams([])                      # nothing to do, no IndexError
+        compute_batch([])
+        with pytest.raises(psm.capi.PsmError, match="appears twice"):
+            share_streams([des[0], des[1], des[0]])
+        share_streams(des)                     # the refused call left the contexts untouched
+        for de in des:
+            de.setInputImages_async(l, r)      # (the shared upload stream is alive)
+        compute_batch(des)
+        assert np.array_equal(des[0].download_maps()[0], des[1].download_maps()[0])
+    finally:
+        for de in des:
+            de.close()
+
+
+def test_batch_after_an_out_of_range_volume_upload(psm, oracle):
+    """(advisor, round 4) an earlier out-of-range psm_upload_volume left vol_domain_ok false; the batch rebuilds the costs from the
+    images (as psm_cost_construct does) and must neither be refused with a message about float images nor leave the flag stale."""
+    from primestereomatch_amd import capi, synth
+    from primestereomatch_amd.dispest import compute_batch
+    W, H, D = 128, 64, 16
+    l, r, _ = synth.make_pair(W, H, D, seed=3)
+    ref = oracle.pipeline_f32(l, r, D, threads=8)
+    with psm.DispEst(l, r, D) as de:
+        de.CostConst_GPU()
+        de.upload_volume(0, np.full((D, H, W), 2.0 ** 100, np.float32))      # outside 2^-60 .. 2^60: the storing form's domain
+        compute_batch([de])
+        lm, rm = de.download_maps()
+        assert np.array_equal(lm, ref["ldisp"]) and np.array_equal(rm, ref["rdisp"])
+        de.set_option(capi.PSM_OPT_PROFILE, 2)
+        de.CostConst_GPU(); de.CostFilter_GPU(); de.DispSelect_GPU()          # the single-pair path is back on its select forms
+        forms = [f for _, f in de.filter_launch_times()]
+        assert forms and 0 not in forms, forms
+        assert np.array_equal(de.lDisMap, ref["ldisp"])
+

@@ -257,3 +257,31 @@ def test_device_wm_weights_equal_the_host(psm, oracle):
         bad = np.flatnonzero(dev[:20000].view(np.uint32) != host.view(np.uint32))
         assert bad.size == 0, (right, bad[:5], dev[bad[:5]], host[bad[:5]])
         assert np.isfinite(dev).all() and (dev[: n // 4] > 0).any()
+
+
+def test_device_wm_weights_with_overflowing_colour_distances(psm, oracle):
+    """Round-4 advisor finding: float images are accepted at any scale; channel differences around 1.8e19 make the squared colour
+    distance overflow to +inf.  The reference then forms exp(-inf) = 0 (src/PP.cpp:175,224); the FMA refinements that replace the
+    double division and the root are proven for FINITE operands only and would give NaN - they must fall back.  Also NaN colours:
+    the host's NaN weight, bit for bit."""
+    import ctypes as C
+    lib = psm.capi.load()
+    big = np.float32(3e19)
+    p3 = np.array([[big, 0, 0], [big, big, 0], [1e10, 0, 0], [np.float32(1.8e19), 0, 0], [np.nan, 0, 0], [0.5, 0.25, 0.125]], np.float32)
+    q3 = np.array([[-big, 0, 0], [0, 0, big], [0, 0, 0], [0, 0, 0], [0, 0, 0], [0.5, 0.25, 0.125]], np.float32)
+    wxy = np.array([[0, 0], [3, -2], [9, 9], [1, 1], [0, 0], [0, 0]], np.int32)
+    n = len(p3)
+    pq = np.zeros((n, 8), np.float32)
+    pq[:, 0:3], pq[:, 4:7] = p3, q3
+    fn = lib.psm_debug_wm_weights
+    fn.restype = C.c_int
+    for right in (0, 1):
+        dev = np.empty(n, np.float32)
+        assert fn(pq.ctypes.data_as(C.c_void_p), wxy.ctypes.data_as(C.c_void_p), n, right, dev.ctypes.data_as(C.c_void_p)) == 0
+        with np.errstate(all="ignore"):
+            host = oracle.wm_weights(p3, q3, wxy[:, 0], wxy[:, 1], right)
+        fin = ~np.isnan(host)                 # (a NaN colour gives a NaN weight on both sides; its sign / payload bits carry no meaning)
+        assert np.array_equal(np.isnan(dev), ~fin) and not fin[4], (right, dev, host)
+        assert np.array_equal(dev[fin].view(np.uint32), host[fin].view(np.uint32)), (right, dev, host)
+        assert dev[0] == 0 and dev[1] == 0 and dev[5] == 1.0
+
