@@ -78,19 +78,25 @@ def spawn_ranks(n, args):
             return 124, "no communicator within %d s" % timeout
         return p.returncode, err
 
-    if args.same_device and args.backend == "auto":
+    if args.backend in ("auto", "nccl") and not args.nccl_probe:
+        # Does an RCCL communicator of these ranks come up at all?  One short probe run first (init + one collective, two minutes
+        # at most), so that a transport problem is ONE clear line instead of N tracebacks in the middle of a measurement.
         rc, err = run(["--backend", "nccl", "--nccl-probe"], timeout=120)
         if rc == 0:
             return run(["--backend", "nccl"])[0]
         lines = [ln.strip() for ln in (err or "").splitlines() if ln.strip()]
         why = "rc %d" % rc
-        for pat in ("uplicate GPU", "ncclInvalid", "NCCL error", "NCCL WARN", "DistBackendError", "HIP error", "Error"):
+        for pat in ("bench.py: RCCL", "uplicate GPU", "ncclInvalid", "NCCL error", "NCCL WARN", "DistBackendError", "HIP error", "Error"):
             hit = [ln for ln in lines if pat in ln and "traceback" not in ln]
             if hit:
                 why = hit[-1]
                 break
-        print("bench.py: RCCL with %d ranks on one device failed (%s) - staging the exchange over gloo" % (n, why[:200]), file=sys.stderr)
-        return run(["--backend", "gloo", "--backend-note", "RCCL refused %d ranks on one device: %s" % (n, why[:200])])[0]
+        if args.same_device and args.backend == "auto":
+            print("bench.py: RCCL with %d ranks on one device failed (%s) - staging the exchange over gloo" % (n, why[:200]), file=sys.stderr)
+            return run(["--backend", "gloo", "--backend-note", "RCCL refused %d ranks on one device: %s" % (n, why[:200])])[0]
+        print("bench.py: no RCCL communicator of %d ranks on this node (%s); nothing measured.  (--backend gloo stages the exchange "
+              "through host memory: a correctness run, not a transport)" % (n, why[:300]), file=sys.stderr)
+        return 3
     return run([])[0]
 
 
@@ -149,6 +155,15 @@ def parse_args():
                          "staged through page-locked host tensors (for --same-device when RCCL refuses a duplicate device)")
     ap.add_argument("--nccl-probe", action="store_true", help=argparse.SUPPRESS)     # internal: init RCCL, one collective, exit
     ap.add_argument("--backend-note", default="", help=argparse.SUPPRESS)
+    ap.add_argument("--pair", default="synthetic", choices=["synthetic", "fixture"],
+                    help="c1 / c1x / c2: 'fixture' times the Middlebury pair BASELINE.json names instead of a synthetic pair of its size - Cones "
+                         "(c1; c1x: its 384 x 288 crop) and Teddy (c2) from tests/golden/*_pair.npz, the images the reference ships")
+    ap.add_argument("--frames-in-flight", type=int, default=1,
+                    help="N = 1: F contexts of the configuration, each on its own stream, take the steps in turn - frame i + 1 is queued while "
+                         "frame i runs, so a frame's short kernels (prep, guidance, reduction) and the half-empty last round of its fused "
+                         "launch run beside the next frame's fused kernel.  The reference's use is a frame loop (src/main.cpp:64-73); this is "
+                         "that loop with two frames in the device's queues.  Measured: -9 % at 720p x 128, -19 % at 450 x 375 x 64, nothing at "
+                         "1080p x 256 (profiles/r05/exp_frames_in_flight.txt); default 1")
     ap.add_argument("--shard-sim", type=int, default=0,
                     help="diagnostic: time only rank 0's share of a G-rank job on this GPU (no exchange); "
                          "the JSON line is then NOT the headline metric")
@@ -195,16 +210,24 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
         torch.cuda.set_device(dev_index)
-        if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev_index))
-        else:
-            dist.init_process_group("gloo", rank=rank, world_size=world)
         from primestereomatch_amd.exchange import Exchange
-        ex = Exchange(torch, dist, backend)
-        if args.nccl_probe:      # does a communicator of these ranks come up at all?  (--same-device: usually not)
+        try:
+            import datetime
+            if backend == "nccl":
+                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev_index),
+                                        timeout=datetime.timedelta(seconds=180))
+            else:
+                dist.init_process_group("gloo", rank=rank, world_size=world)
+            ex = Exchange(torch, dist, backend)
+            # the transport's first collective (communicator set-up happens here at the latest): outside every timed region
             t = torch.ones(4, dtype=torch.int64, device="cuda")
             ex.all_reduce_min(t)
             torch.cuda.synchronize()
+        except Exception as e:      # one clear line per rank instead of a traceback in the middle of a measurement
+            msg = " ".join(str(e).split())[:400]
+            print(f"bench.py: {xname} communicator of {world} ranks failed on rank {rank} (device {dev_index}): {type(e).__name__}: {msg}", file=sys.stderr)
+            os._exit(3)
+        if args.nccl_probe:
             dist.destroy_process_group()
             return 0
 
@@ -219,6 +242,16 @@ def main():
     if dtype == "u8" and not args.config.startswith("c1"):
         desc = desc.replace("float32", "8-bit char mode")
     l, r, _ = synth.make_pair(W, H, D, seed=0)
+    data_note = "synthetic"
+    if args.pair == "fixture":
+        if args.config not in ("c1", "c1x", "c2"):
+            raise SystemExit("bench.py: --pair fixture exists for the Middlebury-size configs c1, c1x, c2")
+        which = "teddy" if args.config == "c2" else "cones"
+        g_ = np.load(os.path.join(ROOT, "tests", "golden", which + "_pair.npz"))
+        l, r = np.ascontiguousarray(g_["l_bgr"][:H, :W]), np.ascontiguousarray(g_["r_bgr"][:H, :W])
+        assert l.shape == (H, W, 3), l.shape
+        data_note = f"Middlebury {which.capitalize()} (tests/golden/{which}_pair.npz" + (", top-left 384 x 288 crop)" if args.config == "c1x" else ")")
+        desc = desc.replace("synthetic", f"Middlebury {which.capitalize()}")
     use_batch = (args.batch > 1 or args.batch == -1) and N == 1 and not args.force_dist and args.shard_sim <= 1 and not args.fgf
     B = abs(args.batch) if use_batch else 1      # (--batch -1: ONE pair through the batch entry - one call instead of three)
     batch_pairs = [(l, r)] + [synth.make_pair(W, H, D, seed=b)[:2] for b in range(1, B)]    # B different pairs
@@ -284,6 +317,20 @@ def main():
             de.set_rows(y0, y1)
         if args.fgf:
             de.setSubsampleRate(args.fgf)
+        # --frames-in-flight F: F - 1 more contexts with the same pair, geometry and options; step i runs on context i % F
+        FIF = max(1, args.frames_in_flight) if (not use_dist and not use_batch and not args.fgf) else 1
+        ring = [de]
+        for _ in range(FIF - 1):
+            o_ = P.DispEst(l, r, D, 8, True, device=dev_index, d_range=(d0, d1), dtype=dtype)
+            if args.seg_rows >= 0:
+                o_.set_option(capi.PSM_OPT_SEG_ROWS, args.seg_rows)
+            o_.set_option(capi.PSM_OPT_KERNEL_VARIANT, args.variant)
+            if args.flags >= 0:
+                o_.set_option(capi.PSM_OPT_FLAGS, args.flags)
+            o_.set_option(capi.PSM_OPT_ASYNC, 1)
+            if rows_mode:
+                o_.set_rows(y0, y1)
+            ring.append(o_)
         keys_local = keys_all = None
         kbuf = []
         pending = []                 # (work handles, buffer) of the frame whose merge is still outstanding
@@ -324,7 +371,8 @@ def main():
             if use_batch:                    # all B pairs: one prep, one guidance, one fused grid (blockIdx.z = pair), one reduction
                 compute_batch(batch_all)
                 return
-            de.CostConst_GPU()
+            if FIF == 1:
+                de.CostConst_GPU()
             if args.fgf:
                 de.CostFilter_FGF_GPU()
                 if use_dist:
@@ -365,6 +413,18 @@ def main():
                 w_ = ex.all_reduce_min(kb, async_op=True)
                 pending.append(((w_,), kb))
                 return
+            if FIF > 1:                      # frames in flight: this step's frame goes to the next context of the ring (its own stream)
+                cur = ring[frame[0] % FIF]
+                frame[0] += 1
+                cur.CostConst_GPU()          # (the CostConst_GPU issued above on context 0 is then this ring slot's turn only)
+                cur.CostFilter_GPU()
+                if args.shard_sim > 1 and not rows_mode:
+                    cur.DispSelect_partial()
+                else:
+                    cur.DispSelect_device()
+                if lrc:
+                    cur.LRCheck_device()
+                return
             if use_dist:
                 de.set_key_buffer(keys_local.data_ptr())
             de.CostFilter_GPU()
@@ -388,7 +448,8 @@ def main():
             finish_pending()
             if use_dist:
                 torch.cuda.synchronize()
-            de.synchronize()
+            for o_ in ring:
+                o_.synchronize()
 
         def barrier():
             if use_dist:
@@ -401,17 +462,20 @@ def main():
         if args.graph and use_batch:
             de.set_option(capi.PSM_OPT_GRAPH, 1)
         else:
-            de.set_option(capi.PSM_OPT_PROFILE, 2)
+            for o_ in ring:
+                o_.set_option(capi.PSM_OPT_PROFILE, 2)
         sync()
-        de.filter_launch_times()
+        for o_ in ring:
+            o_.filter_launch_times()
         sync(); barrier(); sync()
         t0 = time.perf_counter()
         for _ in range(args.steps):
             step()
         sync(); barrier(); sync()
         elapsed = time.perf_counter() - t0
-        launch_times = de.filter_launch_times()
-        de.set_option(capi.PSM_OPT_PROFILE, 0)
+        launch_times = [lt for o_ in ring for lt in o_.filter_launch_times()]
+        for o_ in ring:
+            o_.set_option(capi.PSM_OPT_PROFILE, 0)
         if use_dist:
             elapsed = ex.max_float(elapsed)
         rec = {"shard": shard if (use_dist or args.shard_sim > 1) else None,
@@ -436,8 +500,52 @@ def main():
                                                              "max_ms": round(max(v), 4), "per_step": len(v) / args.steps}
                                   for f, v in sorted(by_form.items())}
         rec["filter_ms_per_step"] = sum(ms for ms, _ in launch_times) / args.steps if launch_times else None
+        # ---- N > 1: what a step is made of on every rank - the rank-local kernels alone and the frame's ONE collective alone (each
+        # bracketed by its own synchronisation: their sum exceeds a pipelined step, which overlaps the two) ----
+        if use_dist and not args.fgf:
+            def local_only():
+                de.CostConst_GPU()
+                if rows_mode:
+                    de.set_map_buffer(mbuf[0].data_ptr())
+                    de.CostFilter_GPU()
+                    de.DispSelect_device()
+                else:
+                    de.set_key_buffer(kbuf[0].data_ptr())
+                    de.CostFilter_GPU()
+
+            def exchange_only():
+                if rows_mode:
+                    stripe_exchange(mbuf[0], False)
+                    stripes.assemble(recv, world, H, W, rows_max, mbuf[0])
+                elif exchange == "allgather":
+                    ex.all_gather(keys_all, kbuf[0])
+                    de.DispSelect_merge(keys_all.data_ptr(), world, download=False)
+                elif exchange == "allreduce":
+                    ex.all_reduce_min(kbuf[0])
+                    de.DispSelect_merge(kbuf[0].data_ptr(), 1, download=False)
+
+            comp, coll = [], []
+            for _ in range(5):
+                sync(); barrier()
+                ts = time.perf_counter()
+                local_only()
+                sync()
+                comp.append(1e3 * (time.perf_counter() - ts))
+                barrier()
+                ts = time.perf_counter()
+                exchange_only()
+                sync()
+                coll.append(1e3 * (time.perf_counter() - ts))
+            comp.sort(); coll.sort()
+            per = ex.gather_floats([comp[len(comp) // 2], coll[len(coll) // 2]])
+            rec["per_rank"] = {"compute_ms": [round(v[0], 4) for v in per], "collective_ms": [round(v[1], 4) for v in per],
+                               "note": "medians of 5: the rank-local kernels of one frame (prep, guidance, fused filter, reduction) and the "
+                                       "frame's one exchange (+ gather / merge of its result), each alone between synchronisations; a "
+                                       "pipelined step overlaps the exchange of frame i with the filter of frame i + 1"}
+            step(); sync()                       # (leave the context as a complete step does: final maps of this pair)
         rec["geometry"] = {"rows": [y0, y1], "slices": [d0, d1], "rows_max": rows_max, "parts": parts, "rows_mode": rows_mode}
-        rec["sync"], rec["step"], rec["de"], rec["batch_all"] = sync, step, de, batch_all
+        rec["sync"], rec["step"], rec["de"], rec["batch_all"] = sync, step, de, batch_all + ring[1:]
+        rec["ring"] = ring
         return rec
 
     def check_maps(rec, ref_maps, oracle_maps):
@@ -463,6 +571,10 @@ def main():
     exchange = args.exchange or ("allreduce" if args.shard == "disp" else "allgather")
     head = measure(args.shard, exchange)
     de, sync, step, batch_all = head["de"], head["sync"], head["step"], head["batch_all"]
+
+    def step_all():      # one step on every context of the frame ring (one step when there is no ring): every context holds current maps
+        for _ in head["ring"]:
+            step()
     geo = head["geometry"]
     (y0, y1), (d0, d1), rows_mode = geo["rows"], geo["slices"], geo["rows_mode"]
     ms_per_step, value = head["ms_per_step"], head["value"]
@@ -481,7 +593,7 @@ def main():
         ts = time.perf_counter()
         de.setInputImages(l, r)              # H2D of the u8 pair (blocking)
         h2d = 1e3 * (time.perf_counter() - ts)
-        step(); sync()                       # maps of this pair on the device again
+        step_all(); sync()                       # maps of this pair on the device again
     if rank == 0 and args.shard_sim <= 1:
         de.download_maps()                   # (first call allocates the library's page-locked bounce buffer)
         ts = time.perf_counter()
@@ -519,7 +631,7 @@ def main():
             pcie["frame_loop"] = {"frames": nf, "pairs_per_frame": B, "ms_per_frame": round(loop_ms, 4), "over_step_ms": round(loop_ms - ms_per_step, 4),
                                   "maps_equal_timed_path": bool(np.array_equal(bl[0][0], timed_maps[0]) and np.array_equal(bl[0][1], timed_maps[1])),
                                   "note": "H2D of every frame's B pairs + D2H of its 2 B maps inside the loop, overlapped with the kernels"}
-            step(); sync()
+            step_all(); sync()
         elif not use_dist and args.frame_loop > 0 and not args.fgf:
             # the reference's use is a frame loop (src/main.cpp:64-73) whose stage timers include the copies: pair i+1
             # travels (psm_upload_pair_async) and the maps of frame i-1 return (psm_download_maps_async) while frame i computes
@@ -553,13 +665,15 @@ def main():
                                   "note": "H2D of every frame's pair + D2H of every frame's maps inside the loop, overlapped with the "
                                           "kernels (psm_upload_pair_async / psm_download_maps_async); unpipelined it would be "
                                           f"{ms_per_step + h2d + d2h:.3f} ms"}
-            step(); sync()
+            step_all(); sync()
 
     # ---- per-kernel device time of the OTHER kernels (hipEvents on the launch stream), separate pass: it perturbs the step
     # by a few %, so the fused filter's times are NOT taken from it (filter_launches are the timed region's own) ----
-    de.set_option(capi.PSM_OPT_PROFILE, 1)
-    de.reset_kernel_times()
-    prof_steps = max(2, min(args.steps, 5))
+    ring = head["ring"]
+    for o_ in ring:
+        o_.set_option(capi.PSM_OPT_PROFILE, 1)
+        o_.reset_kernel_times()
+    prof_steps = max(2, min(args.steps, 5)) * len(ring)
     for _ in range(prof_steps):
         step()
     sync()
@@ -568,10 +682,11 @@ def main():
              capi.PSM_K_MERGE: "merge", capi.PSM_K_FGF: "cvf_fgf", capi.PSM_K_LRC: "lr_check"}
     kern = {}
     for k, nm in names.items():
-        tot, n = de.kernel_time_ms(k)
+        tot, n = (sum(v) for v in zip(*[o_.kernel_time_ms(k) for o_ in ring]))
         if n:
             kern[nm] = {"avg_ms": tot / n, "launches_per_step": n / prof_steps, "source": "hipEvent pass (separate; perturbs the step)"}
-    de.set_option(capi.PSM_OPT_PROFILE, 0)
+    for o_ in ring:
+        o_.set_option(capi.PSM_OPT_PROFILE, 0)
     fl = head["filter_launches"]
     if fl and not args.fgf:
         # the dominant kernel's entry comes from the timed region: mean over all its launches (planes and key phase)
@@ -630,7 +745,7 @@ def main():
             if key in tr:
                 roofline["traffic"] = tr[key]    # HBM bytes per launch from rocprofv3 PMC passes (not measured in this run)
                 roofline["traffic_source"] = tr.get("_source", "profiles/traffic.json")
-                roofline["traffic_session"] = tr.get("_session")      # box / date of the PMC session the figure comes from
+                roofline["traffic_session"] = tr.get(key + "_session", tr.get("_session"))      # box / date of the PMC session the figure comes from
                 roofline["traffic_GBs"] = round(tr[key] / (dom_ms * 1e-3) / 1e9, 1)   # physical HBM rate of the kernel
                 roofline["traffic_frac"] = round(tr[key] / (dom_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
                 vi, s4 = tr.get(key + "_valu_insts"), tr.get(key + "_four_cycle_share")
@@ -644,9 +759,39 @@ def main():
                     roofline["valu"] = {"wave_insts_per_launch": vi, "four_cycle_share": s4,
                                         "bound_ms_at_measured_issue_rates": round(bound_ms, 4),
                                         "frac_of_valu_bound": round(bound_ms / dom_ms, 4),
-                                        "source": "SQ_INSTS_VALU (rocprofv3 PMC pass, " + str(tr.get("_session")) + "), mix from scripts/isa_mix.py"}
+                                        "source": "SQ_INSTS_VALU (rocprofv3 PMC pass, " + str(tr.get(key + "_session", tr.get("_session"))) + "), mix from scripts/isa_mix.py"}
         except Exception:
             pass
+    # ---- lead with the binding resource.  The fused select kernel keeps the staged pipeline's intermediates on chip: its physical
+    # HBM rate is a small fraction of the peak (traffic_frac) and what bounds it is VALU issue - binding says so, next to the HBM
+    # fraction on the algorithmic bytes that SURVEY.md 8d defines (48 B / voxel, unchanged) ----
+    if select_mode and dom == "cvf_fused":
+        roofline["binding"] = "valu"
+        if "valu" in roofline:
+            roofline["binding_frac"] = roofline["valu"]["frac_of_valu_bound"]
+            roofline["binding_note"] = ("VALU issue: SQ_INSTS_VALU per launch at the part's measured issue rates (0.50 / 0.86 G wave-instructions/s per SIMD "
+                                        "for 4- / 2-cycle ops) over the launch time; the HBM figures (frac, traffic_frac) are context")
+        else:
+            roofline["binding_frac"] = None
+            roofline["binding_note"] = "VALU issue (no PMC pass of this configuration in profiles/traffic.json: measured for c4 / c3 / c2 / c5 f32 and c4 u8)"
+    else:
+        roofline["binding"] = "hbm"
+    roofline["frac_basis"] = "dominant kernel: algorithmic bytes per launch / launch time"
+    if roofline["frac"] > 1.0 and roofline.get("pipeline_frac"):
+        # An algorithmic-equivalent rate above the physical peak is not a utilisation: a fused kernel that never moves the staged
+        # pipeline's intermediates can outrun that byte count.  The line then reports the whole step on the same bytes instead.
+        roofline["kernel_alg_equiv_frac"] = roofline["frac"]
+        roofline["kernel_alg_equiv_GBs"] = roofline["achieved"]
+        roofline["achieved"], roofline["frac"] = roofline["pipeline_alg_GBs"], roofline["pipeline_frac"]
+        roofline["frac_basis"] = ("whole step: pipeline algorithmic bytes / ms_per_step (the dominant kernel's own algorithmic-equivalent rate "
+                                  "exceeds the HBM peak - kernel_alg_equiv_frac - which no bandwidth figure can)")
+    if len(ring) > 1:
+        # frames in flight: the launches of consecutive frames overlap, so a launch's own duration says little - the line reports the
+        # whole step (frames / time) on the pipeline's algorithmic bytes
+        roofline["kernel_alg_equiv_frac"], roofline["kernel_alg_equiv_GBs"] = roofline["frac"], roofline["achieved"]
+        roofline["achieved"], roofline["frac"] = roofline["pipeline_alg_GBs"], roofline["pipeline_frac"]
+        roofline["frac_basis"] = f"whole step: pipeline algorithmic bytes / ms_per_step ({len(ring)} frames in flight: launches of consecutive frames overlap)"
+        roofline.pop("valu", None); roofline["binding_frac"] = None
     for nm, v in kern.items():
         if nm in algb:
             v["alg_GBs"] = round(algb[nm] * vox_per_launch / (v["avg_ms"] * 1e-3) / 1e9, 1)
@@ -713,6 +858,14 @@ def main():
         if use_dist or args.verify:
             ref_maps = single_gpu_maps()
         checks = check_maps(head, ref_maps, oracle_maps)
+        if len(ring) > 1:           # every context of the ring left the same maps (same pair): frames in flight change no result
+            same = True
+            for o_ in ring[1:]:
+                o_.set_option(capi.PSM_OPT_ASYNC, 0)
+                got_ = o_.download_maps()
+                same = same and bool(np.array_equal(got_[0], timed_maps[0]) and np.array_equal(got_[1], timed_maps[1]))
+                o_.set_option(capi.PSM_OPT_ASYNC, 1)
+            checks["frames_in_flight_maps_equal"] = same
         if tol_model_maps is not None and timed_maps is not None:
             checks["tolerance_form"] = {"flag": "PSM_FLAG_F32_TOL", "maps_equal_its_oracle_model": bool(np.array_equal(timed_maps[0], tol_model_maps[0]) and
                                                                                                    np.array_equal(timed_maps[1], tol_model_maps[1])),
@@ -739,7 +892,7 @@ def main():
     if rank == 0 and sim and not args.fgf:
         G = args.shard_sim
         de.set_option(capi.PSM_OPT_ASYNC, 0)
-        step(); sync()
+        step_all(); sync()
         parts_ctx = [de]
         for g_ in range(1, G):
             if rows_mode:
@@ -778,7 +931,7 @@ def main():
         de.set_option(capi.PSM_OPT_ASYNC, 0)
         pp = {}
         for it in range(2):                      # second pass: scratch allocated, clocks up
-            step(); sync()
+            step_all(); sync()
             raw_l, raw_r = (m.copy() for m in de.download_maps())
             t = time.perf_counter(); de.LRCheck_device(); de.synchronize(); pp["lr_check_ms"] = round(1e3 * (time.perf_counter() - t), 4)
             lv, rv = (m.copy() for m in de.download_valid())
@@ -836,7 +989,7 @@ def main():
         if ok_axis:
             a = measure(other, args.exchange or "allgather")
             alt = {"shard": other, "exchange": a["exchange"], "ms_per_step": a["ms_per_step"], "value": a["value"],
-                   "median_ms_per_step": a["median_ms_per_step"], "filter_launches": a["filter_launches"],
+                   "median_ms_per_step": a["median_ms_per_step"], "filter_launches": a["filter_launches"], "per_rank": a.get("per_rank"),
                    "parallelism": (f"D sharded over {world} ranks + 1 {xname} {a['exchange']} of packed minima per frame" if other == "disp"
                                    else f"{world} row stripes + 1 {xname} all_gather of the map rows per frame"),
                    "note": ("the configuration BASELINE configs[3] / the north star name (D slices sharded, one all-gather of per-pixel minima); "
@@ -853,13 +1006,14 @@ def main():
             "value": value, "unit": "voxels/s",
             "n_gpus": N, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": dtype,
-            "data": "synthetic",
+            "data": data_note,
             "config": {"workload": desc, "W": W, "H": H, "D": D, "voxels_per_step": voxels_per_step,
                        "parallelism": "1 GPU" if world == 1 and not use_dist else
                                       (f"{world} row stripes of {geo['rows_max']} rows (all {D} slices each) + 1 {xname} all_gather of the map rows per frame"
                                        if rows_mode else f"D sharded over {world} ranks + 1 {xname} {exchange} of packed minima"),
                        "kernel_variant": args.variant, "shard_sim": args.shard_sim, "lr_check_on_gpu": bool(lrc),
                        "shard": head["shard"], "batch": B, "graph": bool(args.graph and use_batch), "ranks": world, "same_device": bool(args.same_device),
+                       "frames_in_flight": len(head["ring"]),
                        "exchange_backend": (backend if use_dist else None)},
             "roofline": roofline, "cpu_baseline": cpu, "kernels": kern,
             "kernels_sum_ms_per_step": round(kernels_sum, 4), "kernels_sum_le_step": bool(kernels_sum <= ms_per_step * 1.005),
@@ -873,6 +1027,13 @@ def main():
             out["same_device_note"] = (f"{world} ranks share GPU 0: the N > 1 protocol (alternating buffers, pending exchange, gather / merge at world "
                                        f"{world}) run for correctness - value is NOT a scaling measurement"
                                        + (f"; {args.backend_note}" if args.backend_note else ""))
+        if use_dist:
+            out["ranks"] = world
+            out["exchange_backend"] = backend
+            out["shard"] = head["shard"]
+            out["exchange"] = head["exchange"]
+            out["per_rank"] = head.get("per_rank")
+            out["frame_pipeline"] = bool(not args.no_frame_pipeline)
         if alt:
             out["alt_shard"] = alt
         if pp:

@@ -58,8 +58,11 @@ enum {
     PSM_OPT_SEG_ROWS = 3,       /* rows per y-segment of the marching kernels (0 = auto)      */
     PSM_OPT_WAVES = 4,          /* waves (disparity slices) per workgroup: 1,2,4,8            */
     PSM_OPT_FLAGS = 5,          /* PSM_FLAG_* bits below; no flag but PSM_FLAG_F32_TOL / PSM_FLAG_FMA_SOLVE changes any result */
-    PSM_OPT_GRAPH = 6           /* 1: psm_compute_batch captures its launches once as a hipGraph and replays it while the batch
+    PSM_OPT_GRAPH = 6,          /* 1: psm_compute_batch captures its launches once as a hipGraph and replays it while the batch
                                    (contexts, geometry, options) stays the same; ignored while PSM_OPT_PROFILE is on */
+    PSM_OPT_GATHER_STAGED = 7   /* 1 (on the ROOT context): psm_gather_rows_ctx / psm_disp_merge_ctx move every stripe / shard through
+                                   page-locked host memory instead of device / peer copies - what they do on their own between two
+                                   devices for which hipDeviceCanAccessPeer says no; the option forces that path (test hook) */
 };
 
 /* PSM_OPT_FLAGS bits.  The default (0) is the product path: cost volumes and filtered volumes stay virtual, the fused
@@ -128,6 +131,13 @@ int psm_set_option(psm_ctx *ctx, int option, int value);
 /* Run all work of this context on an existing hipStream_t (NULL = the context's own). */
 int psm_set_stream(psm_ctx *ctx, void *hip_stream);
 int psm_synchronize(psm_ctx *ctx);
+/* Give back the device / page-locked memory the context allocated ON FIRST USE and that holds no state between calls: the
+ * weighted median's sweep scratch and weight cache (1.5 KB per invalid pixel), the minima planes of the fused filter, the gather /
+ * bounce buffers of the single-process exchange, the 8-bit storing path's float work volume.  Synchronises the context first;
+ * everything is allocated again by the call that needs it.  Maps, minima, volumes and images are untouched.  (The reference
+ * allocates its CVF intermediates per call, src/CVF_cl.cpp:115-159; this library keeps them - this is how a long-running host
+ * gets the memory back without destroying the context.) */
+int psm_release_scratch(psm_ctx *ctx);
 
 /* Copy a stereo pair to the device and planarise it.  Replaces the host half of
  * CVC_cl::buildCV (split + 8x map/memcpy, src/CVC_cl.cpp:95-160) and
@@ -190,7 +200,8 @@ int psm_disp_merge(psm_ctx *ctx, const void *dev_keys_all, int nranks, uint8_t *
 
 /* Single-process form of the exchange step: `shards` are nshards contexts of one job (on the
  * same or on different devices) whose psm_disp_select_partial has run; their key planes are
- * copied (peer copy across devices) into `root`'s gather buffer and merged there.  This is
+ * copied (device copy; peer copy across devices; through page-locked host memory when the two
+ * devices have no peer access) into `root`'s gather buffer and merged there.  This is
  * what a C++ host that drives several GPUs from one process uses instead of RCCL, and what
  * the single-GPU "logical shard" tests use. */
 int psm_disp_merge_ctx(psm_ctx *root, psm_ctx *const *shards, int nshards, uint8_t *lmap,
@@ -262,6 +273,9 @@ int psm_set_map_buffer(psm_ctx *ctx, void *dev_maps, int whole);
  * maps into root's maps (root may be one of them); checks that the stripes tile [0, H) and that every context has run
  * psm_disp_select for the frame.  lmap/rmap (optional) receive the whole maps. */
 int psm_gather_rows_ctx(psm_ctx *root, psm_ctx *const *stripes, int nstripes, uint8_t *lmap, uint8_t *rmap, size_t stride);
+/* How many legs of psm_gather_rows_ctx / psm_disp_merge_ctx with this root went through host memory so far (devices without
+ * peer access, or PSM_OPT_GATHER_STAGED) instead of a device / peer copy. */
+int psm_gather_staged_legs(const psm_ctx *root);
 
 /* ---- several pairs per launch: the reference's use on Middlebury-size data is a loop over pairs / datasets
  * (src/main.cpp:64-73, src/StereoMatch.cpp:556-607) - one 450 x 375 x 64 pair is 1.7 rounds of the chip's resident workgroups

@@ -19,7 +19,8 @@ PSM_LEFT, PSM_RIGHT = 0, 1
 PSM_STAGE_CVC, PSM_STAGE_CVF, PSM_STAGE_DISPSEL, PSM_STAGE_PP = 0, 1, 2, 3
 (PSM_K_PREP, PSM_K_CVC, PSM_K_GUIDE, PSM_K_CVF_A, PSM_K_CVF_B, PSM_K_WTA, PSM_K_MERGE, PSM_K_BOX,
  PSM_K_LRC, PSM_K_CVF_F, PSM_K_FGF, PSM_K_WMF) = range(12)
-PSM_OPT_ASYNC, PSM_OPT_KERNEL_VARIANT, PSM_OPT_PROFILE, PSM_OPT_SEG_ROWS, PSM_OPT_WAVES, PSM_OPT_FLAGS, PSM_OPT_GRAPH = range(7)
+(PSM_OPT_ASYNC, PSM_OPT_KERNEL_VARIANT, PSM_OPT_PROFILE, PSM_OPT_SEG_ROWS, PSM_OPT_WAVES, PSM_OPT_FLAGS, PSM_OPT_GRAPH,
+ PSM_OPT_GATHER_STAGED) = range(8)
 # enum psm_flag (PSM_OPT_FLAGS bits)
 PSM_FLAG_MATERIALISE_COSTS, PSM_FLAG_FGF_STORE, PSM_FLAG_STORE_FILTERED = 128, 4096, 8192
 PSM_FLAG_TWO_PHASE_ON, PSM_FLAG_TWO_PHASE_OFF = 1048576, 2097152
@@ -39,6 +40,7 @@ SYMBOLS = [
     ("psm_set_option", _i, [_vp, _i, _i]),
     ("psm_set_stream", _i, [_vp, _vp]),
     ("psm_synchronize", _i, [_vp]),
+    ("psm_release_scratch", _i, [_vp]),
     ("psm_upload_pair", _i, [_vp, _vp, _vp, _i, _sz, _i]),
     ("psm_upload_pair_async", _i, [_vp, _vp, _vp, _i, _sz, _i]),
     ("psm_cost_construct", _i, [_vp]),
@@ -64,6 +66,7 @@ SYMBOLS = [
     ("psm_set_rows", _i, [_vp, _i, _i]),
     ("psm_set_map_buffer", _i, [_vp, _vp, _i]),
     ("psm_gather_rows_ctx", _i, [_vp, _vp, _i, _vp, _vp, _sz]),
+    ("psm_gather_staged_legs", _i, [_vp]),
     ("psm_upload_maps", _i, [_vp, _vp, _vp, _vp, _vp, _sz]),
     ("psm_download_volume", _i, [_vp, _i, _i, _i, _vp]),
     ("psm_upload_volume", _i, [_vp, _i, _i, _i, _vp]),

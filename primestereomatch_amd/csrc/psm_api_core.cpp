@@ -117,6 +117,7 @@ void free_all(psm_ctx *c)
     (void)hipFree(c->gather);
     (void)hipFree(c->maps_own);
     (void)hipFree(c->valid);
+    if (c->xfer_pin) (void)hipHostFree(c->xfer_pin);
     if (c->pinned) (void)hipHostFree(c->pinned);
     if (c->pinned2) (void)hipHostFree(c->pinned2);
     if (c->pin_up) (void)hipHostFree(c->pin_up);
@@ -355,6 +356,7 @@ int psm_set_option(psm_ctx *c, int option, int value)
         }
         c->march.flags = value; return 0;
     case PSM_OPT_GRAPH: c->opt_graph = value != 0; return 0;
+    case PSM_OPT_GATHER_STAGED: c->opt_gather_staged = value != 0; return 0;
     default: return fail(c, "psm_set_option: unknown option %d", option);
     }
 }
@@ -376,6 +378,21 @@ int psm_synchronize(psm_ctx *c)
     PSM_HIP(c, hipStreamSynchronize(c->stream));
     if (c->copy_stream) PSM_HIP(c, hipStreamSynchronize(c->copy_stream));
     if (c->down_stream && c->down_stream != c->copy_stream) PSM_HIP(c, hipStreamSynchronize(c->down_stream));
+    return 0;
+}
+
+int psm_release_scratch(psm_ctx *c)
+{
+    if (!c) return 1;
+    if (psm_synchronize(c)) return 1;
+    (void)hipFree(c->wm_wts); c->wm_wts = nullptr; c->wm_wts_n = 0;
+    (void)hipFree(c->wm_par); c->wm_par = nullptr;
+    (void)hipFree(c->wm); c->wm = nullptr;
+    (void)hipFree(c->gf_scratch); c->gf_scratch = nullptr; c->gf_scratch_bytes = 0;
+    (void)hipFree(c->gather); c->gather = nullptr; c->gather_ranks = 0;
+    (void)hipFree(c->fvol); c->fvol = nullptr;
+    if (c->xfer_pin) { (void)hipHostFree(c->xfer_pin); c->xfer_pin = nullptr; c->xfer_pin_bytes = 0; }
+    (void)hipGetLastError();
     return 0;
 }
 

@@ -179,6 +179,42 @@ int psm_set_map_buffer(psm_ctx *c, void *dev_maps, int whole)
     return 0;
 }
 
+// One leg of the single-process exchange (psm_gather_rows_ctx / psm_disp_merge_ctx): n bytes of context s (its stream already
+// synchronised) into root's memory, ordered on root's stream.  Same device: a device copy.  Other device: a peer copy when
+// hipDeviceCanAccessPeer(root, s) says the two can reach each other (xGMI / PCIe P2P), else - or with PSM_OPT_GATHER_STAGED, the
+// test hook for exactly this path on a one-GPU box - through a page-locked bounce buffer of root: device -> host on s's device,
+// host -> device on root's stream (one buffer, so each leg completes before the next reuses it: the slow but always available way).
+static int gather_leg(psm_ctx *root, void *dst, psm_ctx *s, const void *src, size_t n)
+{
+    bool staged = root->opt_gather_staged != 0;
+    if (!staged && s->device != root->device) {
+        int can = 0;
+        if (hipDeviceCanAccessPeer(&can, root->device, s->device) != hipSuccess) { can = 0; (void)hipGetLastError(); }
+        staged = !can;
+    }
+    if (!staged) {
+        if (s->device == root->device) PSM_HIP(root, hipMemcpyAsync(dst, src, n, hipMemcpyDeviceToDevice, root->stream));
+        else PSM_HIP(root, hipMemcpyPeerAsync(dst, root->device, src, s->device, n, root->stream));
+        return 0;
+    }
+    if (root->xfer_pin_bytes < n) {
+        PSM_HIP(root, hipStreamSynchronize(root->stream));
+        if (root->xfer_pin) (void)hipHostFree(root->xfer_pin);
+        root->xfer_pin = nullptr;
+        root->xfer_pin_bytes = 0;
+        PSM_HIP(root, hipHostMalloc((void **)&root->xfer_pin, n, hipHostMallocPortable));    // (portable: both devices copy to / from it)
+        root->xfer_pin_bytes = n;
+    }
+    (void)hipSetDevice(s->device);
+    const hipError_t e = hipMemcpy(root->xfer_pin, src, n, hipMemcpyDeviceToHost);
+    (void)hipSetDevice(root->device);
+    if (e != hipSuccess) return fail(root, "exchange leg (device %d -> host): %s", s->device, hipGetErrorString(e));
+    PSM_HIP(root, hipMemcpyAsync(dst, root->xfer_pin, n, hipMemcpyHostToDevice, root->stream));
+    PSM_HIP(root, hipStreamSynchronize(root->stream));
+    ++root->gather_staged_legs;
+    return 0;
+}
+
 int psm_gather_rows_ctx(psm_ctx *root, psm_ctx *const *stripes, int nstripes, uint8_t *lmap, uint8_t *rmap, size_t stride)
 {
     if (!root) return 1;
@@ -208,12 +244,8 @@ int psm_gather_rows_ctx(psm_ctx *root, psm_ctx *const *stripes, int nstripes, ui
         PSM_HIP(root, hipStreamSynchronize(s->stream));     // the stripe's maps must be complete before they are read
         (void)hipSetDevice(root->device);
         const size_t o = (size_t)y0_of(s) * root->W, n = (size_t)(y1_of(s) - y0_of(s)) * root->W;
-        for (int side = 0; side < 2; ++side) {
-            if (s->device == root->device)
-                PSM_HIP(root, hipMemcpyAsync(root->maps + side * HW + o, s->maps + side * HW + o, n, hipMemcpyDeviceToDevice, root->stream));
-            else
-                PSM_HIP(root, hipMemcpyPeerAsync(root->maps + side * HW + o, root->device, s->maps + side * HW + o, s->device, n, root->stream));
-        }
+        for (int side = 0; side < 2; ++side)
+            if (gather_leg(root, root->maps + side * HW + o, s, s->maps + side * HW + o, n)) return 1;
     }
     root->have_maps = true;
     root->have_rows = false;      // the root's maps are whole now
@@ -224,6 +256,8 @@ int psm_gather_rows_ctx(psm_ctx *root, psm_ctx *const *stripes, int nstripes, ui
     if (!root->opt_async) PSM_HIP(root, hipStreamSynchronize(root->stream));
     return 0;
 }
+
+int psm_gather_staged_legs(const psm_ctx *root) { return root ? root->gather_staged_legs : -1; }
 
 int psm_set_key_buffer(psm_ctx *c, void *dev_keys)
 {
@@ -302,10 +336,7 @@ int psm_disp_merge_ctx(psm_ctx *root, psm_ctx *const *shards, int nshards, uint8
         (void)hipSetDevice(s->device);
         PSM_HIP(root, hipStreamSynchronize(s->stream));
         (void)hipSetDevice(root->device);
-        if (s->device == root->device)
-            PSM_HIP(root, hipMemcpyAsync((char *)root->gather + bytes * i, s->keys_cur, bytes, hipMemcpyDeviceToDevice, root->stream));
-        else
-            PSM_HIP(root, hipMemcpyPeerAsync((char *)root->gather + bytes * i, root->device, s->keys_cur, s->device, bytes, root->stream));
+        if (gather_leg(root, (char *)root->gather + bytes * i, s, s->keys_cur, bytes)) return 1;
     }
     // the merged maps cover what the shards' minima cover
     root->have_rows = shards[0]->have_rows;

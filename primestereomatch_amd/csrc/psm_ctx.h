@@ -62,6 +62,9 @@ struct psm_ctx {
     long long *keys_cur = nullptr;      // where the packed minima go: `keys`, or the caller's buffer (psm_set_key_buffer)
     long long *gather = nullptr;        // [gather_ranks][2][H][W], psm_disp_merge_ctx
     int gather_ranks = 0;
+    uint8_t *xfer_pin = nullptr;        // page-locked bounce buffer of the single-process exchange when two devices cannot reach each other (gather_leg)
+    size_t xfer_pin_bytes = 0;
+    int gather_staged_legs = 0;         // legs that went through it so far (psm_gather_staged_legs: tests)
     uint8_t *maps = nullptr;            // [2][H][W]: maps_own, or the caller's buffer (psm_set_map_buffer)
     uint8_t *maps_own = nullptr;
     uint8_t *maps_early = nullptr;      // the map buffer the single-phase filter already filled from its final keys (k_chunk_min), or null
@@ -134,7 +137,7 @@ struct psm_ctx {
     bool range_next_pending = false;    // the staged pair's range is still on its way (read when the pair is adopted)
 
     // options
-    int opt_async = 0, opt_variant = 0, opt_profile = 0, opt_graph = 0;
+    int opt_async = 0, opt_variant = 0, opt_profile = 0, opt_graph = 0, opt_gather_staged = 0;
     psm::March march = {0, 4, 0};
 
     double stage_us[PSM_STAGE_COUNT] = {0, 0, 0, 0};

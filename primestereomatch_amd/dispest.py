@@ -176,6 +176,10 @@ class DispEst:
     def set_stream(self, stream_ptr: int | None):
         self._ck(self._lib.psm_set_stream(self._h, C.c_void_p(stream_ptr or 0)), "set_stream")
 
+    def release_scratch(self):
+        """Give back the on-first-use scratch (weighted-median cache, minima planes, exchange buffers); see psm_release_scratch."""
+        self._ck(self._lib.psm_release_scratch(self._h), "release_scratch")
+
     def synchronize(self):
         self._ck(self._lib.psm_synchronize(self._h), "synchronize")
 

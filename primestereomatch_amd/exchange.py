@@ -98,5 +98,15 @@ class Exchange:
         self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
         return float(t.item())
 
+    def gather_floats(self, xs):
+        """[[rank 0's values], [rank 1's], ...] on every rank (diagnostics of the bench line: per-rank compute / collective ms)."""
+        dev = "cuda" if self.backend == "nccl" else "cpu"
+        n = len(xs)
+        world = self.dist.get_world_size()
+        t = self.torch.tensor(list(xs), dtype=self.torch.float64, device=dev)
+        out = self.torch.empty(world * n, dtype=self.torch.float64, device=dev)
+        self.dist.all_gather_into_tensor(out, t)
+        return out.cpu().view(world, n).tolist()
+
     def barrier(self):
         self.dist.barrier()

@@ -13,11 +13,12 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def counters(path, kernel):
+    """counters of the first kernel whose name matches the regex `kernel`"""
     out, cur = {}, None
     for line in open(path):
         if line.startswith("### counters:"):
             cur = line
-        elif cur and kernel in cur:
+        elif cur and re.search(kernel, cur):
             m = re.match(r"\s+(\S+)\s+avg/dispatch = (\S+)", line)
             if m:
                 out[m.group(1)] = float(m.group(2))
@@ -34,7 +35,11 @@ def fabric_bytes(d, pre, kernel):
 def main():
     d, tag = sys.argv[1], sys.argv[2]
     session = open(os.path.join(d, "device.txt")).read().strip().replace("\n", "; ") if os.path.exists(os.path.join(d, "device.txt")) else "?"
-    mix = json.load(open(os.path.join(ROOT, "profiles", tag, "isa_mix.json")))
+    mixf = os.path.join(ROOT, "profiles", tag, "isa_mix.json")
+    if not os.path.exists(mixf):              # (scripts/isa_mix.py of this round not run yet: the latest committed mix)
+        have = sorted(t for t in os.listdir(os.path.join(ROOT, "profiles")) if os.path.exists(os.path.join(ROOT, "profiles", t, "isa_mix.json")))
+        mixf = os.path.join(ROOT, "profiles", have[-1], "isa_mix.json")
+    mix = json.load(open(mixf))
     out = {
         "_comment": "Fabric-side (L2 <-> Infinity Fabric) bytes per launch from rocprofv3 PMC passes (scripts/gpu_round.sh, "
                     "scripts/make_traffic.py): TCC_EA0_RDREQ_sum*128 (+32 B per 32-byte request; equals 2*FETCH_SIZE*1024, the "
@@ -43,30 +48,50 @@ def main():
                     "two launches of a step (planes phase k_cvf_pc<false,3,1>, key phase k_cvf_pc<false,3,2>), like bench.py's "
                     "avg_launch_ms; *_valu_insts = SQ_INSTS_VALU per launch (same mean), *_four_cycle_share = share of 4-cycle "
                     "VALU ops in the loop bodies (scripts/isa_mix.py), weighted by the two launches' instruction counts.",
-        "_source": f"profiles/{tag}/rocprofv3_pmc_{{rd,wr,sq}}*.summary.txt",
+        "_source": f"profiles/{tag}/rocprofv3_pmc_*{{rd,wr,sq}}.summary.txt (c4: pmc_{{rd,wr,sq}} / pmc_u8_*; other configs pmc_<config>_*)",
         "_session": session,
     }
-    for dt, u8 in (("f32", "false"), ("u8", "true")):
-        pre = "pmc_" if dt == "f32" else "pmc_u8_"
-        ks = {"planes": f"k_cvf_pc<false, 3, 1, {u8}, false, false>", "keys": f"k_cvf_pc<false, 3, 2, {u8}, false, false>"}
+    # (config, dtype, file prefix of its passes): c4 from scripts/gpu_round.sh (pmc_ / pmc_u8_), the other configs pmc_<config>_
+    cases = [("c4", "f32", "pmc_"), ("c4", "u8", "pmc_u8_"), ("c3", "f32", "pmc_c3_"), ("c2", "f32", "pmc_c2_"), ("c5", "f32", "pmc_c5_")]
+    prev = {}
+    if os.path.exists(os.path.join(ROOT, "profiles", "traffic.json")):
+        prev = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+    for cfg, dt, pre in cases:
+        u8 = "true" if dt == "u8" else "false"
+        # (the last template argument was a bool before round 5's VAR: both spellings)
+        ks = {"planes": rf"k_cvf_pc<false, 3, 1, {u8}, false, (false|0)>", "keys": rf"k_cvf_pc<false, 3, 2, {u8}, false, (false|0)>"}
+        key = f"{cfg}:{dt}:k_cvf_fused"
         try:
-            parts = {n: fabric_bytes(d, pre, k) for n, k in ks.items()}
-            insts = {n: counters(os.path.join(d, f"{pre}sq.summary.txt"), k)["SQ_INSTS_VALU"] for n, k in ks.items()}
+            parts, insts = {}, {}
+            for n, k in ks.items():
+                try:
+                    parts[n] = fabric_bytes(d, pre, k)
+                    insts[n] = counters(os.path.join(d, f"{pre}sq.summary.txt"), k)["SQ_INSTS_VALU"]
+                except KeyError:
+                    pass                      # (a configuration below 112 slices runs the plane form only)
+            if not parts:
+                raise FileNotFoundError("no k_cvf_pc counters")
         except Exception as e:
-            print(f"({dt}: no PMC summaries: {e})")
+            print(f"({cfg} {dt}: no PMC summaries in this session: {e}; keeping the committed figures)")
+            for k_, v_ in prev.items():
+                if k_.startswith(key) or k_ == f"{cfg}:{dt}:k_chunk_min":
+                    out[k_] = v_
+            if any(k_.startswith(key) for k_ in prev):
+                out[key + "_session"] = prev.get(key + "_session", prev.get("_session"))
             continue
-        key = f"c4:{dt}:k_cvf_fused"
-        out[key] = round(sum(r + w for r, w in parts.values()) / 2)
-        out[key + "_read"] = round(sum(r for r, _ in parts.values()) / 2)
-        out[key + "_write"] = round(sum(w for _, w in parts.values()) / 2)
-        out[key + "_launches_per_step"] = 2
+        nl = len(parts)
+        out[key] = round(sum(r + w for r, w in parts.values()) / nl)
+        out[key + "_read"] = round(sum(r for r, _ in parts.values()) / nl)
+        out[key + "_write"] = round(sum(w for _, w in parts.values()) / nl)
+        out[key + "_launches_per_step"] = nl
         out[key + "_by_form"] = {n: {"read": round(r), "write": round(w), "valu_insts": round(insts[n])} for n, (r, w) in parts.items()}
-        out[key + "_valu_insts"] = round(sum(insts.values()) / 2)
-        s4 = sum(insts[n] * mix[f"{n}_{dt}"]["four_cycle_share"] for n in ks) / sum(insts.values())
+        out[key + "_valu_insts"] = round(sum(insts.values()) / nl)
+        s4 = sum(insts[n] * mix[f"{n}_{dt}"]["four_cycle_share"] for n in parts) / sum(insts.values())
         out[key + "_four_cycle_share"] = round(s4, 4)
+        out[key + "_session"] = session
         try:
             r2, w2 = fabric_bytes(d, pre, "k_chunk_min")
-            out[f"c4:{dt}:k_chunk_min"] = round(r2 + w2)
+            out[f"{cfg}:{dt}:k_chunk_min"] = round(r2 + w2)
         except Exception:
             pass
     json.dump(out, open(os.path.join(ROOT, "profiles", "traffic.json"), "w"), indent=1)

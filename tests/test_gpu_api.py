@@ -302,3 +302,35 @@ def test_scaled_sums_guard_on_float_images(psm, oracle):
         de.set_option(capi.PSM_OPT_FLAGS, capi.PSM_FLAG_STORE_FILTERED)
         de.CostConst_GPU(); de.CostFilter_GPU(); de.DispSelect_GPU()
         assert np.array_equal(de.lDisMap, scaled_maps[0]) and np.array_equal(de.rDisMap, scaled_maps[1])
+
+
+def test_release_scratch_gives_memory_back_and_changes_nothing(psm, oracle):
+    """psm_release_scratch: the on-first-use scratch (weighted-median sweep state and weight cache, minima planes, exchange buffers)
+    goes back to the device; maps / minima survive and the next calls allocate again and give the same results."""
+    import ctypes as C
+    from primestereomatch_amd import synth
+    hip = C.CDLL("libamdhip64.so")
+
+    def free_bytes():
+        a, b = C.c_size_t(), C.c_size_t()
+        assert hip.hipMemGetInfo(C.byref(a), C.byref(b)) == 0
+        return a.value
+
+    W, H, D = 640, 360, 48
+    l, r, _ = synth.make_pair(W, H, D, seed=12)
+    ref = oracle.pipeline_f32(l, r, D, threads=8)
+    with psm.DispEst(l, r, D) as de:
+        def frame():
+            de.CostConst_GPU(); de.CostFilter_GPU(); de.DispSelect_GPU()
+            assert np.array_equal(de.lDisMap, ref["ldisp"]) and np.array_equal(de.rDisMap, ref["rdisp"])
+            de.LRCheck_GPU(); de.FillInv_GPU(); de.WgtMedian_GPU()
+            return de.lDisMap.copy(), de.rDisMap.copy()
+        a = frame()
+        held = free_bytes()
+        de.release_scratch()
+        assert free_bytes() > held + (8 << 20)             # (minima planes + sweep scratch + weight cache of a 640 x 360 pair: tens of MB)
+        lm, rm = de.download_maps()                        # the maps are state, not scratch
+        assert np.array_equal(lm, a[0]) and np.array_equal(rm, a[1])
+        b = frame()
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+

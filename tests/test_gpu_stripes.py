@@ -230,3 +230,44 @@ def test_cpp_host_mirror_fgf_on_a_striped_host(psm, oracle, golden, tmp_path):
     assert np.array_equal(ld, ref["ldisp"]) and np.array_equal(rd, ref["rdisp"])
     lv = np.fromfile(tmp_path / "o_lvalid.raw", np.uint8).reshape(H, W)
     assert np.array_equal(lv, oracle.lr_check(ld, rd)[0])
+
+
+def test_single_process_exchange_through_host_memory(psm, oracle):
+    """psm_gather_rows_ctx / psm_disp_merge_ctx between devices WITHOUT peer access (hipDeviceCanAccessPeer says no) move every
+    stripe / shard through a page-locked bounce buffer of the root.  One-GPU boxes force that path with PSM_OPT_GATHER_STAGED: same
+    maps as the device-copy path and the oracle, and the legs are counted (a C++ host driving several GPUs from one process -
+    host/DispEst.cpp - relies on exactly these two calls)."""
+    from primestereomatch_amd import capi, synth
+    W, H, D = 333, 150, 40
+    l, r, _ = synth.make_pair(W, H, D, seed=9)
+    ref = oracle.pipeline_f32(l, r, D, threads=8)
+    lib = capi.load()
+    for staged in (0, 1):
+        parts = []
+        for ya, yb in ((0, 50), (50, 51), (51, H)):
+            de = psm.DispEst(l, r, D)
+            de.set_rows(ya, yb)
+            de.CostConst_GPU(); de.CostFilter_GPU(); de.DispSelect_device()
+            parts.append(de)
+        root = parts[1]                                      # (a root that is not the first stripe)
+        root.set_option(capi.PSM_OPT_GATHER_STAGED, staged)
+        root.gather_rows_ctx(parts)
+        assert np.array_equal(root.lDisMap, ref["ldisp"]) and np.array_equal(root.rDisMap, ref["rdisp"])
+        assert lib.psm_gather_staged_legs(root._h) == (4 if staged else 0)      # two other stripes x two maps
+        for de in parts:
+            de.close()
+        shards = []
+        for g in range(4):
+            de = psm.DispEst(l, r, D, d_range=(D * g // 4, D * (g + 1) // 4))
+            de.CostConst_GPU(); de.CostFilter_GPU(); de.DispSelect_partial()
+            shards.append(de)
+        root = shards[2]
+        root.set_option(capi.PSM_OPT_GATHER_STAGED, staged)
+        root.DispSelect_merge_ctx(shards)
+        assert np.array_equal(root.lDisMap, ref["ldisp"]) and np.array_equal(root.rDisMap, ref["rdisp"])
+        assert lib.psm_gather_staged_legs(root._h) == (4 if staged else 0)      # every shard's key planes (the root's own included)
+        root.DispSelect_merge_ctx(shards)                    # a second frame reuses the bounce buffer
+        assert np.array_equal(root.lDisMap, ref["ldisp"])
+        for de in shards:
+            de.close()
+
