@@ -1,7 +1,7 @@
 #!/bin/bash
 # One full GPU-box session of a round: parity tests, smoke, benches of every config, the torch.distributed path on
 # one GPU, rocprofv3 kernel trace + PMC passes (each in its own run).  Usage (via gpurun): bash scripts/gpu_round.sh r03
-TAG=${1:-r04}
+TAG=${1:-r05}
 OUT=$GRAFT_REPO_ROOT/gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
@@ -34,7 +34,16 @@ for v in exact tol; do
   PSM_FLAGS=$fl timeout 300 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_BUSY_CYCLES -d $OUT/pmc_sq_$v -o sq -- python $GRAFT_REPO_ROOT/scripts/prof_run.py c4 > $OUT/pmc_sq_$v.log 2>&1 || echo "pmc $v failed"
   fdb=$(find $OUT/pmc_sq_$v -name "*.db" | head -1); [ -n "$fdb" ] && python $GRAFT_REPO_ROOT/scripts/rocpd_summary.py $fdb > $OUT/pmc_sq_$v.summary.txt 2>&1
 done
+echo "== PMC passes for BASELINE configs[2] (c3: 1280x720x128), c2 and c5 as well"
+for cfg in c3 c2 c5; do
+  for pass in "rd:TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum" "wr:WRITE_SIZE TCC_EA0_WRREQ_sum" "sq:SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY"; do
+    n=${pass%%:*}; c=${pass#*:}
+    timeout 300 rocprofv3 --kernel-trace --pmc $c -d $OUT/pmc_${cfg}_$n -o $n -- python $GRAFT_REPO_ROOT/scripts/prof_run.py $cfg > $OUT/pmc_${cfg}_$n.log 2>&1 || echo "pmc pass $cfg $n failed"
+    fdb=$(find $OUT/pmc_${cfg}_$n -name "*.db" | head -1); [ -n "$fdb" ] && python $GRAFT_REPO_ROOT/scripts/rocpd_summary.py $fdb > $OUT/pmc_${cfg}_$n.summary.txt 2>&1
+  done
+done
 cd $GRAFT_REPO_ROOT
+mkdir -p profiles/$TAG; python scripts/isa_mix.py --json profiles/$TAG/isa_mix.json > $OUT/isa_mix.log 2>&1; cp profiles/$TAG/isa_mix.json $OUT/isa_mix.json
 python scripts/make_traffic.py $OUT $TAG > $OUT/traffic.log 2>&1; tail -12 $OUT/traffic.log
 cp profiles/traffic.json $OUT/traffic.json
 echo "== bench (default: c4, N=1) - the headline line"
@@ -45,6 +54,15 @@ $B --config c2 --steps 30 --verify --pp > $OUT/bench_c2_n1.json 2>> $OUT/bench_v
 $B --config c5 --steps 4 --warmup 1 --verify --no-cpu-wide > $OUT/bench_c5_n1.json 2>> $OUT/bench_var.err
 $B --config c1 --steps 30 --verify > $OUT/bench_c1_u8_n1.json 2>> $OUT/bench_var.err
 $B --config c1x --steps 30 --verify > $OUT/bench_c1x_u8_n1.json 2>> $OUT/bench_var.err
+echo "== the Middlebury pairs BASELINE configs[0] / [1] name (tests/golden fixtures) and two frames in flight on the configurations below the headline"
+$B --config c2 --pair fixture --steps 30 --verify --no-cpu-wide > $OUT/bench_c2_teddy_n1.json 2>> $OUT/bench_var.err
+$B --config c1 --pair fixture --steps 30 --verify --no-cpu-wide > $OUT/bench_c1_cones_u8_n1.json 2>> $OUT/bench_var.err
+$B --config c1x --pair fixture --steps 30 --verify --no-cpu-wide > $OUT/bench_c1x_cones_u8_n1.json 2>> $OUT/bench_var.err
+for cfg in c3 c2 c1 c1x; do $B --config $cfg --frames-in-flight 2 --steps 40 --verify --no-cpu-wide > $OUT/bench_${cfg}_fif2.json 2>> $OUT/bench_var.err; done
+$B --config c2 --pair fixture --frames-in-flight 2 --steps 40 --verify --no-cpu-wide > $OUT/bench_c2_teddy_fif2.json 2>> $OUT/bench_var.err
+$B --config c1 --pair fixture --frames-in-flight 2 --steps 40 --verify --no-cpu-wide > $OUT/bench_c1_cones_u8_fif2.json 2>> $OUT/bench_var.err
+$B --frames-in-flight 2 --no-cpu-baseline --frame-loop 0 > $OUT/bench_c4_fif2.json 2>> $OUT/bench_var.err
+$B --flags 67108864 --no-cpu-wide --frame-loop 0 > $OUT/bench_c4_fma_solve.json 2>> $OUT/bench_var.err
 $B --config c4 --dtype u8 --verify > $OUT/bench_c4_u8_n1.json 2>> $OUT/bench_var.err
 $B --flags 2097152 --no-cpu-baseline --verify > $OUT/bench_c4_single_phase_n1.json 2>> $OUT/bench_var.err
 $B --flags 8192 --no-cpu-baseline --verify > $OUT/bench_c4_store_mode_n1.json 2>> $OUT/bench_var.err
@@ -60,6 +78,8 @@ $B --config c2 --batch 8 --graph --steps 30 --warmup 5 --no-cpu-baseline > $OUT/
 $B --config c2 --batch -1 --graph --steps 30 --warmup 5 --no-cpu-baseline > $OUT/bench_c2_batch1_graph.json 2>> $OUT/bench_var.err
 for g in 2 4 8; do $B --shard-sim $g --steps 40 > $OUT/bench_c4_shardsim_1of$g.json 2>> $OUT/bench_var.err; done
 for g in 2 4 8; do $B --shard-sim $g --shard disp --steps 40 > $OUT/bench_c4_shardsim_disp_1of$g.json 2>> $OUT/bench_var.err; done
+$B --shard-sim 8 --frames-in-flight 2 --steps 40 > $OUT/bench_c4_shardsim_1of8_fif2.json 2>> $OUT/bench_var.err
+$B --shard-sim 8 --shard disp --frames-in-flight 2 --steps 40 > $OUT/bench_c4_shardsim_disp_1of8_fif2.json 2>> $OUT/bench_var.err
 $B --config c5 --shard-sim 8 --steps 6 --warmup 2 > $OUT/bench_c5_shardsim_1of8.json 2>> $OUT/bench_var.err
 echo "== weighted median timing (hybrid sweeps form / dataflow form)"
 timeout 300 python scripts/dbg_wmf.py big > $OUT/wmf_timing.txt 2>&1; WM_FLAGS=4194304 timeout 300 python scripts/dbg_wmf.py >> $OUT/wmf_timing.txt 2>&1; tail -22 $OUT/wmf_timing.txt
