@@ -4,6 +4,6 @@ The product is libprimesm_hip.so (csrc/, C ABI in include/primesm_hip.h) plus th
 mirrors of the reference's DispEst interface (host/ in C++, dispest.py in Python).
 """
 from . import capi  # noqa: F401
-from .dispest import DispEst  # noqa: F401
+from .dispest import DispEst, FrameRing  # noqa: F401
 
-__all__ = ["capi", "DispEst"]
+__all__ = ["capi", "DispEst", "FrameRing"]

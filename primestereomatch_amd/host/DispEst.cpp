@@ -124,10 +124,20 @@ int DispEst::DispSelect_GPU()
     return rc;
 }
 
-int DispEst::PostProcess_GPU()
+int DispEst::LRCheck_GPU()
 {
     if (ctx.empty()) return 1;
     return hipUtil::api().lr_check(ctx[0], lValid.data, rValid.data, lValid.step);
+}
+
+int DispEst::PostProcess_GPU()
+{   // PP::processDM as its source spells it out (src/PP.cpp:405-410): lrCheck, fillInv, wgtMedian - all on the device
+    if (ctx.empty()) return 1;
+    const HipApi &api = hipUtil::api();
+    int rc = api.lr_check(ctx[0], lValid.data, rValid.data, lValid.step);
+    if (!rc) rc = api.fill_invalid(ctx[0], nullptr, nullptr, 0);
+    if (!rc) rc = api.wgt_median(ctx[0], lDisMap.data, rDisMap.data, lDisMap.step);
+    return rc;
 }
 
 int DispEst::FillInvalid_GPU()

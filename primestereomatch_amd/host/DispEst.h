@@ -68,14 +68,16 @@ public:
     int CostFilter_GPU();
     int CostFilter_FGF_GPU();  // DispEst::CostFilter_FGF (src/DispEst.cpp:281-296) on the device, s = subsample_rate
     int DispSelect_GPU();
-    // The reference's PostProcess_GPU runs the CPU JointWMF (src/DispEst.cpp:338-344), which is
-    // out of scope here; this one runs the device left-right check
-    // (src/PP.cpp:17-50) and leaves the maps untouched.
+    // DispEst::PostProcess_GPU (src/DispEst.cpp:338-344) = PP::processDM.  The reference's live processDM body is the CPU JointWMF
+    // (third-party, out of scope: SURVEY.md 2); the data-parallel sequence its source spells out - lrCheck, fillInv, wgtMedian
+    // (src/PP.cpp:405-410) - is what runs here, on the device: afterwards lValid / rValid hold the L-R validity and lDisMap /
+    // rDisMap the filled, weighted-median-filtered maps, so a caller that selected and then post-processed holds finished maps as
+    // it does after the reference's call.  The three stages alone:
     int PostProcess_GPU();
-    // fillInv (src/PP.cpp:52-143) on the device: fills the pixels PostProcess_GPU marked invalid
-    int FillInvalid_GPU();
-    // wgtMedian (src/PP.cpp:145-247; the plain weighted-median stage of PP::processDM, :405-410) on the device, for the
-    // pixels PostProcess_GPU marked invalid; same result as the reference's sequential in-place form
+    int LRCheck_GPU();         // lrCheck (src/PP.cpp:17-50): lValid / rValid; the maps stay untouched
+    int FillInvalid_GPU();     // fillInv (src/PP.cpp:52-143): fills the pixels the last L-R check marked invalid
+    // wgtMedian (src/PP.cpp:145-247) for the pixels the last L-R check marked invalid; same result as the reference's sequential
+    // in-place form
     int WgtMedian_GPU();
 
     // Frame loop (src/main.cpp:64-73) with the PCIe legs next to the kernels (single-device hosts): one call per frame -

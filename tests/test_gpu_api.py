@@ -334,3 +334,25 @@ def test_release_scratch_gives_memory_back_and_changes_nothing(psm, oracle):
         b = frame()
         assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
 
+
+@pytest.mark.parametrize("frames,dtype", [(1, "f32"), (2, "f32"), (3, "u8")])
+def test_frame_ring_returns_every_frames_maps_in_order(psm, oracle, frames, dtype):
+    """FrameRing: `frames` contexts take the frames of a stream in turn (two frames in the device's queues); every frame's maps
+    come back, in order, and equal the oracle's for THAT frame's pair."""
+    from primestereomatch_amd import synth
+    W, H, D = 200, 120, 24
+    pairs = [synth.make_pair(W, H, D, seed=40 + k)[:2] for k in range(7)]
+    want = [(oracle.pipeline_u8 if dtype == "u8" else oracle.pipeline_f32)(l, r, D, threads=8) for l, r in pairs]
+    got = []
+    with psm.FrameRing(*pairs[0], D, frames=frames, dtype=dtype) as ring:
+        for l, r in pairs:
+            out = ring.push(l, r)
+            if out is not None:
+                got.append(out)
+        assert len(got) == len(pairs) - frames
+        got += ring.flush()
+        assert ring.flush() == []
+    assert len(got) == len(pairs)
+    for k, ((lm, rm), e) in enumerate(zip(got, want)):
+        assert np.array_equal(lm, e["ldisp"]) and np.array_equal(rm, e["rdisp"]), k
+
