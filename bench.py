@@ -215,7 +215,7 @@ def main():
             import datetime
             if backend == "nccl":
                 dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev_index),
-                                        timeout=datetime.timedelta(seconds=180))
+                                        timeout=datetime.timedelta(seconds=900))      # (rank 0 checks maps against the CPU oracle between collectives: seconds at 1080p, a minute at 4K)
             else:
                 dist.init_process_group("gloo", rank=rank, world_size=world)
             ex = Exchange(torch, dist, backend)

@@ -180,6 +180,9 @@ def _exchange_worker(rank, world, port, q):
         w, b = pending.pop(0); w.wait(); stripes.assemble(recv, world, H, W, R, b); maps.append(b[:n].clone().numpy().reshape(2, H, W))
         ok &= all(np.array_equal(maps[f], full[f]) for f in range(frames))
         ok &= ex.max_float(float(rank)) == float(world - 1) and ex.collectives == 2 * frames + 1
+        # per-rank diagnostics of the bench line (compute / collective ms of every rank, on every rank)
+        per = ex.gather_floats([10.0 + rank, 0.5 * rank])
+        ok &= per == [[10.0 + r_, 0.5 * r_] for r_ in range(world)]
         ex.barrier()
         q.put((rank, bool(ok)))
     finally:
