@@ -738,7 +738,8 @@ def main():
                             "60/s^2 and 8 + 16/s^2 - bench.py); the sub-sampled costs are built on the fly and the filtered volume stays "
                             "virtual, so the physical traffic is far below these figures")
     traffic_file = os.path.join(ROOT, "profiles", "traffic.json")
-    if os.path.exists(traffic_file) and world == 1 and not args.shard_sim and select_mode:
+    variant_flags = fl_bits & (capi.PSM_FLAG_F32_TOL | capi.PSM_FLAG_FMA_SOLVE)      # (the PMC figures are those of the default form, one pair per launch)
+    if os.path.exists(traffic_file) and world == 1 and not args.shard_sim and select_mode and B == 1 and not variant_flags:
         try:
             tr = json.load(open(traffic_file))
             key = f"{args.config}:{dtype}:k_{dom}"
@@ -800,6 +801,7 @@ def main():
     # ---- CPU baseline: the oracle, driven like the reference pthreads path; its maps also check the timed path's ----
     cpu = None
     tol_model_maps = None
+    fma_model_maps = None
     oracle_maps = None
     O = None
     sim = args.shard_sim > 1
@@ -827,6 +829,11 @@ def main():
                 with O.variant(O.VAR_F32_L1):
                     rm_ = O.pipeline_f32(l, r, sd, threads=min(32, cores))
                 tol_model_maps = [rm_["ldisp"], rm_["rdisp"]]
+            if dtype == "f32" and args.flags >= 0 and (args.flags & capi.PSM_FLAG_FMA_SOLVE):
+                # the FMA reading of the solve is checked against the oracle's same reading - bit for bit
+                with O.variant(O.VAR_FMA_SOLVE):
+                    rm_ = O.pipeline_f32(l, r, sd, threads=min(32, cores))
+                fma_model_maps = [rm_["ldisp"], rm_["rdisp"]]
         elif dtype == "f32" and not args.no_oracle_check and not args.fgf:
             # (larger than 1080p x 256: the timed cpu_baseline is a sample of the disparities; the maps come from the oracle's
             # streaming form - same jobs and arithmetic, no volumes held - on up to 32 threads, outside every timed region)
@@ -869,6 +876,10 @@ def main():
         if tol_model_maps is not None and timed_maps is not None:
             checks["tolerance_form"] = {"flag": "PSM_FLAG_F32_TOL", "maps_equal_its_oracle_model": bool(np.array_equal(timed_maps[0], tol_model_maps[0]) and
                                                                                                    np.array_equal(timed_maps[1], tol_model_maps[1])),
+                                        "pixels_differing_from_the_canonical_oracle": checks.get("oracle_map_mismatches")}
+        if fma_model_maps is not None and timed_maps is not None:
+            checks["fma_solve_form"] = {"flag": "PSM_FLAG_FMA_SOLVE", "maps_equal_its_oracle_reading": bool(np.array_equal(timed_maps[0], fma_model_maps[0]) and
+                                                                                                        np.array_equal(timed_maps[1], fma_model_maps[1])),
                                         "pixels_differing_from_the_canonical_oracle": checks.get("oracle_map_mismatches")}
         if B > 1:      # every pair of the batch against its own single-pair run through the three reference entry points
             okb = True
