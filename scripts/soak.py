@@ -2,7 +2,9 @@
     python scripts/soak.py [seconds] [seed]
 Every case: random geometry / disparity range / dtype / tuning flags / segment rows, then one of: whole image, disparity
 shards, row stripes, both, or a BATCH of 2-6 different pairs through psm_compute_batch (round 4; sometimes with float images,
-shared streams, a hipGraph replay, a second frame staged asynchronously); maps (and sometimes the filtered volumes, the L-R check, fill and the weighted median) must be
+shared streams, a hipGraph replay, a second frame staged asynchronously), or (round 5) a FrameRing of 2-3 contexts over a short stream of
+pairs; one float case in five runs the FMA reading of the solve (PSM_FLAG_FMA_SOLVE) against the oracle's same reading, merges
+sometimes go through the host-staged exchange leg, scratch is sometimes released between calls; maps (and sometimes the filtered volumes, the L-R check, fill and the weighted median) must be
 bit-identical to the oracle.  Prints one line per failure and a summary."""
 import os
 import sys
@@ -19,6 +21,7 @@ from primestereomatch_amd.dispest import compute_batch, share_streams   # noqa: 
 import psm_oracle_py as O                 # noqa: E402
 
 FLAGS = [0, 0, 0, 0, 1048576, 1048576, 2097152, 128, 8192, 8192 | 128, 1048576 | 128]
+FMA_SOLVE = 67108864
 
 
 def one(rng, idx):
@@ -34,8 +37,14 @@ def one(rng, idx):
     if rng.random() < 0.3:
         a, b = sorted(int(v) for v in rng.integers(0, H, 2)); c, d = sorted(int(v) for v in rng.integers(0, W, 2))
         l[a:b + 1, c:d + 1] = int(rng.integers(0, 256)); r[a:b + 1, c:d + 1] = l[a, c]
-    ref = (O.pipeline_u8 if dtype == "u8" else O.pipeline_f32)(l, r, D, threads=8, want_volumes=(dtype == "f32" and D <= 24))
-    mode = rng.choice(["whole", "whole", "shards", "stripes", "both", "batch"])
+    mode = rng.choice(["whole", "whole", "shards", "stripes", "both", "batch", "ring"])
+    fma = dtype == "f32" and mode not in ("batch", "ring") and rng.random() < 0.2
+    if fma:
+        flags |= FMA_SOLVE
+        with O.variant(O.VAR_FMA_SOLVE):
+            ref = O.pipeline_f32(l, r, D, threads=8, want_volumes=(D <= 24))
+    else:
+        ref = (O.pipeline_u8 if dtype == "u8" else O.pipeline_f32)(l, r, D, threads=8, want_volumes=(dtype == "f32" and D <= 24))
     desc = f"case {idx}: {W}x{H} D={D} {dtype} flags={flags} seg={seg} mode={mode}"
 
     def setup(c):
@@ -44,6 +53,23 @@ def one(rng, idx):
             c.set_option(capi.PSM_OPT_SEG_ROWS, seg)
 
     ok = True
+    if mode == "ring":
+        # a FrameRing of 2-3 contexts over a short stream of different pairs: every frame's maps, in order, against its own oracle run
+        F = int(rng.integers(2, 4))
+        n = int(rng.integers(F, F + 4))
+        pairs = [(l, r)] + [synth.make_pair(W, H, D, seed=int(rng.integers(0, 1 << 16)))[:2] for _ in range(n - 1)]
+        refs = [ref] + [(O.pipeline_u8 if dtype == "u8" else O.pipeline_f32)(a, b, D, threads=8) for a, b in pairs[1:]]
+        got = []
+        with P.FrameRing(l, r, D, frames=F, dtype=dtype) as ring:
+            for c in ring.ctx:
+                c.set_option(capi.PSM_OPT_FLAGS, flags if flags in (0, 1048576, 2097152) else 0)
+            for a, b in pairs:
+                out = ring.push(a, b)
+                if out is not None:
+                    got.append(out)
+            got += ring.flush()
+        ok = len(got) == n and all(np.array_equal(g[0], e["ldisp"]) and np.array_equal(g[1], e["rdisp"]) for g, e in zip(got, refs))
+        return ok, desc + f" F={F} frames={n}"
     if mode == "batch":
         # B different pairs of this geometry in shared launches; every pair against its own oracle run.  Only the select
         # forms batch (flags 0 / two-phase on / off).
@@ -84,6 +110,8 @@ def one(rng, idx):
             setup(de)
             de.CostConst_GPU(); de.CostFilter_GPU(); de.DispSelect_GPU()
             ok &= np.array_equal(de.lDisMap, ref["ldisp"]) and np.array_equal(de.rDisMap, ref["rdisp"])
+            if rng.random() < 0.2:
+                de.release_scratch()             # (maps, minima and volumes are state, not scratch: everything below still holds)
             if "lvol" in ref and rng.random() < 0.5:
                 ok &= np.array_equal(de.download_volume(0), ref["lvol"]) and np.array_equal(de.download_volume(1), ref["rvol"])
             if rng.random() < 0.5:
@@ -107,7 +135,7 @@ def one(rng, idx):
     if mode in ("shards", "both") and D >= 2:
         dcuts = sorted(set([0, D] + [int(v) for v in rng.integers(1, D, size=int(rng.integers(1, 3)))]))
     if flags & (8192 | 128) and len(ycuts) > 2:
-        flags = 0             # stripes need the default select form
+        flags &= FMA_SOLVE    # stripes need the default select form (either arithmetic reading)
     outl, outr = np.zeros_like(ref["ldisp"]), np.zeros_like(ref["rdisp"])
     for y0, y1 in zip(ycuts[:-1], ycuts[1:]):
         shards = [P.DispEst(l, r, D, dtype=dtype, d_range=(d0, d1)) for d0, d1 in zip(dcuts[:-1], dcuts[1:])]
@@ -124,6 +152,8 @@ def one(rng, idx):
             else:
                 for s in shards:
                     s.DispSelect_partial()
+                if rng.random() < 0.3:
+                    shards[0].set_option(capi.PSM_OPT_GATHER_STAGED, 1)     # the exchange leg through page-locked host memory
                 shards[0].DispSelect_merge_ctx(shards)
             outl[y0:y1], outr[y0:y1] = shards[0].lDisMap[y0:y1], shards[0].rDisMap[y0:y1]
         finally:
