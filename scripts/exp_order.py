@@ -1,6 +1,8 @@
 """Experiment (round 5; experiment build: make -C primestereomatch_amd/csrc exp; PRIMESM_HIP_LIB=.../libprimesm_hip_exp.so):
 does the order in which an XCD walks its (pair, chunk) items matter for SHORT launches (a 32-slice disparity shard)?
     PSM_PC_ORDER=K  XCDs own whole (column group, segment) pairs and walk them K pairs interleaved (1: pair-major)
+                    (this knob and PSM_PC_SIDESX - both sides of a pair adjacent in one grid - lived in the kernel for the round-5
+                    experiments only: git history; the product's planner knobs PSM_PC_DC / _SLOTS / _S / _SPREAD remain)
     PSM_PC_DC, PSM_PC_SLOTS, seg_rows: the planner's other choices
 Prints ms per frame (best of 3 x 40 frames) per setting; maps / keys are compared with the default setting's."""
 import os
@@ -18,7 +20,7 @@ l, r, _ = synth.make_pair(W, H, D, seed=0)
 
 
 def run(d0, d1, env, seg=0, flags=0, steps=40):
-    for k in ("PSM_PC_ORDER", "PSM_PC_DC", "PSM_PC_SLOTS", "PSM_PC_S", "PSM_PC_SPREAD"):
+    for k in ("PSM_PC_ORDER", "PSM_PC_DC", "PSM_PC_SLOTS", "PSM_PC_S", "PSM_PC_SPREAD", "PSM_PC_SIDESX"):
         os.environ.pop(k, None)
     os.environ.update({k: str(v) for k, v in env.items()})
     with P.DispEst(l, r, D, 8, True, d_range=(d0, d1)) as de:
