@@ -104,10 +104,12 @@ def test_bare_multi_gpu_command_becomes_its_own_launcher(monkeypatch):
     monkeypatch.delenv("WORLD_SIZE", raising=False)
     monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "3", "--warmup", "1"])
     assert bench.main() == 0
-    (cmd, env), = calls
+    # round 5: the transport is probed first (init + one collective of the N ranks, two minutes at most), then the measurement runs
+    (probe, _), (cmd, env) = calls
+    assert probe[-3:] == ["--backend", "nccl", "--nccl-probe"] and "--nproc-per-node=4" in probe
     assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and "--nproc-per-node=4" in cmd
     assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
-    assert cmd[-6:] == ["--gpus", "4", "--steps", "3", "--warmup", "1"] and cmd[-7].endswith("bench.py")
+    assert cmd[-8:] == ["--gpus", "4", "--steps", "3", "--warmup", "1", "--backend", "nccl"] and cmd[-9].endswith("bench.py")
     assert env["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
     # more ranks than disparity slices (--shard disp) / than image rows (--shard rows, the default) is refused up front
     monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "100", "--config", "c2", "--shard", "disp"])
@@ -116,6 +118,36 @@ def test_bare_multi_gpu_command_becomes_its_own_launcher(monkeypatch):
     monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "400", "--config", "c2"])
     with pytest.raises(SystemExit):
         bench.main()
+
+
+def test_no_communicator_is_one_clear_line_and_no_measurement(monkeypatch, capsys):
+    """Round 5 (verdict r4 1b): when the RCCL probe of the N ranks fails, `python bench.py --gpus N` says so in ONE line and exits
+    with code 3 without starting the measurement; `--same-device` instead falls back to the gloo-staged exchange."""
+    import subprocess
+    import sys
+    import bench
+    calls = []
+
+    class FailingProbe:
+        pid = 0
+
+        def __init__(self, cmd, env=None, **kw):
+            calls.append(cmd)
+            self.returncode = 3 if "--nccl-probe" in cmd else 0
+
+        def communicate(self, timeout=None):
+            return None, "Traceback ...\nbench.py: RCCL communicator of 4 ranks failed on rank 2 (device 2): DistBackendError: NCCL error: unhandled system error\n"
+
+    monkeypatch.setattr(subprocess, "Popen", FailingProbe)
+    monkeypatch.delenv("RANK", raising=False)
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4"])
+    assert bench.main() == 3 and len(calls) == 1
+    err = capsys.readouterr().err.strip().splitlines()
+    assert len(err) == 1 and "no RCCL communicator of 4 ranks" in err[0] and "rank 2" in err[0]
+    calls.clear()
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "2", "--same-device"])
+    assert bench.main() == 0 and len(calls) == 2 and calls[1][calls[1].index("--backend") + 1] == "gloo"
 
 
 def test_round3_lines():
@@ -192,3 +224,50 @@ def test_round4_lines():
     t = _line_r("r04", "bench_c4_tol_ab1.json")
     assert t["tolerance_form"]["maps_equal_its_oracle_model"] is True and sum(t["tolerance_form"]["pixels_differing_from_the_canonical_oracle"]) < 50
     assert t["ms_per_step"] < _line_r("r04", "bench_c4_exact_ab1.json")["ms_per_step"]
+
+
+def test_round5_lines():
+    """profiles/r05: the headline leads with the binding resource, no line prints an HBM fraction above 1, BASELINE configs[2]
+    carries its own rocprof counters, the lines below the headline exist on the Middlebury pairs and with two frames in flight,
+    and N > 1 lines explain themselves (ranks, backend, per-rank compute / collective ms for both axes)."""
+    import glob
+    j = _line_r("r05", "bench_c4_n1.json")
+    W, H, D = j["config"]["W"], j["config"]["H"], j["config"]["D"]
+    assert (W, H, D) == (1920, 1080, 256) and j["dtype"] == "f32" and j["n_gpus"] == 1 and j["vs_baseline"] is None
+    assert abs(j["value"] - 2.0 * W * H * D / (j["ms_per_step"] * 1e-3)) / j["value"] < 1e-6
+    assert j["oracle_maps_equal"] is True and j["verified_vs_single_gpu"] is True and j["config"]["frames_in_flight"] == 1
+    r = j["roofline"]
+    assert r["bound"] == "hbm" and r["binding"] == "valu" and 0.7 < r["binding_frac"] <= 1.0 and r["binding_frac"] == r["valu"]["frac_of_valu_bound"]
+    assert r["traffic_session"].startswith("r05") and 0 < r["traffic_frac"] < 0.2 and "frac_basis" in r
+    for f in glob.glob(os.path.join(ROOT, "profiles", "r05", "bench_*.json")):       # never an HBM fraction above 1
+        k = json.loads([ln for ln in open(f).read().strip().splitlines() if ln.startswith("{")][-1])
+        fr = k["roofline"]["frac"]
+        assert fr is None or fr <= 1.0, (f, fr)
+    # BASELINE configs[2] (1280 x 720 x 128): rocprof HBM counters of its own passes
+    c3 = _line_r("r05", "bench_c3_n1.json")["roofline"]
+    assert c3["traffic"] > 0 and 0 < c3["traffic_frac"] < 0.2 and c3["binding"] == "valu" and 0.5 < c3["binding_frac"] <= 1.0
+    for n in ("rd", "wr", "sq"):
+        assert os.path.exists(os.path.join(ROOT, "profiles", "r05", f"rocprofv3_pmc_c3_{n}.summary.txt")), n
+    # the Middlebury pairs themselves, and two frames in flight
+    for name, what in (("bench_c2_teddy_n1.json", "Teddy"), ("bench_c1_cones_u8_n1.json", "Cones"), ("bench_c1x_cones_u8_n1.json", "Cones")):
+        k = _line_r("r05", name)
+        assert what in k["data"] and what in k["config"]["workload"] and k["oracle_maps_equal"] is True and k["verified_vs_single_gpu"] is True
+    for cfg in ("c3", "c2", "c1", "c1x"):
+        one = _line_r("r05", f"bench_{cfg}_n1.json" if cfg in ("c3", "c2") else f"bench_{cfg}_u8_n1.json")
+        two = _line_r("r05", f"bench_{cfg}_fif2.json")
+        assert two["config"]["frames_in_flight"] == 2 and two["frames_in_flight_maps_equal"] is True and two["oracle_maps_equal"] is True
+        assert two["ms_per_step"] < one["ms_per_step"] and "whole step" in two["roofline"]["frac_basis"], cfg
+    # N > 1 lines: self-explaining
+    for name, ranks in (("bench_c4_dist_world1.json", 1), ("bench_c4_world2_same_device.json", 2), ("bench_c4_world2_same_device_disp.json", 2)):
+        k = _line_r("r05", name)
+        assert k["ranks"] == ranks and k["exchange_backend"] in ("nccl", "gloo") and k["shard"] in ("rows", "disp")
+        for rec in (k, k["alt_shard"]):
+            assert len(rec["per_rank"]["compute_ms"]) == ranks and len(rec["per_rank"]["collective_ms"]) == ranks
+            assert all(v > 0 for v in rec["per_rank"]["compute_ms"] + rec["per_rank"]["collective_ms"])
+        assert k["verified_vs_single_gpu"] is True and k["alt_shard"]["verified_vs_single_gpu"] is True
+    # the opt-in arithmetic variants say what they were checked against
+    t = _line_r("r05", "bench_c4_tol_ab1.json")
+    assert t["tolerance_form"]["maps_equal_its_oracle_model"] is True and t["roofline"]["kernel_alg_equiv_frac"] >= t["roofline"]["frac"]
+    f = _line_r("r05", "bench_c4_fma_solve.json")
+    assert f["fma_solve_form"]["maps_equal_its_oracle_reading"] is True and sum(f["fma_solve_form"]["pixels_differing_from_the_canonical_oracle"]) < 50
+
