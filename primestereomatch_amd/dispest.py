@@ -359,12 +359,19 @@ class FrameRing:
         for lm, rm in ring.flush(): ...     # the frames still in flight, oldest first
     """
 
-    def __init__(self, l, r, d: int, frames: int = 2, *, dtype: str = "f32", device: int = 0, lr_check: bool = False):
+    def __init__(self, l, r, d: int, frames: int = 2, *, dtype: str = "f32", device: int = 0, lr_check: bool = False,
+                 seg_rows: int = 0):
+        """seg_rows > 0: PSM_OPT_SEG_ROWS of every context.  The planner's cost model assumes a launch runs alone (its last, half-empty
+        round of workgroups costs half a round); with a second frame filling that tail a Middlebury-size launch is best served by
+        ONE segment (seg_rows = image height: least halo) - measured -4 ... -7 % at 450 x 375 x 64 and 384 x 288 x 64, nothing at
+        1280 x 720 x 128 and above (profiles/r05/exp_segments_with_frames_in_flight.txt)."""
         if frames < 1:
             raise ValueError("FrameRing: frames must be >= 1")
         self.ctx = [DispEst(l, r, d, dtype=dtype, device=device) for _ in range(frames)]
         for c in self.ctx:
             c.set_option(capi.PSM_OPT_ASYNC, 1)
+            if seg_rows > 0:
+                c.set_option(capi.PSM_OPT_SEG_ROWS, int(seg_rows))
         self._n = 0
         self._busy = [False] * frames
         self._lrc = lr_check

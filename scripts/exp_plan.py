@@ -49,20 +49,22 @@ def run(W, H, D, l, r, d0, d1, y0, y1, env, seg, F, steps=40, dtype="f32"):
     return best
 
 
-W, H, D = 1920, 1080, 256
-l, r, _ = synth.make_pair(W, H, D, seed=0)
-for name, d0, d1, y0, y1 in (("disp8", 0, 32, 0, 0), ("rows8", 0, 256, 0, 135)):
-    for F in (1, 2):
-        for dc in ((0, 1, 2, 4, 8) if name == "disp8" else (0,)):
-            for seg in ((0, 135, 180, 216, 270, 360) if name == "disp8" else (0, 45, 68, 135)):
-                env = {"PSM_PC_DC": dc} if dc else {}
-                ms = run(W, H, D, l, r, d0, d1, y0, y1, env, seg, F)
-                print(f"{name}: F={F} DC={dc} seg={seg}: {ms:.4f} ms per frame", flush=True)
-for cfg, (W, H, D), dt in (("c3", (1280, 720, 128), "f32"), ("c2", (450, 375, 64), "f32"), ("c1", (450, 375, 64), "u8")):
+if __name__ == "__main__":
+    W, H, D = 1920, 1080, 256
     l, r, _ = synth.make_pair(W, H, D, seed=0)
-    for F in (1, 2):
-        for dc in (0, 1, 2, 4):
-            for seg in ((0,) if cfg == "c3" else (0, 94, 125, 188, 375)):
-                env = {"PSM_PC_DC": dc} if dc else {}
-                ms = run(W, H, D, l, r, 0, D, 0, 0, env, seg, F, dtype=dt)
-                print(f"{cfg}: F={F} DC={dc} seg={seg}: {ms:.4f} ms per frame", flush=True)
+    for name, d0, d1, y0, y1 in (("disp8", 0, 32, 0, 0), ("rows8", 0, 256, 0, 135)):
+        for F in (1, 2):
+            for dc in ((0, 1, 2, 4, 8) if name == "disp8" else (0,)):
+                for seg in ((0, 135, 180, 216, 270, 360) if name == "disp8" else (0, 45, 68, 135)):
+                    env = {"PSM_PC_DC": dc} if dc else {}
+                    ms = run(W, H, D, l, r, d0, d1, y0, y1, env, seg, F)
+                    print(f"{name}: F={F} DC={dc} seg={seg}: {ms:.4f} ms per frame", flush=True)
+    for cfg, (W, H, D), dt in (("c3", (1280, 720, 128), "f32"), ("c2", (450, 375, 64), "f32"), ("c1", (450, 375, 64), "u8")):
+        l, r, _ = synth.make_pair(W, H, D, seed=0)
+        for F in (1, 2):
+            for dc in (0, 1, 2, 4):
+                for seg in ((0,) if cfg == "c3" else (0, 94, 125, 188, 375)):
+                    env = {"PSM_PC_DC": dc} if dc else {}
+                    ms = run(W, H, D, l, r, 0, D, 0, 0, env, seg, F, dtype=dt)
+                    print(f"{cfg}: F={F} DC={dc} seg={seg}: {ms:.4f} ms per frame", flush=True)
+

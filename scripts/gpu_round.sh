@@ -61,6 +61,11 @@ $B --config c1x --pair fixture --steps 30 --verify --no-cpu-wide > $OUT/bench_c1
 for cfg in c3 c2 c1 c1x; do $B --config $cfg --frames-in-flight 2 --steps 40 --verify --no-cpu-wide > $OUT/bench_${cfg}_fif2.json 2>> $OUT/bench_var.err; done
 $B --config c2 --pair fixture --frames-in-flight 2 --steps 40 --verify --no-cpu-wide > $OUT/bench_c2_teddy_fif2.json 2>> $OUT/bench_var.err
 $B --config c1 --pair fixture --frames-in-flight 2 --steps 40 --verify --no-cpu-wide > $OUT/bench_c1_cones_u8_fif2.json 2>> $OUT/bench_var.err
+# (with a second frame filling its tail a small launch wants ONE segment - least halo - which the planner, whose cost model assumes the
+#  launch runs alone, does not pick: profiles/r05/exp_segments_with_frames_in_flight.txt)
+$B --config c2 --pair fixture --frames-in-flight 2 --seg-rows 375 --steps 40 --verify --no-cpu-wide > $OUT/bench_c2_teddy_fif2_seg375.json 2>> $OUT/bench_var.err
+$B --config c1 --pair fixture --frames-in-flight 2 --seg-rows 375 --steps 40 --verify --no-cpu-wide > $OUT/bench_c1_cones_u8_fif2_seg375.json 2>> $OUT/bench_var.err
+$B --config c1x --pair fixture --frames-in-flight 2 --seg-rows 288 --steps 40 --verify --no-cpu-wide > $OUT/bench_c1x_cones_u8_fif2_seg288.json 2>> $OUT/bench_var.err
 $B --frames-in-flight 2 --no-cpu-baseline --frame-loop 0 > $OUT/bench_c4_fif2.json 2>> $OUT/bench_var.err
 $B --flags 67108864 --no-cpu-wide --frame-loop 0 > $OUT/bench_c4_fma_solve.json 2>> $OUT/bench_var.err
 $B --config c4 --dtype u8 --verify > $OUT/bench_c4_u8_n1.json 2>> $OUT/bench_var.err
