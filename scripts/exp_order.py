@@ -61,23 +61,25 @@ def run(d0, d1, env, seg=0, flags=0, steps=40):
     return best, [round(ms, 4) for ms, _ in lt], sig
 
 
-base = {}
-QUICK = len(sys.argv) > 1 and sys.argv[1] == "quick"
-for name, d0, d1, steps in (("disp8", 0, 32, 40), ("c4", 0, 256, 12)):
-    settings = [({}, 0, 0)]
-    if QUICK:
-        settings += [({}, 0, capi.PSM_FLAG_TWO_PHASE_OFF)] if name == "c4" else [({"PSM_PC_DC": 4}, 0, 0)]
-    elif name == "disp8":
-        settings += [({"PSM_PC_ORDER": k}, 0, 0) for k in (1, 2, 3, 9)]
-        settings += [({"PSM_PC_DC": dc}, 0, 0) for dc in (1, 4)]
-        settings += [({"PSM_PC_DC": 1, "PSM_PC_ORDER": 1}, 0, 0)]
-        settings += [({}, s, 0) for s in (120, 135, 180, 216, 270, 360, 540)]
-        settings += [({"PSM_PC_SLOTS": s}, 0, 0) for s in (64, 128)]
-        settings += [({"PSM_PC_S": s}, 0, capi.PSM_FLAG_TWO_PHASE_ON) for s in (4, 8, 16, 32)]
-    else:
-        settings += [({"PSM_PC_ORDER": k}, 0, 0) for k in (1, 2)]
-    for env, seg, flags in settings:
-        ms, lt, sig = run(d0, d1, env, seg, flags, steps)
-        if name not in base:
-            base[name] = sig
-        print(f"{name}: env {env} seg {seg} flags {flags}: {ms:.4f} ms per frame; launches {lt}; same result: {bool(np.array_equal(sig, base[name]))}", flush=True)
+if __name__ == "__main__":
+    base = {}
+    QUICK = len(sys.argv) > 1 and sys.argv[1] == "quick"
+    for name, d0, d1, steps in (("disp8", 0, 32, 40), ("c4", 0, 256, 12)):
+        settings = [({}, 0, 0)]
+        if QUICK:
+            settings += [({}, 0, capi.PSM_FLAG_TWO_PHASE_OFF)] if name == "c4" else [({"PSM_PC_DC": 4}, 0, 0), ({}, 0, capi.PSM_FLAG_TWO_PHASE_ON), ({"PSM_PC_S": 4}, 0, capi.PSM_FLAG_TWO_PHASE_ON)]
+        elif name == "disp8":
+            settings += [({"PSM_PC_ORDER": k}, 0, 0) for k in (1, 2, 3, 9)]
+            settings += [({"PSM_PC_DC": dc}, 0, 0) for dc in (1, 4)]
+            settings += [({"PSM_PC_DC": 1, "PSM_PC_ORDER": 1}, 0, 0)]
+            settings += [({}, s, 0) for s in (120, 135, 180, 216, 270, 360, 540)]
+            settings += [({"PSM_PC_SLOTS": s}, 0, 0) for s in (64, 128)]
+            settings += [({"PSM_PC_S": s}, 0, capi.PSM_FLAG_TWO_PHASE_ON) for s in (4, 8, 16, 32)]
+        else:
+            settings += [({"PSM_PC_ORDER": k}, 0, 0) for k in (1, 2)]
+        for env, seg, flags in settings:
+            ms, lt, sig = run(d0, d1, env, seg, flags, steps)
+            if name not in base:
+                base[name] = sig
+            print(f"{name}: env {env} seg {seg} flags {flags}: {ms:.4f} ms per frame; launches {lt}; same result: {bool(np.array_equal(sig, base[name]))}", flush=True)
+
