@@ -124,6 +124,14 @@ int DispEst::DispSelect_GPU()
     return rc;
 }
 
+int DispEst::setOption(int option, int value)
+{
+    if (ctx.empty()) return 1;
+    int rc = 0;
+    for (psm_ctx *c : ctx) rc |= hipUtil::api().set_option(c, option, value);
+    return rc;
+}
+
 int DispEst::LRCheck_GPU()
 {
     if (ctx.empty()) return 1;
