@@ -78,6 +78,18 @@ def spawn_ranks(n, args):
             return 124, "no communicator within %d s" % timeout
         return p.returncode, err
 
+    if not args.same_device:
+        # one rank per GPU: more ranks than devices cannot work - say so before anything is launched
+        try:
+            from primestereomatch_amd import capi
+            ndev = capi.device_count()
+        except Exception as e:      # (no library / no runtime: the ranks will say why)
+            ndev = None
+            print(f"bench.py: could not count the devices ({type(e).__name__}: {e}); launching anyway", file=sys.stderr)
+        if ndev is not None and ndev < n:
+            print(f"bench.py: --gpus {n} needs {n} devices, this node shows {ndev} (one rank per GPU; --same-device runs the N > 1 "
+                  "protocol on one GPU as a correctness check); nothing measured", file=sys.stderr)
+            return 3
     if args.backend in ("auto", "nccl") and not args.nccl_probe:
         # Does an RCCL communicator of these ranks come up at all?  One short probe run first (init + one collective, two minutes
         # at most), so that a transport problem is ONE clear line instead of N tracebacks in the middle of a measurement.
@@ -209,6 +221,9 @@ def main():
             raise SystemExit(f"bench.py --gpus {N}: WORLD_SIZE={world} in the environment does not match")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
+        if dev_index >= torch.cuda.device_count():
+            print(f"bench.py: rank {rank} wants device {dev_index}, this node shows {torch.cuda.device_count()} (one rank per GPU)", file=sys.stderr)
+            os._exit(3)
         torch.cuda.set_device(dev_index)
         from primestereomatch_amd.exchange import Exchange
         try:

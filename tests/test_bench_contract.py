@@ -100,6 +100,8 @@ def test_bare_multi_gpu_command_becomes_its_own_launcher(monkeypatch):
             return None, ""
 
     monkeypatch.setattr(subprocess, "Popen", FakePopen)
+    from primestereomatch_amd import capi
+    monkeypatch.setattr(capi, "device_count", lambda: 8)
     monkeypatch.delenv("RANK", raising=False)
     monkeypatch.delenv("WORLD_SIZE", raising=False)
     monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "3", "--warmup", "1"])
@@ -139,6 +141,8 @@ def test_no_communicator_is_one_clear_line_and_no_measurement(monkeypatch, capsy
             return None, "Traceback ...\nbench.py: RCCL communicator of 4 ranks failed on rank 2 (device 2): DistBackendError: NCCL error: unhandled system error\n"
 
     monkeypatch.setattr(subprocess, "Popen", FailingProbe)
+    from primestereomatch_amd import capi
+    monkeypatch.setattr(capi, "device_count", lambda: 8)
     monkeypatch.delenv("RANK", raising=False)
     monkeypatch.delenv("WORLD_SIZE", raising=False)
     monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4"])
@@ -148,6 +152,14 @@ def test_no_communicator_is_one_clear_line_and_no_measurement(monkeypatch, capsy
     calls.clear()
     monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "2", "--same-device"])
     assert bench.main() == 0 and len(calls) == 2 and calls[1][calls[1].index("--backend") + 1] == "gloo"
+    # more ranks than devices: refused before anything is launched, in one line
+    calls.clear()
+    capsys.readouterr()
+    monkeypatch.setattr(capi, "device_count", lambda: 1)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4"])
+    assert bench.main() == 3 and calls == []
+    err = capsys.readouterr().err.strip().splitlines()
+    assert len(err) == 1 and "needs 4 devices" in err[0]
 
 
 def test_round3_lines():
