@@ -98,3 +98,30 @@ def test_lr_check_inside_the_step(extra):
     the validity masks of the timed path equal those of the plain one-GPU run."""
     j = _bench("--config", "c3", "--lr-check", "1", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--verify", *extra)
     assert j["config"]["lr_check_on_gpu"] is True and j["verified_vs_single_gpu"] is True
+
+
+@pytest.mark.parametrize("cfg,extra", [("c2", ("--pair", "fixture", "--seg-rows", "375")), ("c1x", ("--pair", "fixture")), ("c3", ("--pp",))])
+def test_frames_in_flight_and_the_middlebury_fixtures(cfg, extra):
+    """Round 5: --frames-in-flight 2 (two contexts on two streams take the steps in turn) and --pair fixture (Teddy for c2, Cones /
+    its 384 x 288 crop for the c1 configs): same maps on every context of the ring, equal to the single-context run and the oracle;
+    the line says what its roofline fraction refers to; N > 1 fields appear on distributed lines only."""
+    j = _bench("--config", cfg, "--frames-in-flight", "2", "--steps", "6", "--warmup", "2", "--cpu-sample-d", "0", "--no-cpu-wide", "--verify", *extra)
+    assert j["config"]["frames_in_flight"] == 2 and j["frames_in_flight_maps_equal"] is True
+    assert j["verified_vs_single_gpu"] is True and j["oracle_maps_equal"] is True
+    r = j["roofline"]
+    assert "whole step" in r["frac_basis"] and r["frac"] <= 1.0 and r["binding"] == "valu" and "valu" not in r
+    assert "ranks" not in j and "per_rank" not in j
+    if "fixture" in extra:
+        assert "Middlebury" in j["data"]
+    if "--pp" in extra:
+        assert j["pp"]["verified_vs_oracle"] is True
+
+
+def test_n_gt_1_line_explains_itself():
+    """Round 5: ranks, backend, shard, exchange, frame pipeline and per-rank compute / collective ms for both axes."""
+    j = _bench("--gpus", "1", "--force-dist", "--config", "c3", "--steps", "3", "--warmup", "1", "--no-cpu-baseline")
+    assert j["ranks"] == 1 and j["exchange_backend"] == "nccl" and j["shard"] == "rows" and j["frame_pipeline"] is True
+    for rec in (j, j["alt_shard"]):
+        pr = rec["per_rank"]
+        assert len(pr["compute_ms"]) == 1 and len(pr["collective_ms"]) == 1 and pr["compute_ms"][0] > pr["collective_ms"][0] > 0
+
