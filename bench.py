@@ -346,6 +346,9 @@ def main():
             if rows_mode:
                 o_.set_rows(y0, y1)
             ring.append(o_)
+        if FIF > 1:
+            for o_ in ring:                  # what FrameRing tells its contexts: the planner cuts the launches for FIF pairs at a time
+                o_.set_option(capi.PSM_OPT_FRAMES_IN_FLIGHT, FIF)
         keys_local = keys_all = None
         kbuf = []
         pending = []                 # (work handles, buffer) of the frame whose merge is still outstanding

@@ -60,9 +60,13 @@ enum {
     PSM_OPT_FLAGS = 5,          /* PSM_FLAG_* bits below; no flag but PSM_FLAG_F32_TOL / PSM_FLAG_FMA_SOLVE changes any result */
     PSM_OPT_GRAPH = 6,          /* 1: psm_compute_batch captures its launches once as a hipGraph and replays it while the batch
                                    (contexts, geometry, options) stays the same; ignored while PSM_OPT_PROFILE is on */
-    PSM_OPT_GATHER_STAGED = 7   /* 1 (on the ROOT context): psm_gather_rows_ctx / psm_disp_merge_ctx move every stripe / shard through
+    PSM_OPT_GATHER_STAGED = 7,  /* 1 (on the ROOT context): psm_gather_rows_ctx / psm_disp_merge_ctx move every stripe / shard through
                                    page-locked host memory instead of device / peer copies - what they do on their own between two
                                    devices for which hipDeviceCanAccessPeer says no; the option forces that path (test hook) */
+    PSM_OPT_FRAMES_IN_FLIGHT = 8 /* F >= 1 (default 1): this context is one of F contexts of the same geometry whose frames are
+                                   filtered at the same time, each on its own stream (the frame loop of src/main.cpp:64-73 with F
+                                   frames queued).  A hint for the planner of the fused launches only - how the work is cut into
+                                   segments and chunks; no result changes */
 };
 
 /* PSM_OPT_FLAGS bits.  The default (0) is the product path: cost volumes and filtered volumes stay virtual, the fused

@@ -20,7 +20,7 @@ PSM_STAGE_CVC, PSM_STAGE_CVF, PSM_STAGE_DISPSEL, PSM_STAGE_PP = 0, 1, 2, 3
 (PSM_K_PREP, PSM_K_CVC, PSM_K_GUIDE, PSM_K_CVF_A, PSM_K_CVF_B, PSM_K_WTA, PSM_K_MERGE, PSM_K_BOX,
  PSM_K_LRC, PSM_K_CVF_F, PSM_K_FGF, PSM_K_WMF) = range(12)
 (PSM_OPT_ASYNC, PSM_OPT_KERNEL_VARIANT, PSM_OPT_PROFILE, PSM_OPT_SEG_ROWS, PSM_OPT_WAVES, PSM_OPT_FLAGS, PSM_OPT_GRAPH,
- PSM_OPT_GATHER_STAGED) = range(8)
+ PSM_OPT_GATHER_STAGED, PSM_OPT_FRAMES_IN_FLIGHT) = range(9)
 # enum psm_flag (PSM_OPT_FLAGS bits)
 PSM_FLAG_MATERIALISE_COSTS, PSM_FLAG_FGF_STORE, PSM_FLAG_STORE_FILTERED = 128, 4096, 8192
 PSM_FLAG_TWO_PHASE_ON, PSM_FLAG_TWO_PHASE_OFF = 1048576, 2097152

@@ -357,6 +357,9 @@ int psm_set_option(psm_ctx *c, int option, int value)
         c->march.flags = value; return 0;
     case PSM_OPT_GRAPH: c->opt_graph = value != 0; return 0;
     case PSM_OPT_GATHER_STAGED: c->opt_gather_staged = value != 0; return 0;
+    case PSM_OPT_FRAMES_IN_FLIGHT:
+        if (value < 1 || value > 64) return fail(c, "psm_set_option: frames in flight %d not in [1, 64]", value);
+        c->march.inflight = value; return 0;
     default: return fail(c, "psm_set_option: unknown option %d", option);
     }
 }

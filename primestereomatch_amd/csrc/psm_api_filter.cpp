@@ -360,7 +360,7 @@ int filter_both(psm_ctx *c)
     if (two_phase) {
         const int S = pc_seed_stride(c->W, c->H);
         const int n1 = (c->Dloc + S - 1) / S, n2 = c->Dloc - n1;
-        const PcPlan pl1 = pc_plan(c->W, c->march.rows(c->H), n1, c->march.seg_rows, PC_PLANES | PC_BOTH);
+        const PcPlan pl1 = pc_plan(c->W, c->march.rows(c->H), n1, c->march.seg_rows, PC_PLANES | PC_BOTH, 1, c->march.inflight);
         if (ensure_gf_scratch(c, 2 * pl1.scratch_bytes())) return 1;
         {
             Prof p(c, PSM_K_CVF_F);
@@ -377,7 +377,7 @@ int filter_both(psm_ctx *c)
         c->gf_virtual[0] = c->gf_virtual[1] = true;
         return check_launch(c, "cvf (fused, select mode, two phases, both volumes)");
     }
-    const PcPlan pl = pc_plan(c->W, c->march.rows(c->H), c->Dloc, c->march.seg_rows, PC_PLANES | PC_BOTH);
+    const PcPlan pl = pc_plan(c->W, c->march.rows(c->H), c->Dloc, c->march.seg_rows, PC_PLANES | PC_BOTH, 1, c->march.inflight);
     if (ensure_gf_scratch(c, 2 * pl.scratch_bytes())) return 1;
     {
         Prof p(c, PSM_K_CVF_F);

@@ -22,6 +22,7 @@ struct March {       // geometry of the marching kernels
     int seg_rows;    // output rows per y-segment (0 = auto)
     int waves;       // waves (= disparity slices) per workgroup: 1,2,4,8
     int flags;       // PSM_OPT_FLAGS (include/primesm_hip.h)
+    int inflight = 1;         // PSM_OPT_FRAMES_IN_FLIGHT: pairs other contexts filter at the same time on their own streams (a planning hint only)
     int ybeg = 0, yend = 0;   // row stripe of the select-form filter (psm_set_rows): output rows [ybeg, yend) of the whole
                               // image; yend <= ybeg: all rows
     int y0(int H) const { (void)H; return yend > ybeg ? ybeg : 0; }
@@ -74,11 +75,13 @@ PcDev pc_dev();                                                  // of the devic
 enum { PC_STORE = 0, PC_PLANES = 1, PC_KEYS = 2, PC_BOTH = 4 };  // forms of pc_plan (PC_BOTH: both volumes per launch)
 struct PcPlan {
     int ngroups, nsegs, seg_rows, DC, nchunks, nbmax, nxcd;
+    int cols;                                                    // output columns per column group (107; 50 in the narrow layout; 96 storing form)
+    bool narrow;                                                 // two-wave workgroups (one producer + one consumer wave)
     size_t rec_per_chunk;                                        // records per chunk plane
     int rec_bytes;                                               // bytes per record (costs + disparities)
     size_t scratch_bytes() const { return rec_per_chunk * (size_t)nchunks * rec_bytes; }
 };
-PcPlan pc_plan(int W, int rows, int Dloc, int seg_rows_opt, int form, int batch = 1);   // batch: pairs per launch (psm_compute_batch)
+PcPlan pc_plan(int W, int rows, int Dloc, int seg_rows_opt, int form, int batch = 1, int inflight = 1);   // batch: pairs per launch (psm_compute_batch); inflight: March::inflight
 int pc_seed_stride(int W, int H);                                // S of the two-phase selection: every S-th slice seeds the key plane
 // ts (may be NULL): slot of this launch in a buffer of 3 x PC_TS_SLOTS 64-bit words {first workgroup start | last workgroup
 // end | form} in ticks of the device's constant-rate clock (PSM_OPT_PROFILE 2, psm_filter_launch_times)

@@ -55,10 +55,16 @@ typedef float f4v __attribute__((ext_vector_type(4)));
 // spills under the cap, but there the shorter look-ahead costs what the fourth workgroup gains.
 constexpr int PC_RING = 4;   // batches of four model rows kept in LDS
 
-template <int MODE> struct PcLayout;
-template <> struct PcLayout<0> { static constexpr int NA = 2, NB = 2, OUT_A = 52, OUT_B = 48, COLS = 96; };
-template <> struct PcLayout<1> { static constexpr int NA = 2, NB = 2, OUT_A = 57, OUT_B = 54, COLS = 107; };
-template <> struct PcLayout<2> : PcLayout<1> {};
+// NARROW (select forms only): one producer + one consumer wave, 57 model columns -> 50 output columns.  Per wave a little less
+// useful (25 output columns against 26.75) but half the granularity: an image whose last 107-column group would be mostly empty
+// (450 columns = 4 groups + 22 columns) is cut into 9 groups of 50 instead - 18 waves' worth of columns instead of 20.  pc_plan picks
+// the layout that needs fewer waves per row of the image (ties: the wide one).
+template <int MODE, bool NARROW = false> struct PcLayout;
+template <> struct PcLayout<0, false> { static constexpr int NA = 2, NB = 2, OUT_A = 52, OUT_B = 48, COLS = 96; };
+template <> struct PcLayout<1, false> { static constexpr int NA = 2, NB = 2, OUT_A = 57, OUT_B = 54, COLS = 107; };
+template <> struct PcLayout<2, false> : PcLayout<1, false> {};
+template <> struct PcLayout<1, true> { static constexpr int NA = 1, NB = 1, OUT_A = 57, OUT_B = 50, COLS = 50; };
+template <> struct PcLayout<2, true> : PcLayout<1, true> {};
 constexpr int PC_K_LD_AUX = 0;     // cache policy of MODE 1's record loads.  A record is only ever read by the lane that wrote it
                                    // (one slice earlier), and a thread always observes its own stores: plain cached loads are
                                    // coherent here.  (16 = sc1 bypasses the L2 as well: measured 25 % slower kernel.)
@@ -151,8 +157,8 @@ __device__ __forceinline__ int pc_slice(const PcSel &o, int i)
 //     BASELINE.json states for float mode, not the oracle's bits;
 //   2 (PSM_FLAG_FMA_SOLVE): the 3x3 solve as an FMA target compiles it (psm_dev.h: solve_ab<true>; minors / DET from
 //     k_guide_march in their fused forms) - the oracle's reading PSMO_VAR_FMA_SOLVE, bit for bit.
-template <bool VEC4, int CVC, int MODE, bool U8 = false, bool BATCH = false, int VAR = 0>
-__global__ __launch_bounds__(64 * (PcLayout<MODE>::NA + PcLayout<MODE>::NB))
+template <bool VEC4, int CVC, int MODE, bool U8 = false, bool BATCH = false, int VAR = 0, bool NARROW = false>
+__global__ __launch_bounds__(64 * (PcLayout<MODE, NARROW>::NA + PcLayout<MODE, NARROW>::NB))
 __attribute__((amdgpu_waves_per_eu(MODE == 2 ? 4 : 1, MODE == 2 ? 4 : 8)))   // the key form capped at 128 VGPRs = four workgroups per CU
 void k_cvf_pc(
     const float *__restrict__ vin, float *__restrict__ vout, const float4 *__restrict__ G1a, const float4 *__restrict__ G2a,
@@ -185,7 +191,8 @@ void k_cvf_pc(
     const float4 *const Gother = s1 ? side1.Gother : Gothera;
     float *const kcost = s1 ? side1.kcost : kcosta;
     unsigned *const kdisp = s1 ? side1.kdisp : kdispa;
-    using L = PcLayout<MODE>;
+    static_assert(!NARROW || (MODE != 0 && CVC == 3), "the narrow layout exists for the two-volume select forms");
+    using L = PcLayout<MODE, NARROW>;
     constexpr int PC_NA = L::NA, PC_NB = L::NB, PC_OUT_A = L::OUT_A, PC_OUT_B = L::OUT_B, PC_COLS = L::COLS;
     constexpr int PC_MCOLS = PC_NA * PC_OUT_A;   // model columns per workgroup (>= PC_COLS + 7)
     // Select forms: the x 1/64 of the two box filters is not applied per window sum (a v_ldexp_f64 per channel and step).  The
@@ -567,12 +574,11 @@ void k_cvf_pc(
 __global__ __launch_bounds__(256) void k_chunk_min(const float4 *kcost, const unsigned *kdisp, int nchunks, int npairs,
                                                   int nbmax, int ngroups, int seg_rows, int W, int H, long long *keys,
                                                   uint8_t *map, const float4 *__restrict__ kcost1, const unsigned *__restrict__ kdisp1,
-                                                  int ybeg, int yend, const PcPair *__restrict__ batch, int to_maps)
-{
-    using L = PcLayout<1>;
+                                                  int ybeg, int yend, const PcPair *__restrict__ batch, int to_maps, int cols)
+{   // cols: output columns per (column group) of the layout the select kernel ran with (107 / 50)
     if (batch) {             // batched launch: blockIdx.z = pair, planes / keys / maps from the table
         const PcPair pp = batch[blockIdx.z];
-        const size_t rec_total = (size_t)npairs * nbmax * L::COLS * nchunks;
+        const size_t rec_total = (size_t)npairs * nbmax * cols * nchunks;
         kcost = (const float4 *)pp.scratch;
         kdisp = (const unsigned *)(kcost + rec_total);
         kcost1 = (const float4 *)((const char *)pp.scratch + rec_total * 20);
@@ -586,15 +592,15 @@ __global__ __launch_bounds__(256) void k_chunk_min(const float4 *kcost, const un
         if (keys) keys += (size_t)W * H;
         if (map) map += (size_t)W * H;
     }
-    const size_t nrec = (size_t)npairs * nbmax * L::COLS;          // records per chunk plane
+    const size_t nrec = (size_t)npairs * nbmax * cols;          // records per chunk plane
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= nrec) return;
-    const int col = (int)(idx % L::COLS);
-    size_t t = idx / L::COLS;
+    const int col = (int)(idx % cols);
+    size_t t = idx / cols;
     const int c = (int)(t % nbmax);
     const int pair = (int)(t / nbmax);
     const int g = pair % ngroups, seg = pair / ngroups;
-    const int x = g * L::COLS + col;
+    const int x = g * cols + col;
     if (x >= W) return;
     const int y0 = ybeg + seg * seg_rows, y1 = min(yend, y0 + seg_rows);
     const int ya = y0 + 4 * c - 7;                                  // output row of the record's first entry
@@ -661,23 +667,45 @@ PcDev pc_dev()
 // workgroups (key form: x 4).  Cost model, fitted to measurements at 1080p (DC = 1, 2, 4, 8, 16: 4.39, 4.41, 4.46, 4.71,
 // 4.99 ms for kernel + reduction): (rounds + 1/2) x rows walked per workgroup - the last round is on average half empty,
 // which is what makes long-running workgroups (large DC) expensive - plus two row-steps per chunk plane for the reduction.
-PcPlan pc_plan(int W, int rows, int Dloc, int seg_rows_opt, int form, int batch)
+PcPlan pc_plan(int W, int rows, int Dloc, int seg_rows_opt, int form, int batch, int inflight)
 {   // form: PC_STORE; PC_PLANES (select with chunk planes) / PC_KEYS (select against a shared key plane, one slice per
     // workgroup, no reduction afterwards), each + PC_BOTH when one launch covers both volumes (twice the work items)
     const bool planes = (form & 3) == PC_PLANES, keys = (form & 3) == PC_KEYS;
     const int sides = ((form & PC_BOTH) ? 2 : 1) * (batch > 1 ? batch : 1);   // volumes per launch
-    const int cols = (form & 3) == PC_STORE ? PcLayout<0>::COLS : PcLayout<1>::COLS;
     const PcDev dev = pc_dev();
     PcPlan pl;
     pl.nxcd = dev.nxcd;
+    // layout: the narrow one (2 waves per 50 columns) where it needs fewer waves per image row than the wide one (4 per 107);
+    // both-volume select launches only (the product path); ties go to the wide layout
+    constexpr int WIDE = PcLayout<1>::COLS, NARROW = PcLayout<1, true>::COLS;
+    pl.narrow = (form & 3) != PC_STORE && (form & PC_BOTH) && 2 * ((W + NARROW - 1) / NARROW) < 4 * ((W + WIDE - 1) / WIDE);
+    if ((form & 3) != PC_STORE && (form & PC_BOTH) && PSM_KNOB("PSM_PC_NARROW", 0) > 0) pl.narrow = PSM_KNOB("PSM_PC_NARROW", 0) == 1;   // (experiment builds: 1 forces the narrow layout, 2 the wide one)
+    const int cols = (form & 3) == PC_STORE ? PcLayout<0>::COLS : (pl.narrow ? NARROW : WIDE);
+    pl.cols = cols;
     pl.ngroups = (W + cols - 1) / cols;
-    const int kmax = rows / 64 > 1 ? rows / 64 : 1;
+    const int kdiv = PSM_KNOB("PSM_PC_KDIV", rows < 128 ? 32 : 64);     // (under 128 rows: segments of 32+ rows - 150 x 120: 0.082 -> 0.057 ms)
+    const int kmax = rows / kdiv > 1 ? rows / kdiv : 1;
     int dcs[5] = {1, 2, 4, 8, 16};
     int ndc = planes ? 5 : 1;
     if (planes && PSM_KNOB("PSM_PC_DC", 0) > 0) { dcs[0] = PSM_KNOB("PSM_PC_DC", 0); ndc = 1; }
-    const long slots = PSM_KNOB("PSM_PC_SLOTS", (long)dev.cus_per_xcd * (keys ? 4 : 3));   // resident workgroups per XCD
+    const long slots = PSM_KNOB("PSM_PC_SLOTS", (long)dev.cus_per_xcd * (keys ? 4 : 3) * (pl.narrow ? 2 : 1));   // resident workgroups per XCD (two-wave workgroups: twice as many)
+    // Many small items (a batch of pairs, or frames in flight on other streams: `inflight`) do not run in lockstep rounds: the
+    // launch behaves like a flow - work / slots plus half an item of tail - and the reduction hides under the next pair's
+    // filter.  Measured in round 5 on batches of 8 (profiles/r05/exp_plan_model.txt): against the rounds model 450 x 375
+    // 0.197 -> 0.178 ms per pair, 340 x 256 0.104 -> 0.097, 150 x 120 0.022 -> 0.016; two frames in flight 450 x 375 0.203 ->
+    // 0.188.  Single pairs and everything from 1280 x 720 up keep the rounds model (the flow model loses 1 - 7 % there: long
+    // uniform items do run in rounds).
+    const int conc = inflight > 1 ? inflight : 1;
+    const int model_knob = PSM_KNOB("PSM_PC_MODEL", 0);    // (experiment builds: 1 forces the flow model, 2 the rounds model)
+    const bool flow = model_knob ? model_knob == 1 : (sides * conc > 2 && (long)W * rows < 524288);
     auto cost_of = [&](int dc, int kk) -> long {
         const int nch = (Dloc + dc - 1) / dc;
+        if (flow) {
+            const double items = (double)sides * conc * pl.ngroups * kk * nch, len = dc * ((rows + kk - 1) / kk + 14) + 10.0;
+            double c = items * len / ((double)slots * dev.nxcd) + 0.5 * len;
+            if (planes && dc == 1) c *= 1.06;
+            return (long)(c * 16.0);
+        }
         const long per_xcd = ((long)sides * pl.ngroups * kk * nch + dev.nxcd - 1) / dev.nxcd;
         const long rounds2 = 2 * ((per_xcd + slots - 1) / slots) + 1;   // 2 x (rounds + 1/2)
         long c = rounds2 * dc * ((rows + kk - 1) / kk + 14) / 2 + (planes ? 2L * sides * nch : 0);
@@ -701,7 +729,7 @@ PcPlan pc_plan(int W, int rows, int Dloc, int seg_rows_opt, int form, int batch)
     pl.DC = bdc;
     pl.nchunks = (Dloc + bdc - 1) / bdc;
     pl.nbmax = (pl.seg_rows + 7 + 3) / 4;                            // consumer batches of a full segment
-    pl.rec_per_chunk = (size_t)pl.ngroups * pl.nsegs * pl.nbmax * PcLayout<1>::COLS;
+    pl.rec_per_chunk = (size_t)pl.ngroups * pl.nsegs * pl.nbmax * pl.cols;
     pl.rec_bytes = 20;                                               // 16 bytes of costs + 4 bytes of disparities
     return pl;
 }
@@ -767,7 +795,7 @@ void launch_chunk_min(hipStream_t s, March m, int W, int H, int Dloc, void *scra
     const unsigned *kdisp = (const unsigned *)(kcost + 4 * pl.rec_per_chunk * pl.nchunks);
     hipLaunchKernelGGL(k_chunk_min, dim3((unsigned)((pl.rec_per_chunk + 255) / 256)), dim3(256), 0, s, (const float4 *)kcost, (const unsigned *)kdisp,
                        pl.nchunks, pl.ngroups * pl.nsegs, pl.nbmax, pl.ngroups, pl.seg_rows, W, H, keys, map, (const float4 *)nullptr,
-                       (const unsigned *)nullptr, m.y0(H), m.y1(H), (const PcPair *)nullptr, 0);
+                       (const unsigned *)nullptr, m.y0(H), m.y1(H), (const PcPair *)nullptr, 0, pl.cols);
 }
 
 // Both volumes in one launch each (costs built on the fly): left volume = (g[0], other g[1].g1), right = (g[1], other g[0].g1).
@@ -778,38 +806,37 @@ void launch_cvf_select2(hipStream_t s, March m, const Guidance *g, int W, int H,
                         unsigned long long *ts, const uint8_t *const *p4, int sel, int step)
 {
     const bool tol = !p4 && (m.flags & PSM_FLAG_F32_TOL), fma = !p4 && (m.flags & PSM_FLAG_FMA_SOLVE);
-    const PcPlan pl = pc_plan(W, m.rows(H), Dloc, m.seg_rows, PC_PLANES | PC_BOTH);
+    const PcPlan pl = pc_plan(W, m.rows(H), Dloc, m.seg_rows, PC_PLANES | PC_BOTH, 1, m.inflight);
     const PcSel ps = {sel, step, pl.nxcd, 0, Dloc, 0};
     float *kcost0 = (float *)scratch;
     unsigned *kdisp0 = (unsigned *)(kcost0 + 4 * pl.rec_per_chunk * pl.nchunks);
     float *kcost1 = (float *)((char *)scratch + pl.scratch_bytes());
     unsigned *kdisp1 = (unsigned *)(kcost1 + 4 * pl.rec_per_chunk * pl.nchunks);
-    const dim3 grid(pc_blocks(pl, pl.nchunks), 2), blk(64 * (PcLayout<1>::NA + PcLayout<1>::NB));
+    const dim3 grid(pc_blocks(pl, pl.nchunks), 2), blk(pl.narrow ? 64 * (PcLayout<1, true>::NA + PcLayout<1, true>::NB) : 64 * (PcLayout<1>::NA + PcLayout<1>::NB));
     const PcSide s1 = {(const float4 *)g[1].g1, (const float4 *)g[1].g2, (const float4 *)g[1].g3, (const float2 *)g[1].g4, (const float4 *)g[0].g1, kcost1, kdisp1};
-    if (p4)
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_cvf_pc<false, 3, 1, true>), grid, blk, 0, s, (const float *)p4[0], (float *)const_cast<uint8_t *>(p4[1]),
-                           (const float4 *)g[0].g1, (const float4 *)g[0].g2, (const float4 *)g[0].g3, (const float2 *)g[0].g4, W, H, Dloc, pl.ngroups,
-                           pl.nsegs, pl.seg_rows, m.y0(H), m.y1(H), (const float4 *)g[1].g1, d_begin, pl.DC, kcost0, kdisp0, pl.nbmax, s1, ps, ts, (const PcPair *)nullptr);
-    else {
-#define PSM_LAUNCH_PC(VR)                                                                                                    \
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_cvf_pc<false, 3, 1, false, false, VR>), grid, blk, 0, s, (const float *)nullptr, (float *)nullptr, (const float4 *)g[0].g1, \
-                           (const float4 *)g[0].g2, (const float4 *)g[0].g3, (const float2 *)g[0].g4, W, H, Dloc, pl.ngroups, pl.nsegs, pl.seg_rows, m.y0(H), m.y1(H), \
-                           (const float4 *)g[1].g1, d_begin, pl.DC, kcost0, kdisp0, pl.nbmax, s1, ps, ts, (const PcPair *)nullptr)
-        if (fma) PSM_LAUNCH_PC(2); else if (tol) PSM_LAUNCH_PC(1); else PSM_LAUNCH_PC(0);
+#define PSM_LAUNCH_PC(U8V, VR, NW, A0, A1)                                                                                   \
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_cvf_pc<false, 3, 1, U8V, false, VR, NW>), grid, blk, 0, s, A0, A1, (const float4 *)g[0].g1, \
+                       (const float4 *)g[0].g2, (const float4 *)g[0].g3, (const float2 *)g[0].g4, W, H, Dloc, pl.ngroups, pl.nsegs, pl.seg_rows, m.y0(H), m.y1(H), \
+                       (const float4 *)g[1].g1, d_begin, pl.DC, kcost0, kdisp0, pl.nbmax, s1, ps, ts, (const PcPair *)nullptr)
+#define PSM_LAUNCH_PCN(U8V, VR, A0, A1) { if (pl.narrow) PSM_LAUNCH_PC(U8V, VR, true, A0, A1); else PSM_LAUNCH_PC(U8V, VR, false, A0, A1); }
+    if (p4) PSM_LAUNCH_PCN(true, 0, (const float *)p4[0], (float *)const_cast<uint8_t *>(p4[1]))
+    else if (fma) PSM_LAUNCH_PCN(false, 2, (const float *)nullptr, (float *)nullptr)
+    else if (tol) PSM_LAUNCH_PCN(false, 1, (const float *)nullptr, (float *)nullptr)
+    else PSM_LAUNCH_PCN(false, 0, (const float *)nullptr, (float *)nullptr)
+#undef PSM_LAUNCH_PCN
 #undef PSM_LAUNCH_PC
-    }
 }
 
 void launch_chunk_min2sides(hipStream_t s, March m, int W, int H, int Dloc, void *scratch, long long *keys, uint8_t *map)
 {
-    const PcPlan pl = pc_plan(W, m.rows(H), Dloc, m.seg_rows, PC_PLANES | PC_BOTH);
+    const PcPlan pl = pc_plan(W, m.rows(H), Dloc, m.seg_rows, PC_PLANES | PC_BOTH, 1, m.inflight);
     const float *kcost0 = (const float *)scratch;
     const unsigned *kdisp0 = (const unsigned *)(kcost0 + 4 * pl.rec_per_chunk * pl.nchunks);
     const float *kcost1 = (const float *)((const char *)scratch + pl.scratch_bytes());
     const unsigned *kdisp1 = (const unsigned *)(kcost1 + 4 * pl.rec_per_chunk * pl.nchunks);
     hipLaunchKernelGGL(k_chunk_min, dim3((unsigned)((pl.rec_per_chunk + 255) / 256), 2), dim3(256), 0, s, (const float4 *)kcost0, kdisp0,
                        pl.nchunks, pl.ngroups * pl.nsegs, pl.nbmax, pl.ngroups, pl.seg_rows, W, H, keys, map, (const float4 *)kcost1, kdisp1, m.y0(H), m.y1(H),
-                       (const PcPair *)nullptr, 0);
+                       (const PcPair *)nullptr, 0, pl.cols);
 }
 
 // ... key form (MODE 2): keys[2][H][W] receives the packed minima (init: start from key(+inf, 0); otherwise continue from what
@@ -817,25 +844,24 @@ void launch_chunk_min2sides(hipStream_t s, March m, int W, int H, int Dloc, void
 void launch_cvf_select_keys2(hipStream_t s, March m, const Guidance *g, int W, int H, int Dloc, int d_begin, long long *keys,
                              unsigned long long *ts, const uint8_t *const *p4, int init, int sel, int step)
 {
-    const PcPlan pl = pc_plan(W, m.rows(H), Dloc, m.seg_rows, PC_KEYS | PC_BOTH);
+    const PcPlan pl = pc_plan(W, m.rows(H), Dloc, m.seg_rows, PC_KEYS | PC_BOTH, 1, m.inflight);
     const PcSel ps = {sel, step, pl.nxcd, PSM_KNOB("PSM_PC_SPREAD", PC_KEY_SPREAD), Dloc, 0};
     const size_t HW = (size_t)W * H;
     if (init) hipLaunchKernelGGL(k_fill_keys, dim3((unsigned)((2 * HW + 255) / 256)), dim3(256), 0, s, keys, 2 * HW);
-    const dim3 grid(pc_blocks(pl, Dloc), 2), blk(64 * (PcLayout<2>::NA + PcLayout<2>::NB));
+    const dim3 grid(pc_blocks(pl, Dloc), 2), blk(pl.narrow ? 64 * (PcLayout<2, true>::NA + PcLayout<2, true>::NB) : 64 * (PcLayout<2>::NA + PcLayout<2>::NB));
     const PcSide s1 = {(const float4 *)g[1].g1, (const float4 *)g[1].g2, (const float4 *)g[1].g3, (const float2 *)g[1].g4, (const float4 *)g[0].g1,
                        (float *)(keys + HW), nullptr};
-    if (p4)
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_cvf_pc<false, 3, 2, true>), grid, blk, 0, s, (const float *)p4[0], (float *)const_cast<uint8_t *>(p4[1]),
-                           (const float4 *)g[0].g1, (const float4 *)g[0].g2, (const float4 *)g[0].g3, (const float2 *)g[0].g4, W, H, Dloc, pl.ngroups,
-                           pl.nsegs, pl.seg_rows, m.y0(H), m.y1(H), (const float4 *)g[1].g1, d_begin, 1, (float *)keys, (unsigned *)nullptr, 0, s1, ps, ts, (const PcPair *)nullptr);
-    else {
-#define PSM_LAUNCH_PC(VR)                                                                                                    \
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_cvf_pc<false, 3, 2, false, false, VR>), grid, blk, 0, s, (const float *)nullptr, (float *)nullptr, \
-                           (const float4 *)g[0].g1, (const float4 *)g[0].g2, (const float4 *)g[0].g3, (const float2 *)g[0].g4, W, H, Dloc, pl.ngroups, \
-                           pl.nsegs, pl.seg_rows, m.y0(H), m.y1(H), (const float4 *)g[1].g1, d_begin, 1, (float *)keys, (unsigned *)nullptr, 0, s1, ps, ts, (const PcPair *)nullptr)
-        if (m.flags & PSM_FLAG_FMA_SOLVE) PSM_LAUNCH_PC(2); else if (m.flags & PSM_FLAG_F32_TOL) PSM_LAUNCH_PC(1); else PSM_LAUNCH_PC(0);
+#define PSM_LAUNCH_PC(U8V, VR, NW, A0, A1)                                                                                   \
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_cvf_pc<false, 3, 2, U8V, false, VR, NW>), grid, blk, 0, s, A0, A1,                     \
+                       (const float4 *)g[0].g1, (const float4 *)g[0].g2, (const float4 *)g[0].g3, (const float2 *)g[0].g4, W, H, Dloc, pl.ngroups, \
+                       pl.nsegs, pl.seg_rows, m.y0(H), m.y1(H), (const float4 *)g[1].g1, d_begin, 1, (float *)keys, (unsigned *)nullptr, 0, s1, ps, ts, (const PcPair *)nullptr)
+#define PSM_LAUNCH_PCN(U8V, VR, A0, A1) { if (pl.narrow) PSM_LAUNCH_PC(U8V, VR, true, A0, A1); else PSM_LAUNCH_PC(U8V, VR, false, A0, A1); }
+    if (p4) PSM_LAUNCH_PCN(true, 0, (const float *)p4[0], (float *)const_cast<uint8_t *>(p4[1]))
+    else if (m.flags & PSM_FLAG_FMA_SOLVE) PSM_LAUNCH_PCN(false, 2, (const float *)nullptr, (float *)nullptr)
+    else if (m.flags & PSM_FLAG_F32_TOL) PSM_LAUNCH_PCN(false, 1, (const float *)nullptr, (float *)nullptr)
+    else PSM_LAUNCH_PCN(false, 0, (const float *)nullptr, (float *)nullptr)
+#undef PSM_LAUNCH_PCN
 #undef PSM_LAUNCH_PC
-    }
 }
 
 // ---- the same launches for `npairs` stereo pairs at once (psm_compute_batch): blockIdx.z = pair, pointers from the table ----
@@ -844,14 +870,16 @@ void launch_cvf_select2_batch(hipStream_t s, March m, const PcPair *tab, int npa
 {
     const PcPlan pl = pc_plan(W, m.rows(H), Dloc, m.seg_rows, PC_PLANES | PC_BOTH, npairs);
     const PcSel ps = {sel, step, pl.nxcd, 0, Dloc, (unsigned long long)pl.rec_per_chunk * pl.nchunks};
-    const dim3 grid(pc_blocks(pl, pl.nchunks), 2, npairs), blk(64 * (PcLayout<1>::NA + PcLayout<1>::NB));
-#define PSM_LAUNCH_PCB(U8V)                                                                                                   \
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_cvf_pc<false, 3, 1, U8V, true>), grid, blk, 0, s, (const float *)nullptr, (float *)nullptr,  \
+    const dim3 grid(pc_blocks(pl, pl.nchunks), 2, npairs), blk(pl.narrow ? 64 * (PcLayout<1, true>::NA + PcLayout<1, true>::NB) : 64 * (PcLayout<1>::NA + PcLayout<1>::NB));
+#define PSM_LAUNCH_PCB(U8V) { if (pl.narrow) PSM_LAUNCH_PCBN(U8V, true); else PSM_LAUNCH_PCBN(U8V, false); }
+#define PSM_LAUNCH_PCBN(U8V, NW)                                                                                              \
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_cvf_pc<false, 3, 1, U8V, true, 0, NW>), grid, blk, 0, s, (const float *)nullptr, (float *)nullptr,  \
                        (const float4 *)nullptr, (const float4 *)nullptr, (const float4 *)nullptr, (const float2 *)nullptr, W, H, Dloc, \
                        pl.ngroups, pl.nsegs, pl.seg_rows, m.y0(H), m.y1(H), (const float4 *)nullptr, d_begin, pl.DC, (float *)nullptr, \
                        (unsigned *)nullptr, pl.nbmax, PcSide{}, ps, ts, tab)
-    if (u8) PSM_LAUNCH_PCB(true); else PSM_LAUNCH_PCB(false);
+    if (u8) PSM_LAUNCH_PCB(true) else PSM_LAUNCH_PCB(false)
 #undef PSM_LAUNCH_PCB
+#undef PSM_LAUNCH_PCBN
 }
 
 void launch_chunk_min2sides_batch(hipStream_t s, March m, const PcPair *tab, int npairs, int W, int H, int Dloc, bool to_maps)
@@ -859,7 +887,7 @@ void launch_chunk_min2sides_batch(hipStream_t s, March m, const PcPair *tab, int
     const PcPlan pl = pc_plan(W, m.rows(H), Dloc, m.seg_rows, PC_PLANES | PC_BOTH, npairs);
     hipLaunchKernelGGL(k_chunk_min, dim3((unsigned)((pl.rec_per_chunk + 255) / 256), 2, npairs), dim3(256), 0, s, (const float4 *)nullptr,
                        (const unsigned *)nullptr, pl.nchunks, pl.ngroups * pl.nsegs, pl.nbmax, pl.ngroups, pl.seg_rows, W, H, (long long *)nullptr,
-                       (uint8_t *)nullptr, (const float4 *)nullptr, (const unsigned *)nullptr, m.y0(H), m.y1(H), tab, to_maps ? 1 : 0);
+                       (uint8_t *)nullptr, (const float4 *)nullptr, (const unsigned *)nullptr, m.y0(H), m.y1(H), tab, to_maps ? 1 : 0, pl.cols);
 }
 
 void launch_cvf_select_keys2_batch(hipStream_t s, March m, const PcPair *tab, int npairs, int W, int H, int Dloc, int d_begin,
@@ -867,14 +895,16 @@ void launch_cvf_select_keys2_batch(hipStream_t s, March m, const PcPair *tab, in
 {
     const PcPlan pl = pc_plan(W, m.rows(H), Dloc, m.seg_rows, PC_KEYS | PC_BOTH, npairs);
     const PcSel ps = {sel, step, pl.nxcd, PC_KEY_SPREAD, Dloc, 0};
-    const dim3 grid(pc_blocks(pl, Dloc), 2, npairs), blk(64 * (PcLayout<2>::NA + PcLayout<2>::NB));
-#define PSM_LAUNCH_PCB(U8V)                                                                                                   \
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_cvf_pc<false, 3, 2, U8V, true>), grid, blk, 0, s, (const float *)nullptr, (float *)nullptr,  \
+    const dim3 grid(pc_blocks(pl, Dloc), 2, npairs), blk(pl.narrow ? 64 * (PcLayout<2, true>::NA + PcLayout<2, true>::NB) : 64 * (PcLayout<2>::NA + PcLayout<2>::NB));
+#define PSM_LAUNCH_PCB(U8V) { if (pl.narrow) PSM_LAUNCH_PCBN(U8V, true); else PSM_LAUNCH_PCBN(U8V, false); }
+#define PSM_LAUNCH_PCBN(U8V, NW)                                                                                              \
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_cvf_pc<false, 3, 2, U8V, true, 0, NW>), grid, blk, 0, s, (const float *)nullptr, (float *)nullptr,  \
                        (const float4 *)nullptr, (const float4 *)nullptr, (const float4 *)nullptr, (const float2 *)nullptr, W, H, Dloc, \
                        pl.ngroups, pl.nsegs, pl.seg_rows, m.y0(H), m.y1(H), (const float4 *)nullptr, d_begin, 1, (float *)nullptr,      \
                        (unsigned *)nullptr, 0, PcSide{}, ps, ts, tab)
-    if (u8) PSM_LAUNCH_PCB(true); else PSM_LAUNCH_PCB(false);
+    if (u8) PSM_LAUNCH_PCB(true) else PSM_LAUNCH_PCB(false)
 #undef PSM_LAUNCH_PCB
+#undef PSM_LAUNCH_PCBN
 }
 
 }  // namespace psm

@@ -50,6 +50,7 @@ class DispEst:
         self._lib = capi.load()
         self._dtype = capi.PSM_U8 if dtype == "u8" else capi.PSM_F32
         self._h = C.c_void_p()
+        self.options = {}
         d0, d1 = (0, self.maxDis) if d_range is None else (int(d_range[0]), int(d_range[1]))
         self.d_begin, self.d_end = d0, d1
         rc = self._lib.psm_create_shard(C.byref(self._h), self.wid, self.hei, self.maxDis, d0, d1,
@@ -172,6 +173,7 @@ class DispEst:
 
     def set_option(self, option: int, value: int):
         self._ck(self._lib.psm_set_option(self._h, int(option), int(value)), "set_option")
+        self.options[int(option)] = int(value)           # (what was accepted, for callers that inspect a context)
 
     def set_stream(self, stream_ptr: int | None):
         self._ck(self._lib.psm_set_stream(self._h, C.c_void_p(stream_ptr or 0)), "set_stream")
@@ -370,6 +372,7 @@ class FrameRing:
         self.ctx = [DispEst(l, r, d, dtype=dtype, device=device) for _ in range(frames)]
         for c in self.ctx:
             c.set_option(capi.PSM_OPT_ASYNC, 1)
+            c.set_option(capi.PSM_OPT_FRAMES_IN_FLIGHT, frames)      # the planner cuts the launches for `frames` pairs at a time
             if seg_rows > 0:
                 c.set_option(capi.PSM_OPT_SEG_ROWS, int(seg_rows))
         self._n = 0

@@ -11,14 +11,19 @@ import primestereomatch_amd as P
 from primestereomatch_amd import capi, synth
 
 
-def run(W, H, D, l, r, d0, d1, y0, y1, env, seg, F, steps=40, dtype="f32"):
-    for k in ("PSM_PC_ORDER", "PSM_PC_DC", "PSM_PC_SLOTS", "PSM_PC_S", "PSM_PC_SPREAD"):
+def run(W, H, D, l, r, d0, d1, y0, y1, env, seg, F, steps=40, dtype="f32", hint=True):
+    for k in ("PSM_PC_ORDER", "PSM_PC_DC", "PSM_PC_SLOTS", "PSM_PC_S", "PSM_PC_SPREAD", "PSM_PC_NARROW", "PSM_PC_MODEL", "PSM_PC_KDIV", "PSM_PC_DC1PEN", "PSM_PC_CONC"):
         os.environ.pop(k, None)
     os.environ.update({k: str(v) for k, v in env.items()})
     ctxs = []
     for _ in range(F):
         de = P.DispEst(l, r, D, 8, True, d_range=(d0, d1), dtype=dtype)
         de.set_option(capi.PSM_OPT_ASYNC, 1)
+        if F > 1 and hint and hasattr(capi, "PSM_OPT_FRAMES_IN_FLIGHT"):
+            try:
+                de.set_option(capi.PSM_OPT_FRAMES_IN_FLIGHT, F)
+            except capi.PsmError:
+                pass                                     # (an older library in an A/B run)
         if seg:
             de.set_option(capi.PSM_OPT_SEG_ROWS, seg)
         if y1 > y0:
