@@ -5,7 +5,7 @@ TAG=${1:-r05}
 S=gpurun_out/$TAG
 D=profiles/$TAG
 mkdir -p $D
-cp $S/bench_*.json $S/device.txt $S/smoke.log $S/trace_gaps_c4.txt $S/trace_gaps_shard8.txt $S/wmf_timing.txt $S/soak.txt $S/pytest_gpu_reports.txt $D/ 2>/dev/null
+cp $S/bench_*.json $S/device.txt $S/device_small.txt $S/smoke.log $S/trace_gaps_c4.txt $S/trace_gaps_shard8.txt $S/wmf_timing.txt $S/soak.txt $S/pytest_gpu_reports.txt $D/ 2>/dev/null
 tail -4 $S/pytest_gpu.log > $D/pytest_gpu_tail.txt
 cp $(find $S/prof -name "*kernel_stats.csv" | head -1) $D/rocprofv3_kernel_stats_bench_c4.csv
 cp $(find $S/prof_s8 -name "*kernel_stats.csv" | head -1) $D/rocprofv3_kernel_stats_bench_c4_shardsim8.csv

@@ -26,10 +26,12 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "primestereomatch_amd", "csrc", "psm_pc.hip")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
          "-fhip-fp32-correctly-rounded-divide-sqrt", "-fno-slp-vectorize"]
-# template arguments <VEC4, CVC, MODE, U8, BATCH, VAR>
-KERNELS = {"planes_f32": "k_cvf_pcILb0ELi3ELi1ELb0ELb0ELi0EEE", "keys_f32": "k_cvf_pcILb0ELi3ELi2ELb0ELb0ELi0EEE",
-           "planes_u8": "k_cvf_pcILb0ELi3ELi1ELb1ELb0ELi0EEE", "keys_u8": "k_cvf_pcILb0ELi3ELi2ELb1ELb0ELi0EEE",
-           "planes_f32_fma": "k_cvf_pcILb0ELi3ELi1ELb0ELb0ELi2EEE", "keys_f32_fma": "k_cvf_pcILb0ELi3ELi2ELb0ELb0ELi2EEE"}
+# template arguments <VEC4, CVC, MODE, U8, BATCH, VAR, NARROW>
+KERNELS = {"planes_f32": "k_cvf_pcILb0ELi3ELi1ELb0ELb0ELi0ELb0EEE", "keys_f32": "k_cvf_pcILb0ELi3ELi2ELb0ELb0ELi0ELb0EEE",
+           "planes_u8": "k_cvf_pcILb0ELi3ELi1ELb1ELb0ELi0ELb0EEE", "keys_u8": "k_cvf_pcILb0ELi3ELi2ELb1ELb0ELi0ELb0EEE",
+           "planes_f32_fma": "k_cvf_pcILb0ELi3ELi1ELb0ELb0ELi2ELb0EEE", "keys_f32_fma": "k_cvf_pcILb0ELi3ELi2ELb0ELb0ELi2ELb0EEE",
+           "planes_f32_narrow": "k_cvf_pcILb0ELi3ELi1ELb0ELb0ELi0ELb1EEE", "keys_f32_narrow": "k_cvf_pcILb0ELi3ELi2ELb0ELb0ELi0ELb1EEE",
+           "planes_u8_narrow": "k_cvf_pcILb0ELi3ELi1ELb1ELb0ELi0ELb1EEE", "keys_u8_narrow": "k_cvf_pcILb0ELi3ELi2ELb1ELb0ELi0ELb1EEE"}
 
 
 def classify(op, rest):

@@ -34,7 +34,11 @@ def fabric_bytes(d, pre, kernel):
 
 def main():
     d, tag = sys.argv[1], sys.argv[2]
-    session = open(os.path.join(d, "device.txt")).read().strip().replace("\n", "; ") if os.path.exists(os.path.join(d, "device.txt")) else "?"
+    session = "?"
+    for name in ("device.txt", "device_small.txt"):          # (device_small.txt: a partial session, scripts/gpu_round_small.sh)
+        if os.path.exists(os.path.join(d, name)):
+            session = open(os.path.join(d, name)).read().strip().replace("\n", "; ")
+            break
     mixf = os.path.join(ROOT, "profiles", tag, "isa_mix.json")
     if not os.path.exists(mixf):              # (scripts/isa_mix.py of this round not run yet: the latest committed mix)
         have = sorted(t for t in os.listdir(os.path.join(ROOT, "profiles")) if os.path.exists(os.path.join(ROOT, "profiles", t, "isa_mix.json")))
@@ -58,8 +62,8 @@ def main():
         prev = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
     for cfg, dt, pre in cases:
         u8 = "true" if dt == "u8" else "false"
-        # (the last template argument was a bool before round 5's VAR: both spellings)
-        ks = {"planes": rf"k_cvf_pc<false, 3, 1, {u8}, false, (false|0)>", "keys": rf"k_cvf_pc<false, 3, 2, {u8}, false, (false|0)>"}
+        # (the sixth template argument was a bool before round 5's VAR, and round 5 added the layout argument NARROW: all spellings)
+        ks = {"planes": rf"k_cvf_pc<false, 3, 1, {u8}, false, (false|0)(, (false|true))?>", "keys": rf"k_cvf_pc<false, 3, 2, {u8}, false, (false|0)(, (false|true))?>"}
         key = f"{cfg}:{dt}:k_cvf_fused"
         try:
             parts, insts = {}, {}
