@@ -352,8 +352,8 @@ class FrameRing:
     contexts of one geometry, each on its own stream, take the frames of a stream in turn.  While frame i runs, frame i + 1 is
     already queued behind it on another stream, so a frame's short kernels (image preparation, guidance, reduction, merge) and the
     half-empty last round of its fused launch run beside the next frame's fused kernel instead of alone.  Results are those of
-    the single-context calls, bit for bit (every context is an ordinary DispEst).  Measured on MI355X (profiles/r05): -9 % per
-    frame at 1280 x 720 x 128, -19 % at 450 x 375 x 64, nothing at 1920 x 1080 x 256 (there the fused launches fill the chip).
+    the single-context calls, bit for bit (every context is an ordinary DispEst).  Measured on MI355X (profiles/r05): -13 % per
+    frame at 1280 x 720 x 128, -24 % at 450 x 375 x 64, nothing at 1920 x 1080 x 256 (there the fused launches fill the chip).
 
         ring = FrameRing(l0, r0, maxDis, frames=2)
         for l, r in stream:
@@ -363,10 +363,10 @@ class FrameRing:
 
     def __init__(self, l, r, d: int, frames: int = 2, *, dtype: str = "f32", device: int = 0, lr_check: bool = False,
                  seg_rows: int = 0):
-        """seg_rows > 0: PSM_OPT_SEG_ROWS of every context.  The planner's cost model assumes a launch runs alone (its last, half-empty
-        round of workgroups costs half a round); with a second frame filling that tail a Middlebury-size launch is best served by
-        ONE segment (seg_rows = image height: least halo) - measured -4 ... -7 % at 450 x 375 x 64 and 384 x 288 x 64, nothing at
-        1280 x 720 x 128 and above (profiles/r05/exp_segments_with_frames_in_flight.txt)."""
+        """Every context is told PSM_OPT_FRAMES_IN_FLIGHT = frames: the planner of the fused launches then cuts them for a shared
+        device (450 x 375 x 64: 0.207 ms per frame against 0.22-0.23 without the hint; no result changes).  seg_rows > 0:
+        PSM_OPT_SEG_ROWS of every context on top of that (round 5's first finding - one segment per launch, seg_rows = image height
+        - is what the hint replaced: profiles/r05/exp_plan_model.txt)."""
         if frames < 1:
             raise ValueError("FrameRing: frames must be >= 1")
         self.ctx = [DispEst(l, r, d, dtype=dtype, device=device) for _ in range(frames)]

@@ -93,7 +93,7 @@ public:
     static int computeBatch(DispEst *const *des, int n);
 
     // psm_set_option on every device's context (PSM_OPT_FLAGS: e.g. PSM_FLAG_FMA_SOLVE - the maps of a reference binary built for an
-    // FMA target -, PSM_OPT_SEG_ROWS, PSM_OPT_GATHER_STAGED ...; include/primesm_hip.h).  0 = ok.
+    // FMA target -, PSM_OPT_SEG_ROWS, PSM_OPT_GATHER_STAGED, PSM_OPT_FRAMES_IN_FLIGHT ...; include/primesm_hip.h).  0 = ok.
     int setOption(int option, int value);
 
     bool ok() const { return !ctx.empty(); }

@@ -61,8 +61,8 @@ $B --config c1x --pair fixture --steps 30 --verify --no-cpu-wide > $OUT/bench_c1
 for cfg in c3 c2 c1 c1x; do $B --config $cfg --frames-in-flight 2 --steps 40 --verify --no-cpu-wide > $OUT/bench_${cfg}_fif2.json 2>> $OUT/bench_var.err; done
 $B --config c2 --pair fixture --frames-in-flight 2 --steps 40 --verify --no-cpu-wide > $OUT/bench_c2_teddy_fif2.json 2>> $OUT/bench_var.err
 $B --config c1 --pair fixture --frames-in-flight 2 --steps 40 --verify --no-cpu-wide > $OUT/bench_c1_cones_u8_fif2.json 2>> $OUT/bench_var.err
-# (with a second frame filling its tail a small launch wants ONE segment - least halo - which the planner, whose cost model assumes the
-#  launch runs alone, does not pick: profiles/r05/exp_segments_with_frames_in_flight.txt)
+# (ONE segment per launch was the round's first answer for a small launch with a second frame filling its tail; the ring's contexts now
+#  carry PSM_OPT_FRAMES_IN_FLIGHT and the planner's own cut is the faster one - these lines stay as the comparison)
 $B --config c2 --pair fixture --frames-in-flight 2 --seg-rows 375 --steps 40 --verify --no-cpu-wide > $OUT/bench_c2_teddy_fif2_seg375.json 2>> $OUT/bench_var.err
 $B --config c1 --pair fixture --frames-in-flight 2 --seg-rows 375 --steps 40 --verify --no-cpu-wide > $OUT/bench_c1_cones_u8_fif2_seg375.json 2>> $OUT/bench_var.err
 $B --config c1x --pair fixture --frames-in-flight 2 --seg-rows 288 --steps 40 --verify --no-cpu-wide > $OUT/bench_c1x_cones_u8_fif2_seg288.json 2>> $OUT/bench_var.err
