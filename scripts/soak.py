@@ -25,7 +25,8 @@ FMA_SOLVE = 67108864
 
 
 def one(rng, idx):
-    W = int(rng.choice([8, 9, 57, 96, 107, 108, 114, 128, 213, 214, 215, 300])) if rng.random() < 0.5 else int(rng.integers(8, 340))
+    # (widths around the layout boundaries of pc_plan: narrow layout for 1-50, 108-150, 215-250, 322-350, 429-450)
+    W = int(rng.choice([8, 9, 49, 50, 51, 57, 96, 107, 108, 114, 128, 149, 150, 151, 213, 214, 215, 250, 251, 300, 321, 322, 350, 351, 428, 429, 450])) if rng.random() < 0.5 else int(rng.integers(8, 460))
     H = int(rng.choice([8, 9, 11, 12, 15, 16, 17, 31, 33, 63, 64, 65, 71])) if rng.random() < 0.5 else int(rng.integers(8, 100))
     D = int(rng.integers(1, min(W, 256) + 1)) if rng.random() < 0.2 else int(rng.integers(1, min(W, 40) + 1))
     dtype = "u8" if rng.random() < 0.25 else "f32"
@@ -45,10 +46,13 @@ def one(rng, idx):
             ref = O.pipeline_f32(l, r, D, threads=8, want_volumes=(D <= 24))
     else:
         ref = (O.pipeline_u8 if dtype == "u8" else O.pipeline_f32)(l, r, D, threads=8, want_volumes=(dtype == "f32" and D <= 24))
-    desc = f"case {idx}: {W}x{H} D={D} {dtype} flags={flags} seg={seg} mode={mode}"
+    inflight = int(rng.integers(2, 5)) if rng.random() < 0.25 else 1     # the planner's hint: another cut of the launches, same bits
+    desc = f"case {idx}: {W}x{H} D={D} {dtype} flags={flags} seg={seg} mode={mode} inflight={inflight}"
 
     def setup(c):
         c.set_option(capi.PSM_OPT_FLAGS, flags)
+        if inflight > 1:
+            c.set_option(capi.PSM_OPT_FRAMES_IN_FLIGHT, inflight)
         if seg > 0:
             c.set_option(capi.PSM_OPT_SEG_ROWS, seg)
 
@@ -142,6 +146,8 @@ def one(rng, idx):
         try:
             for s in shards:
                 s.set_option(capi.PSM_OPT_FLAGS, flags)
+                if inflight > 1:
+                    s.set_option(capi.PSM_OPT_FRAMES_IN_FLIGHT, inflight)
                 if seg > 0:
                     s.set_option(capi.PSM_OPT_SEG_ROWS, seg)
                 if len(ycuts) > 2:
