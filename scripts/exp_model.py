@@ -1,5 +1,10 @@
 """Round-5 experiment (experiment build): the planner's cost model - rounds of resident workgroups (the product's) against a flow
-model (work / slots + half an item) - over single pairs, two frames in flight and batches; and dc = 1 in batches."""
+model (work / slots + half an item) - over single pairs, two frames in flight and batches; and dc = 1 in batches.
+
+Kept as the record of what produced profiles/r05/exp_plan_model.txt: PSM_PC_MODEL = 3 (a rounds / flow blend), PSM_PC_CONC (pairs in
+flight, now the product option PSM_OPT_FRAMES_IN_FLIGHT) and PSM_PC_DC1PEN were knobs of that session's experiment build only; today's
+`make exp` knows PSM_PC_MODEL 1 (flow) / 2 (rounds), PSM_PC_KDIV, PSM_PC_NARROW, PSM_PC_DC - the other settings fall back to the
+product's rule."""
 import os, sys, time
 sys.path.insert(0, '.'); sys.path.insert(0, 'scripts')
 import exp_plan
