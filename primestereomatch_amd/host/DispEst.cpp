@@ -3,6 +3,7 @@
 #include <cassert>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 
 namespace psm {
 
@@ -202,6 +203,79 @@ double DispEst::stageTimeUs(int stage) const
     double us = 0;
     if (!ctx.empty()) hipUtil::api().stage_time_us(ctx[0], stage, &us);
     return us;
+}
+
+// ---- FrameRing ----
+FrameRing::FrameRing(Mat l, Mat r, int d, int frames, int dtype)
+{
+    if (frames < 1) return;
+    for (int i = 0; i < frames; ++i) {
+        DispEst *de = new DispEst(l, r, d, MAX_CPU_THREADS, true, 1, dtype);
+        if (!de->ok() || de->setOption(PSM_OPT_ASYNC, 1) || de->setOption(PSM_OPT_FRAMES_IN_FLIGHT, frames)) {
+            delete de;
+            for (DispEst *o : ring) delete o;
+            ring.clear();
+            return;
+        }
+        ring.push_back(de);
+    }
+    busy.assign(frames, 0);
+}
+
+FrameRing::~FrameRing()
+{
+    for (DispEst *o : ring) delete o;
+}
+
+int FrameRing::setOption(int option, int value)
+{
+    int rc = 0;
+    for (DispEst *o : ring) rc |= o->setOption(option, value);
+    return rc;
+}
+
+int FrameRing::deliver(int i, Mat *outL, Mat *outR)
+{   // the maps of object i's last frame have been on their way since its push: wait for them, hand them over
+    DispEst *de = ring[i];
+    if (hipUtil::api().download_maps_wait(de->ctx[0], de->lDisMap.data, de->rDisMap.data, de->lDisMap.step)) return -1;
+    busy[i] = 0;
+    const size_t row = (size_t)de->wid;
+    for (int y = 0; y < de->hei; ++y) {
+        if (outL && outL->data) memcpy(outL->ptr<unsigned char>(y), de->lDisMap.ptr<unsigned char>(y), row);
+        if (outR && outR->data) memcpy(outR->ptr<unsigned char>(y), de->rDisMap.ptr<unsigned char>(y), row);
+    }
+    return 1;
+}
+
+int FrameRing::push(const Mat &l, const Mat &r, Mat *outL, Mat *outR)
+{
+    if (ring.empty()) return -1;
+    const HipApi &api = hipUtil::api();
+    const int i = (int)(pushed % (long long)ring.size());
+    int got = 0;
+    if (busy[i]) {
+        got = deliver(i, outL, outR);
+        if (got < 0) return got;
+        ++flushed;
+    }
+    DispEst *de = ring[i];
+    psm_ctx *c = de->ctx[0];
+    if (api.upload_pair_async(c, l.data, r.data, l.channels, l.step, l.depth == PSM_32F ? PSM_IMG_F32 : PSM_IMG_U8)) return -1;
+    if (api.cost_construct(c) || api.cost_filter(c) || api.disp_select(c, nullptr, nullptr, 0) || api.download_maps_async(c)) return -1;
+    busy[i] = 1;
+    ++pushed;
+    return got;
+}
+
+int FrameRing::flush(Mat *outL, Mat *outR)
+{
+    if (ring.empty()) return -1;
+    while (flushed < pushed) {
+        const int i = (int)(flushed % (long long)ring.size());
+        ++flushed;
+        if (busy[i]) return deliver(i, outL, outR);
+    }
+    return 0;
 }
 
 }  // namespace psm

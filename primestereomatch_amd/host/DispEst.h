@@ -100,6 +100,7 @@ public:
     double stageTimeUs(int stage) const;
 
 private:
+    friend class FrameRing;
     Mat lImg, rImg;
     int hei, wid, maxDis, threads;
     bool useOCL;
@@ -107,6 +108,31 @@ private:
     std::vector<psm_ctx *> ctx;  // one per device (row stripes of ceil(H / ndev) rows)
     std::vector<int> y0s, y1s;   // their stripes
     bool whole_on_first = false; // the last filter ran on ctx[0] over the whole image (Fast Guided Filter path: no stripes)
+};
+
+// The frame loop of src/main.cpp:64-73 (one compute() per frame) with `frames` frames in the device's queues: that many DispEst
+// objects of one geometry, each with its own streams, take the frames of a stream in turn, so a frame's short launches and the
+// half-empty tail of its fused launch run beside the next frame's fused kernel (the Python
+// form is primestereomatch_amd.FrameRing).  Every object is told PSM_OPT_FRAMES_IN_FLIGHT = frames.  The maps are those of the
+// single-object calls, bit for bit.  Single-device objects only.
+class FrameRing {
+public:
+    FrameRing(Mat l, Mat r, int d, int frames = 2, int dtype = PSM_F32);
+    ~FrameRing();
+    bool ok() const { return !ring.empty(); }
+    int frames() const { return (int)ring.size(); }
+    // Queues the pair (l, r).  Once the ring is full this first hands over the maps of the frame pushed frames() calls earlier:
+    // outL / outR (H x W, 8-bit, may be NULL to drop them) are filled and 1 is returned; 0 = no maps yet; < 0 = a device call failed.
+    int push(const Mat &l, const Mat &r, Mat *outL, Mat *outR);
+    // The frames still in flight, oldest first, one per call: 1 = maps delivered, 0 = none left, < 0 = error.
+    int flush(Mat *outL, Mat *outR);
+    int setOption(int option, int value);      // on every object of the ring
+
+private:
+    int deliver(int i, Mat *outL, Mat *outR);
+    std::vector<DispEst *> ring;
+    std::vector<char> busy;
+    long long pushed = 0, flushed = 0;
 };
 
 }  // namespace psm

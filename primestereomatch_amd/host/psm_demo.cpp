@@ -1,6 +1,8 @@
 // psm_demo - headless counterpart of the reference's StereoMatch::compute accelerator branch
 // (src/StereoMatch.cpp:193-262): raw B,G,R uint8 pair in, four timed stages, raw uint8 maps out.
-//   psm_demo <left.raw> <right.raw> <W> <H> <maxDis> <out_prefix> [ndev] [f32|u8] [float_input] [fgf_rate] [pp] [frames] [batch]
+//   psm_demo <left.raw> <right.raw> <W> <H> <maxDis> <out_prefix> [ndev] [f32|u8] [float_input] [fgf_rate] [pp] [frames] [batch] [ring]
+// ring > 0: additionally push that many frames of the pair through a psm::FrameRing of two objects (two frames in flight, each
+// object told PSM_OPT_FRAMES_IN_FLIGHT = 2), check every delivered frame's maps against the single-pair run, dump <out>_ldisp_ring.raw
 // batch > 1: additionally run that many copies of the pair as ONE batch (DispEst::computeBatch -> psm_compute_batch: the
 // reference's loop over pairs as shared launches), check every copy's maps against the single-pair run, dump <out>_ldisp_batch.raw
 // frames > 0: additionally run that many frames of the pair through DispEst::computeFrame (asynchronous upload of the next
@@ -38,7 +40,7 @@ static bool dump(const std::string &path, const unsigned char *p, size_t n)
 int main(int argc, char **argv)
 {
     if (argc < 7) {
-        fprintf(stderr, "usage: %s left.raw right.raw W H maxDis out_prefix [ndev] [f32|u8] [float_input] [fgf_rate] [pp] [frames] [batch]\n", argv[0]);
+        fprintf(stderr, "usage: %s left.raw right.raw W H maxDis out_prefix [ndev] [f32|u8] [float_input] [fgf_rate] [pp] [frames] [batch] [ring]\n", argv[0]);
         return 2;
     }
     const int W = atoi(argv[3]), H = atoi(argv[4]), D = atoi(argv[5]);
@@ -50,6 +52,7 @@ int main(int argc, char **argv)
     const bool pp = argc > 11 && atoi(argv[11]) != 0;
     const int frames = argc > 12 ? atoi(argv[12]) : 0;
     const int batch = argc > 13 ? atoi(argv[13]) : 0;
+    const int nring = argc > 14 ? atoi(argv[14]) : 0;
     std::vector<unsigned char> lraw, rraw;
     if (!slurp(argv[1], lraw, (size_t)W * H * 3) || !slurp(argv[2], rraw, (size_t)W * H * 3)) {
         fprintf(stderr, "psm_demo: cannot read the input pair\n");
@@ -118,6 +121,28 @@ int main(int argc, char **argv)
         printf("Batch:\t %d pairs in one set of launches, %4.3f ms (first call, maps downloaded), maps %s\n", batch, ms, same ? "equal the single-pair run's" : "DIFFER");
         ok = same && dump(out + "_ldisp_batch.raw", des[batch - 1]->lDisMap.data, (size_t)W * H) && dump(out + "_rdisp_batch.raw", des[batch - 1]->rDisMap.data, (size_t)W * H);
         for (auto *d : des) delete d;
+    }
+    if (ok && nring > 0 && ndev == 1 && !fgf_rate && !pp) {
+        std::vector<uint8_t> kl(SMDE.lDisMap.data, SMDE.lDisMap.data + (size_t)W * H), kr(SMDE.rDisMap.data, SMDE.rDisMap.data + (size_t)W * H);
+        psm::FrameRing ring(l, r, D, 2, dtype);
+        if (!ring.ok()) return 5;
+        psm::Mat ol = psm::Mat::zeros(H, W, 1, psm::PSM_8U), orr = psm::Mat::zeros(H, W, 1, psm::PSM_8U);
+        int delivered = 0;
+        bool same = true;
+        const auto t0 = std::chrono::steady_clock::now();
+        for (int i = 0; i < nring + 2 && same; ++i) {
+            const int got = i < nring ? ring.push(l, r, &ol, &orr) : ring.flush(&ol, &orr);
+            if (got < 0) return 5;
+            if (got == 1) {
+                ++delivered;
+                same = !memcmp(ol.data, kl.data(), (size_t)W * H) && !memcmp(orr.data, kr.data(), (size_t)W * H);
+            }
+        }
+        const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        same = same && delivered == nring && ring.flush(&ol, &orr) == 0;
+        printf("Frame ring:\t %d frames through 2 objects, %4.3f ms per frame (H2D and D2H of every frame included), %d delivered, maps %s\n", nring,
+               ms / nring, delivered, same ? "equal the single-pair run's" : "DIFFER");
+        ok = same && dump(out + "_ldisp_ring.raw", ol.data, (size_t)W * H) && dump(out + "_rdisp_ring.raw", orr.data, (size_t)W * H);
     }
     return ok ? 0 : 6;
 }

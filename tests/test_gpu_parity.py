@@ -482,6 +482,31 @@ def test_cpp_dispest_demo(psm, oracle, golden, tmp_path, mode, float_input):
     assert np.array_equal(lb, gold[key[0]]) and np.array_equal(rb, gold[key[1]])
 
 
+@pytest.mark.parametrize("mode", ["f32", "u8"])
+def test_cpp_frame_ring_demo(psm, golden, tmp_path, mode):
+    """psm::FrameRing (host/DispEst.h): the reference's frame loop (src/main.cpp:64-73) with two frames in flight - two DispEst
+    objects, each told PSM_OPT_FRAMES_IN_FLIGHT = 2, take the frames in turn; every delivered frame's maps are the single-object
+    maps (checked inside the demo) and the committed goldens (checked here)."""
+    import subprocess
+    from conftest import ROOT
+    demo = os.path.join(ROOT, "primestereomatch_amd", "lib", "psm_demo")
+    if not os.path.exists(demo):
+        subprocess.run(["make", "-C", os.path.join(ROOT, "primestereomatch_amd", "host")], check=True)
+    pair, gold = golden("cones_pair.npz"), golden("cones_oracle_d64.npz")
+    H, W, _ = pair["l_bgr"].shape
+    pair["l_bgr"].tofile(tmp_path / "l.raw")
+    pair["r_bgr"].tofile(tmp_path / "r.raw")
+    env = dict(os.environ, PRIMESM_HIP_LIB=psm.capi.LIB_PATH)
+    p = subprocess.run([demo, str(tmp_path / "l.raw"), str(tmp_path / "r.raw"), str(W), str(H), "64",
+                        str(tmp_path / "o"), "1", mode, "0", "0", "0", "0", "0", "7"], env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr + p.stdout
+    assert "Frame ring" in p.stdout and "7 delivered" in p.stdout and "equal the single-pair run" in p.stdout
+    key = ("ldisp", "rdisp") if mode == "f32" else ("ldisp_u8mode", "rdisp_u8mode")
+    lr = np.fromfile(tmp_path / "o_ldisp_ring.raw", np.uint8).reshape(H, W)
+    rr = np.fromfile(tmp_path / "o_rdisp_ring.raw", np.uint8).reshape(H, W)
+    assert np.array_equal(lr, gold[key[0]]) and np.array_equal(rr, gold[key[1]])
+
+
 @pytest.mark.parametrize("flags", [0, 128, 4096, 8192, 8192 + 128, 1048576, 1048576 + 128, 2097152])
 def test_tuning_flags_do_not_change_results(psm, oracle, flags):
     """PSM_OPT_FLAGS picks which volumes are materialised and which select form runs - never a result."""
