@@ -10,8 +10,8 @@ import pytest
 pytestmark = pytest.mark.gpu
 TWO_ON, STORE = 1048576, 8192
 # widths at the edges of the ranges where 2 * ceil(W / 50) < 4 * ceil(W / 107) (narrow), and their wide neighbours
-NARROW_W = [16, 49, 50, 108, 149, 150, 215, 250, 322, 350, 429, 450, 536, 550, 643]
-WIDE_W = [51, 107, 151, 214, 251, 321, 351, 428, 451]
+NARROW_W = [16, 49, 50, 108, 149, 150, 215, 250, 322, 350, 429, 450, 536, 550, 643, 650, 750]
+WIDE_W = [51, 107, 151, 214, 251, 321, 351, 428, 451, 642, 749, 751]
 
 
 @pytest.fixture(scope="module")
