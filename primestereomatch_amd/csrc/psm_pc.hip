@@ -667,6 +667,8 @@ PcDev pc_dev()
 // workgroups (key form: x 4).  Cost model, fitted to measurements at 1080p (DC = 1, 2, 4, 8, 16: 4.39, 4.41, 4.46, 4.71,
 // 4.99 ms for kernel + reduction): (rounds + 1/2) x rows walked per workgroup - the last round is on average half empty,
 // which is what makes long-running workgroups (large DC) expensive - plus two row-steps per chunk plane for the reduction.
+// Round 5 added the choice of the column-group layout (wide / narrow) and, for several small pairs at a time, a flow model
+// in place of the rounds (both below).
 PcPlan pc_plan(int W, int rows, int Dloc, int seg_rows_opt, int form, int batch, int inflight)
 {   // form: PC_STORE; PC_PLANES (select with chunk planes) / PC_KEYS (select against a shared key plane, one slice per
     // workgroup, no reduction afterwards), each + PC_BOTH when one launch covers both volumes (twice the work items)
@@ -678,8 +680,9 @@ PcPlan pc_plan(int W, int rows, int Dloc, int seg_rows_opt, int form, int batch,
     // layout: the narrow one (2 waves per 50 columns) where it needs fewer waves per image row than the wide one (4 per 107);
     // both-volume select launches only (the product path); ties go to the wide layout
     constexpr int WIDE = PcLayout<1>::COLS, NARROW = PcLayout<1, true>::COLS;
-    pl.narrow = (form & 3) != PC_STORE && (form & PC_BOTH) && 2 * ((W + NARROW - 1) / NARROW) < 4 * ((W + WIDE - 1) / WIDE);
-    if ((form & 3) != PC_STORE && (form & PC_BOTH) && PSM_KNOB("PSM_PC_NARROW", 0) > 0) pl.narrow = PSM_KNOB("PSM_PC_NARROW", 0) == 1;   // (experiment builds: 1 forces the narrow layout, 2 the wide one)
+    const bool select2 = (form & 3) != PC_STORE && (form & PC_BOTH);
+    const int narrow_knob = PSM_KNOB("PSM_PC_NARROW", 0);        // (experiment builds: 1 forces the narrow layout, 2 the wide one)
+    pl.narrow = select2 && (narrow_knob ? narrow_knob == 1 : 2 * ((W + NARROW - 1) / NARROW) < 4 * ((W + WIDE - 1) / WIDE));
     const int cols = (form & 3) == PC_STORE ? PcLayout<0>::COLS : (pl.narrow ? NARROW : WIDE);
     pl.cols = cols;
     pl.ngroups = (W + cols - 1) / cols;
