@@ -156,9 +156,6 @@ def parse_args():
     ap.add_argument("--batch", type=int, default=1,
                     help="N = 1: B different stereo pairs of the configuration per step through ONE set of launches (psm_compute_batch: the "
                          "reference's loop over pairs / datasets, src/main.cpp:64-73); value counts the voxels of all B pairs")
-    ap.add_argument("--graph", action="store_true",
-                    help="with --batch: the launches of a step replayed as one hipGraph (PSM_OPT_GRAPH); the fused kernel's in-region "
-                         "time stamps are off then (they need a slot per launch), its time comes from the separate event pass")
     ap.add_argument("--same-device", action="store_true",
                     help="N > 1: every rank uses GPU 0 - the N > 1 protocol (two buffers, pending exchange, gather / merge at world N) "
                          "on a box with one GPU; a correctness run, not a scaling measurement")
@@ -170,12 +167,12 @@ def parse_args():
     ap.add_argument("--pair", default="synthetic", choices=["synthetic", "fixture"],
                     help="c1 / c1x / c2: 'fixture' times the Middlebury pair BASELINE.json names instead of a synthetic pair of its size - Cones "
                          "(c1; c1x: its 384 x 288 crop) and Teddy (c2) from tests/golden/*_pair.npz, the images the reference ships")
-    ap.add_argument("--frames-in-flight", type=int, default=1,
-                    help="N = 1: F contexts of the configuration, each on its own stream, take the steps in turn - frame i + 1 is queued while "
+    ap.add_argument("--frames-in-flight", type=int, default=0,
+                    help="(0 = default: 1 at N = 1, 2 per rank at N > 1)  F contexts of the configuration, each on its own stream, take the steps in turn - frame i + 1 is queued while "
                          "frame i runs, so a frame's short kernels (prep, guidance, reduction) and the half-empty last round of its fused "
                          "launch run beside the next frame's fused kernel.  The reference's use is a frame loop (src/main.cpp:64-73); this is "
                          "that loop with two frames in the device's queues.  Measured: -9 % at 720p x 128, -19 % at 450 x 375 x 64, nothing at "
-                         "1080p x 256 (profiles/r05/exp_frames_in_flight.txt); default 1")
+                         "1080p x 256 (profiles/r05/exp_frames_in_flight.txt); a rank's 1/8 share of 1080p x 256: -6 %")
     ap.add_argument("--shard-sim", type=int, default=0,
                     help="diagnostic: time only rank 0's share of a G-rank job on this GPU (no exchange); "
                          "the JSON line is then NOT the headline metric")
@@ -311,159 +308,166 @@ def main():
             d0, d1 = 0, D // args.shard_sim
         else:
             d0, d1 = 0, D
-        de = P.DispEst(l, r, D, 8, True, device=dev_index, d_range=(d0, d1), dtype=dtype)
-        if args.seg_rows >= 0:
-            de.set_option(capi.PSM_OPT_SEG_ROWS, args.seg_rows)
-        de.set_option(capi.PSM_OPT_KERNEL_VARIANT, args.variant)
-        if args.flags >= 0:
-            de.set_option(capi.PSM_OPT_FLAGS, args.flags)
-        de.set_option(capi.PSM_OPT_ASYNC, 1)
-        batch_all = [de]
-        for pl_, pr_ in batch_pairs[1:]:
-            o_ = P.DispEst(pl_, pr_, D, 8, True, device=dev_index, dtype=dtype)
-            if args.seg_rows >= 0:
-                o_.set_option(capi.PSM_OPT_SEG_ROWS, args.seg_rows)
-            if args.flags >= 0:
-                o_.set_option(capi.PSM_OPT_FLAGS, args.flags)
-            batch_all.append(o_)
-        if len(batch_all) > 1:
-            share_streams(batch_all)         # one compute stream and one copy stream each way for the whole batch
-        if rows_mode:
-            de.set_rows(y0, y1)
-        if args.fgf:
-            de.setSubsampleRate(args.fgf)
-        # --frames-in-flight F: F - 1 more contexts with the same pair, geometry and options; step i runs on context i % F
-        FIF = max(1, args.frames_in_flight) if (not use_dist and not use_batch and not args.fgf) else 1
-        ring = [de]
-        for _ in range(FIF - 1):
-            o_ = P.DispEst(l, r, D, 8, True, device=dev_index, d_range=(d0, d1), dtype=dtype)
+        def new_ctx(pl_=l, pr_=r, dr=(d0, d1)):
+            o_ = P.DispEst(pl_, pr_, D, 8, True, device=dev_index, d_range=dr, dtype=dtype)
             if args.seg_rows >= 0:
                 o_.set_option(capi.PSM_OPT_SEG_ROWS, args.seg_rows)
             o_.set_option(capi.PSM_OPT_KERNEL_VARIANT, args.variant)
             if args.flags >= 0:
                 o_.set_option(capi.PSM_OPT_FLAGS, args.flags)
             o_.set_option(capi.PSM_OPT_ASYNC, 1)
+            return o_
+
+        de = new_ctx()
+        batch_all = [de] + [new_ctx(pl_, pr_, (0, D)) for pl_, pr_ in batch_pairs[1:]]
+        if len(batch_all) > 1:
+            share_streams(batch_all)         # one compute stream and one copy stream each way for the whole batch
+        if rows_mode:
+            de.set_rows(y0, y1)
+        if args.fgf:
+            de.setSubsampleRate(args.fgf)
+        # --frames-in-flight F: F - 1 more contexts with the same pair, geometry and options, each on its own stream; step i runs on
+        # context i % F.  Default (0): one frame at a time at N = 1 (the headline configuration does not gain), TWO per rank for
+        # N > 1 - a rank's share of the job is a short launch chain whose tails and small kernels hide under the next frame's
+        # fused kernel (1/8 row stripe of 1080p x 256: 1.015 -> 0.95 ms rank-local).
+        FIF = args.frames_in_flight if args.frames_in_flight > 0 else (2 if use_dist else 1)
+        if use_batch or args.fgf:
+            FIF = 1
+        ring = [de]
+        for _ in range(FIF - 1):
+            o_ = new_ctx()
             if rows_mode:
                 o_.set_rows(y0, y1)
             ring.append(o_)
         if FIF > 1:
             for o_ in ring:                  # what FrameRing tells its contexts: the planner cuts the launches for FIF pairs at a time
                 o_.set_option(capi.PSM_OPT_FRAMES_IN_FLIGHT, FIF)
-        keys_local = keys_all = None
-        kbuf = []
-        pending = []                 # (work handles, buffer) of the frame whose merge is still outstanding
-        frame = [0]
+        # ---- one slot per frame in flight: its context, (N > 1) its torch stream - kernels AND the frame's collective are ordered
+        # on it, so two slots overlap freely - and its own exchange buffers (two key / map tensors alternate within a slot: a frame's
+        # exchange is still pending when the slot's next frame writes) ----
+        import contextlib
+
+        class Slot:
+            pass
+        slots = []
+        HW2 = 2 * H * W
+        for k_, o_ in enumerate(ring):
+            sl = Slot()
+            sl.de, sl.pending, sl.n, sl.stream = o_, [], 0, None
+            if use_dist:
+                sl.stream = side_stream if k_ == 0 else torch.cuda.Stream()
+                with torch.cuda.stream(sl.stream):
+                    sl.kbuf = [torch.empty(HW2, dtype=torch.int64, device="cuda") for _ in range(2)]
+                    sl.keys_all = torch.empty(world * HW2 if exchange == "allgather" and not rows_mode else 1, dtype=torch.int64, device="cuda")
+                    if rows_mode:
+                        # the maps of a frame are written by the library straight into one of two torch tensors (psm_set_map_buffer);
+                        # the stripe rows go through one all_gather per frame: [world][2][rows_max][W] uint8 = the two whole maps
+                        sl.mbuf = [torch.zeros(HW2 + 4, dtype=torch.uint8, device="cuda") for _ in range(2)]
+                        sl.send = torch.zeros(2 * rows_max * W, dtype=torch.uint8, device="cuda")
+                        sl.recv = torch.zeros(world * 2 * rows_max * W, dtype=torch.uint8, device="cuda")
+                o_.set_stream(sl.stream.cuda_stream)
+            slots.append(sl)
         if use_dist:
-            HW2 = 2 * H * W
-            kbuf = [torch.empty(HW2, dtype=torch.int64, device="cuda") for _ in range(2)]
-            keys_local = kbuf[0]
-            keys_all = torch.empty(world * HW2 if exchange == "allgather" else 1, dtype=torch.int64, device="cuda")
-            if rows_mode:
-                # the maps of a frame are written by the library straight into one of two torch tensors (psm_set_map_buffer);
-                # the stripe rows go through one all_gather per frame: [world][2][rows_max][W] uint8 = the two whole maps
-                mbuf = [torch.zeros(HW2 + 4, dtype=torch.uint8, device="cuda") for _ in range(2)]
-                send = torch.zeros(2 * rows_max * W, dtype=torch.uint8, device="cuda")
-                recv = torch.zeros(world * 2 * rows_max * W, dtype=torch.uint8, device="cuda")
-            de.set_stream(side_stream.cuda_stream)
+            torch.cuda.synchronize()
+        frame = [0]
         pipelined = use_dist and (exchange == "allreduce" or rows_mode) and not args.no_frame_pipeline and not args.fgf
 
-        def finish_pending():
-            # exchange of an earlier frame -> final maps (the collective ran on RCCL's stream meanwhile)
-            while pending:
-                works, kb = pending.pop(0)
+        def on(sl):          # everything torch issues for a slot's frame (packing, the collective, waits, assembling) goes to ITS stream
+            return torch.cuda.stream(sl.stream) if use_dist else contextlib.nullcontext()
+
+        def finish_pending(sl):
+            # exchange of an earlier frame of this slot -> final maps (the collective ran on RCCL's stream meanwhile)
+            while sl.pending:
+                works, kb = sl.pending.pop(0)
                 for w_ in works:
                     w_.wait()
                 if rows_mode:
-                    stripes.assemble(recv, world, H, W, rows_max, kb)    # [rank][side][row][x] -> [side][y][x]
-                    de.set_map_buffer(kb.data_ptr(), whole=True)
+                    stripes.assemble(sl.recv, world, H, W, rows_max, kb)    # [rank][side][row][x] -> [side][y][x]
+                    sl.de.set_map_buffer(kb.data_ptr(), whole=True)
                 else:
-                    de.DispSelect_merge(kb.data_ptr(), 1, download=False)
+                    sl.de.DispSelect_merge(kb.data_ptr(), 1, download=False)
                 if lrc:
-                    de.LRCheck_device()
+                    sl.de.LRCheck_device()
 
-        def stripe_exchange(mb, async_op):
-            stripes.pack_stripe(mb, y0, y1, send, H, W, rows_max)
-            return ex.all_gather(recv, send, async_op=async_op)      # the one exchange step (RCCL; or staged over gloo)
+        def stripe_exchange(sl, mb, async_op):
+            stripes.pack_stripe(mb, y0, y1, sl.send, H, W, rows_max)
+            return ex.all_gather(sl.recv, sl.send, async_op=async_op)      # the one exchange step (RCCL; or staged over gloo)
 
         def step():
             if use_batch:                    # all B pairs: one prep, one guidance, one fused grid (blockIdx.z = pair), one reduction
                 compute_batch(batch_all)
                 return
-            if FIF == 1:
-                de.CostConst_GPU()
+            sl = slots[frame[0] % FIF]       # frames in flight: this step's frame goes to the next slot of the ring (its own stream)
+            frame[0] += 1
+            with on(sl):
+                step_on(sl)
+
+        def step_on(sl):
+            cur = sl.de
+            cur.CostConst_GPU()
             if args.fgf:
-                de.CostFilter_FGF_GPU()
+                cur.CostFilter_FGF_GPU()
                 if use_dist:
-                    de.DispSelect_partial(keys_local.data_ptr())
-                    ex.all_reduce_min(keys_local)
-                    de.DispSelect_merge(keys_local.data_ptr(), 1, download=False)
+                    cur.DispSelect_partial(sl.kbuf[0].data_ptr())
+                    ex.all_reduce_min(sl.kbuf[0])
+                    cur.DispSelect_merge(sl.kbuf[0].data_ptr(), 1, download=False)
                 elif args.shard_sim > 1:
-                    de.DispSelect_partial()
+                    cur.DispSelect_partial()
                 else:
-                    de.DispSelect_device()
+                    cur.DispSelect_device()
                 return
             if rows_mode and use_dist:
                 # Row stripes: nothing of the cost volumes or their minima leaves the rank; the finished rows of both maps are
                 # gathered - asynchronously, behind the next frame's filter when pipelined (maps alternate between two tensors).
-                mb = mbuf[frame[0] & 1]
-                frame[0] += 1
-                de.set_map_buffer(mb.data_ptr())
-                de.CostFilter_GPU()
-                de.DispSelect_device()
-                finish_pending()
+                mb = sl.mbuf[sl.n & 1]
+                sl.n += 1
+                cur.set_map_buffer(mb.data_ptr())
+                cur.CostFilter_GPU()
+                cur.DispSelect_device()
+                finish_pending(sl)
                 if pipelined:
-                    pending.append(((stripe_exchange(mb, True),), mb))
+                    sl.pending.append(((stripe_exchange(sl, mb, True),), mb))
                 else:
-                    stripe_exchange(mb, False)
-                    pending.append(((), mb))
-                    finish_pending()
+                    stripe_exchange(sl, mb, False)
+                    sl.pending.append(((), mb))
+                    finish_pending(sl)
                 return
             if pipelined:
                 # Frame pipeline, ONE collective per frame: the fused kernel leaves the packed minima of both volumes directly
                 # in this frame's key tensor; the all-reduce(MIN) over the ranks is asynchronous and has the whole next
                 # frame's filter to complete - its merge is issued after that filter, so no kernel of ours ever waits for a
                 # collective that is still running.  Keys alternate between two tensors.
-                kb = kbuf[frame[0] & 1]
-                frame[0] += 1
-                de.set_key_buffer(kb.data_ptr())
-                de.CostFilter_GPU()
-                finish_pending()
-                w_ = ex.all_reduce_min(kb, async_op=True)
-                pending.append(((w_,), kb))
-                return
-            if FIF > 1:                      # frames in flight: this step's frame goes to the next context of the ring (its own stream)
-                cur = ring[frame[0] % FIF]
-                frame[0] += 1
-                cur.CostConst_GPU()          # (the CostConst_GPU issued above on context 0 is then this ring slot's turn only)
+                kb = sl.kbuf[sl.n & 1]
+                sl.n += 1
+                cur.set_key_buffer(kb.data_ptr())
                 cur.CostFilter_GPU()
-                if args.shard_sim > 1 and not rows_mode:
-                    cur.DispSelect_partial()
-                else:
-                    cur.DispSelect_device()
-                if lrc:
-                    cur.LRCheck_device()
+                finish_pending(sl)
+                w_ = ex.all_reduce_min(kb, async_op=True)
+                sl.pending.append(((w_,), kb))
                 return
             if use_dist:
-                de.set_key_buffer(keys_local.data_ptr())
-            de.CostFilter_GPU()
+                cur.set_key_buffer(sl.kbuf[0].data_ptr())
+            cur.CostFilter_GPU()
             if use_dist:
                 if exchange == "none":       # diagnostic only: cost of the torch collective call itself
-                    de.DispSelect_merge(keys_local.data_ptr(), 1, download=False)
+                    cur.DispSelect_merge(sl.kbuf[0].data_ptr(), 1, download=False)
                 elif exchange == "allreduce":
-                    ex.all_reduce_min(keys_local)                         # the one exchange step (RCCL)
-                    de.DispSelect_merge(keys_local.data_ptr(), 1, download=False)
+                    ex.all_reduce_min(sl.kbuf[0])                         # the one exchange step (RCCL)
+                    cur.DispSelect_merge(sl.kbuf[0].data_ptr(), 1, download=False)
                 else:
-                    ex.all_gather(keys_all, keys_local)                   # the one exchange step (RCCL)
-                    de.DispSelect_merge(keys_all.data_ptr(), world, download=False)
+                    ex.all_gather(sl.keys_all, sl.kbuf[0])                # the one exchange step (RCCL)
+                    cur.DispSelect_merge(sl.keys_all.data_ptr(), world, download=False)
             elif args.shard_sim > 1 and not rows_mode:
-                de.DispSelect_partial()
+                cur.DispSelect_partial()
             else:
-                de.DispSelect_device()
+                cur.DispSelect_device()
             if lrc and not (use_dist and exchange == "none"):
-                de.LRCheck_device()
+                cur.LRCheck_device()
 
         def sync():
-            finish_pending()
+            for sl in slots:
+                with on(sl):
+                    finish_pending(sl)
             if use_dist:
                 torch.cuda.synchronize()
             for o_ in ring:
@@ -477,11 +481,8 @@ def main():
             step()
         # the fused filter kernel stamps its own start / end from here on: two atomics per workgroup, no events between the
         # kernels - the launches of the timed region itself are what roofline reports
-        if args.graph and use_batch:
-            de.set_option(capi.PSM_OPT_GRAPH, 1)
-        else:
-            for o_ in ring:
-                o_.set_option(capi.PSM_OPT_PROFILE, 2)
+        for o_ in ring:
+            o_.set_option(capi.PSM_OPT_PROFILE, 2)
         sync()
         for o_ in ring:
             o_.filter_launch_times()
@@ -521,26 +522,28 @@ def main():
         # ---- N > 1: what a step is made of on every rank - the rank-local kernels alone and the frame's ONE collective alone (each
         # bracketed by its own synchronisation: their sum exceeds a pipelined step, which overlaps the two) ----
         if use_dist and not args.fgf:
+            s0 = slots[0]
+
             def local_only():
                 de.CostConst_GPU()
                 if rows_mode:
-                    de.set_map_buffer(mbuf[0].data_ptr())
+                    de.set_map_buffer(s0.mbuf[0].data_ptr())
                     de.CostFilter_GPU()
                     de.DispSelect_device()
                 else:
-                    de.set_key_buffer(kbuf[0].data_ptr())
+                    de.set_key_buffer(s0.kbuf[0].data_ptr())
                     de.CostFilter_GPU()
 
             def exchange_only():
                 if rows_mode:
-                    stripe_exchange(mbuf[0], False)
-                    stripes.assemble(recv, world, H, W, rows_max, mbuf[0])
+                    stripe_exchange(s0, s0.mbuf[0], False)
+                    stripes.assemble(s0.recv, world, H, W, rows_max, s0.mbuf[0])
                 elif exchange == "allgather":
-                    ex.all_gather(keys_all, kbuf[0])
-                    de.DispSelect_merge(keys_all.data_ptr(), world, download=False)
+                    ex.all_gather(s0.keys_all, s0.kbuf[0])
+                    de.DispSelect_merge(s0.keys_all.data_ptr(), world, download=False)
                 elif exchange == "allreduce":
-                    ex.all_reduce_min(kbuf[0])
-                    de.DispSelect_merge(kbuf[0].data_ptr(), 1, download=False)
+                    ex.all_reduce_min(s0.kbuf[0])
+                    de.DispSelect_merge(s0.kbuf[0].data_ptr(), 1, download=False)
 
             comp, coll = [], []
             for _ in range(5):
@@ -560,7 +563,9 @@ def main():
                                "note": "medians of 5: the rank-local kernels of one frame (prep, guidance, fused filter, reduction) and the "
                                        "frame's one exchange (+ gather / merge of its result), each alone between synchronisations; a "
                                        "pipelined step overlaps the exchange of frame i with the filter of frame i + 1"}
-            step(); sync()                       # (leave the context as a complete step does: final maps of this pair)
+            for _ in ring:
+                step()
+            sync()                               # (leave every context as a complete step does: final maps of this pair)
         rec["geometry"] = {"rows": [y0, y1], "slices": [d0, d1], "rows_max": rows_max, "parts": parts, "rows_mode": rows_mode}
         rec["sync"], rec["step"], rec["de"], rec["batch_all"] = sync, step, de, batch_all + ring[1:]
         rec["ring"] = ring
@@ -785,7 +790,10 @@ def main():
     # HBM rate is a small fraction of the peak (traffic_frac) and what bounds it is VALU issue - binding says so, next to the HBM
     # fraction on the algorithmic bytes that SURVEY.md 8d defines (48 B / voxel, unchanged) ----
     if select_mode and dom == "cvf_fused":
-        roofline["binding"] = "valu"
+        # `bound` names the resource that binds (the contract lists hbm | mfma; for this kernel neither is true and the line says so
+        # with its first key); achieved / peak / unit / frac stay the HBM figures on SURVEY.md 8d's algorithmic bytes (frac_of)
+        roofline["bound"] = roofline["binding"] = "valu"
+        roofline["frac_of"] = "hbm peak, algorithmic bytes (SURVEY.md 8d: 48 B / voxel for the fused CVC + CVF + WTA kernel)"
         if "valu" in roofline:
             roofline["binding_frac"] = roofline["valu"]["frac_of_valu_bound"]
             roofline["binding_note"] = ("VALU issue: SQ_INSTS_VALU per launch at the part's measured issue rates (0.50 / 0.86 G wave-instructions/s per SIMD "
@@ -1019,6 +1027,7 @@ def main():
             a = measure(other, args.exchange or "allgather")
             alt = {"shard": other, "exchange": a["exchange"], "ms_per_step": a["ms_per_step"], "value": a["value"],
                    "median_ms_per_step": a["median_ms_per_step"], "filter_launches": a["filter_launches"], "per_rank": a.get("per_rank"),
+                   "frames_in_flight": len(a["ring"]),
                    "parallelism": (f"D sharded over {world} ranks + 1 {xname} {a['exchange']} of packed minima per frame" if other == "disp"
                                    else f"{world} row stripes + 1 {xname} all_gather of the map rows per frame"),
                    "note": ("the configuration BASELINE configs[3] / the north star name (D slices sharded, one all-gather of per-pixel minima); "
@@ -1027,7 +1036,8 @@ def main():
                 a["sync"]()
                 a["de"].set_option(capi.PSM_OPT_ASYNC, 0)
                 alt.update(check_maps(a, ref_maps, oracle_maps))
-            a["de"].close()
+            for o_ in a["batch_all"]:
+                o_.close()
 
     if rank == 0:
         out = {
@@ -1041,7 +1051,7 @@ def main():
                                       (f"{world} row stripes of {geo['rows_max']} rows (all {D} slices each) + 1 {xname} all_gather of the map rows per frame"
                                        if rows_mode else f"D sharded over {world} ranks + 1 {xname} {exchange} of packed minima"),
                        "kernel_variant": args.variant, "shard_sim": args.shard_sim, "lr_check_on_gpu": bool(lrc),
-                       "shard": head["shard"], "batch": B, "graph": bool(args.graph and use_batch), "ranks": world, "same_device": bool(args.same_device),
+                       "shard": head["shard"], "batch": B, "ranks": world, "same_device": bool(args.same_device),
                        "frames_in_flight": len(head["ring"]),
                        "exchange_backend": (backend if use_dist else None)},
             "roofline": roofline, "cpu_baseline": cpu, "kernels": kern,

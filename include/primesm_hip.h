@@ -58,8 +58,8 @@ enum {
     PSM_OPT_SEG_ROWS = 3,       /* rows per y-segment of the marching kernels (0 = auto)      */
     PSM_OPT_WAVES = 4,          /* waves (disparity slices) per workgroup: 1,2,4,8            */
     PSM_OPT_FLAGS = 5,          /* PSM_FLAG_* bits below; no flag but PSM_FLAG_F32_TOL / PSM_FLAG_FMA_SOLVE changes any result */
-    PSM_OPT_GRAPH = 6,          /* 1: psm_compute_batch captures its launches once as a hipGraph and replays it while the batch
-                                   (contexts, geometry, options) stays the same; ignored while PSM_OPT_PROFILE is on */
+    PSM_OPT_GRAPH = 6,          /* retired: 1 is refused by the product library (hipGraph replay of a batch's launches measured slower
+                                   than the launches themselves on this runtime; experiment builds keep it), 0 is accepted */
     PSM_OPT_GATHER_STAGED = 7,  /* 1 (on the ROOT context): psm_gather_rows_ctx / psm_disp_merge_ctx move every stripe / shard through
                                    page-locked host memory instead of device / peer copies - what they do on their own between two
                                    devices for which hipDeviceCanAccessPeer says no; the option forces that path (test hook) */

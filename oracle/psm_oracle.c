@@ -322,6 +322,55 @@ void psmo_cvf_preprocess(const float *img, int H, int W, float *rgb, float *mean
     free(hs);
 }
 
+/* src/CVF.cpp:102-149: the per-pixel 3x3 solve of GuidedFilter_cv on planar inputs (var_I: 6 planes of N, cov: 3 planes, a: 3
+ * planes).  Exported so that tests can put the FMA reading next to what GCC emits for the same expressions (oracle/fma_probe.c). */
+void psmo_solve_models(const float *var_I, const float *cov, size_t N, float *a)
+{
+    for (size_t i = 0; i < N; ++i) {
+        float c0 = cov[0 * N + i];
+        float c1 = cov[1 * N + i];
+        float c2 = cov[2 * N + i];
+        float a11 = var_I[0 * N + i] + PSMO_GIF_EPS;
+        float a12 = var_I[1 * N + i];
+        float a13 = var_I[2 * N + i];
+        float a21 = var_I[1 * N + i];
+        float a22 = var_I[3 * N + i] + PSMO_GIF_EPS;
+        float a23 = var_I[4 * N + i];
+        float a31 = var_I[2 * N + i];
+        float a32 = var_I[4 * N + i];
+        float a33 = var_I[5 * N + i] + PSMO_GIF_EPS;
+        if (g_variant & PSMO_VAR_FMA_SOLVE) {
+            /* What GCC's -ffp-contract=fast makes of these lines on an FMA target - read off gcc 11.4 -O2 -mfma on the same
+             * expressions and re-checked against a live compile by tests/test_oracle.py (oracle/fma_probe.c):
+             *   x*y - z*w        -> fma(x, y, -RN(z*w))                 (the SECOND product is the rounded one)
+             *   p0 + p1 + p2     -> fma(x2, y2, fma(x0, y0, RN(x1*y1))) (the MIDDLE product is the rounded one)
+             *   p0 - p1 + p2     -> fma(x2, y2, fma(x0, y0, -RN(x1*y1)))
+             * and common subexpressions are shared first: a31*a23 and a32*a13 are one rounded product P, so the two minors
+             * (a31*a23 - a33*a21) and (a32*a13 - a33*a12) are both fma(-a33, a21, P) - the exact negative of DET's middle minor. */
+#define M2(x, y, z, w) fmaf((x), (y), -((z) * (w)))
+            float m00 = M2(a33, a22, a32, a23), m01 = M2(a33, a12, a32, a13), m02 = M2(a23, a12, a22, a13);
+            float DETf = fmaf(a31, m02, fmaf(a11, m00, -(a21 * m01)));
+            DETf = 1 / DETf;
+            float n01 = fmaf(-a33, a21, a31 * a23);
+            float m11 = M2(a33, a11, a31, a13), m12 = M2(a21, a13, a23, a11), m22 = M2(a22, a11, a21, a12);
+            a[0 * N + i] = DETf * fmaf(c2, m02, fmaf(c0, m00, c1 * n01));
+            a[1 * N + i] = DETf * fmaf(c2, m12, fmaf(c0, n01, c1 * m11));
+            a[2 * N + i] = DETf * fmaf(c2, m22, fmaf(c0, m02, c1 * m12));
+#undef M2
+            continue;
+        }
+        float DET = a11 * (a33 * a22 - a32 * a23) - a21 * (a33 * a12 - a32 * a13) +
+                    a31 * (a23 * a12 - a22 * a13);
+        DET = 1 / DET;
+        a[0 * N + i] = DET * (c0 * (a33 * a22 - a32 * a23) + c1 * (a31 * a23 - a33 * a21) +
+                              c2 * (a32 * a21 - a31 * a22));
+        a[1 * N + i] = DET * (c0 * (a32 * a13 - a33 * a12) + c1 * (a33 * a11 - a31 * a13) +
+                              c2 * (a31 * a12 - a32 * a11));
+        a[2 * N + i] = DET * (c0 * (a23 * a12 - a22 * a13) + c1 * (a21 * a13 - a23 * a11) +
+                              c2 * (a22 * a11 - a21 * a12));
+    }
+}
+
 /* workspace-taking core of GuidedFilter_cv; ws: 9*N floats, hs: N doubles */
 static void guided_filter_ws(const float *rgb, const float *mean_I, const float *var_I, int H,
                              int W, float *p, float *ab_out, float *ws, double *hs)
@@ -347,41 +396,7 @@ static void guided_filter_ws(const float *rgb, const float *mean_I, const float 
             mean_Ip[c * N + i] = mean_Ip[c * N + i] - t;
         }
     /* src/CVF.cpp:102-149 */
-    for (size_t i = 0; i < N; ++i) {
-        float c0 = mean_Ip[0 * N + i];
-        float c1 = mean_Ip[1 * N + i];
-        float c2 = mean_Ip[2 * N + i];
-        float a11 = var_I[0 * N + i] + PSMO_GIF_EPS;
-        float a12 = var_I[1 * N + i];
-        float a13 = var_I[2 * N + i];
-        float a21 = var_I[1 * N + i];
-        float a22 = var_I[3 * N + i] + PSMO_GIF_EPS;
-        float a23 = var_I[4 * N + i];
-        float a31 = var_I[2 * N + i];
-        float a32 = var_I[4 * N + i];
-        float a33 = var_I[5 * N + i] + PSMO_GIF_EPS;
-        if (g_variant & PSMO_VAR_FMA_SOLVE) {
-            /* x*y - z*w -> fma(x, y, -(z*w)); s + x*y -> fma(x, y, s): the contraction GCC applies left to right */
-#define M2(x, y, z, w) fmaf((x), (y), -((z) * (w)))
-            float m00 = M2(a33, a22, a32, a23), m01 = M2(a33, a12, a32, a13), m02 = M2(a23, a12, a22, a13);
-            float DETf = fmaf(a31, m02, fmaf(-a21, m01, a11 * m00));
-            DETf = 1 / DETf;
-            a[0 * N + i] = DETf * fmaf(c2, M2(a32, a21, a31, a22), fmaf(c1, M2(a31, a23, a33, a21), c0 * m00));
-            a[1 * N + i] = DETf * fmaf(c2, M2(a31, a12, a32, a11), fmaf(c1, M2(a33, a11, a31, a13), c0 * M2(a32, a13, a33, a12)));
-            a[2 * N + i] = DETf * fmaf(c2, M2(a22, a11, a21, a12), fmaf(c1, M2(a21, a13, a23, a11), c0 * m02));
-#undef M2
-            continue;
-        }
-        float DET = a11 * (a33 * a22 - a32 * a23) - a21 * (a33 * a12 - a32 * a13) +
-                    a31 * (a23 * a12 - a22 * a13);
-        DET = 1 / DET;
-        a[0 * N + i] = DET * (c0 * (a33 * a22 - a32 * a23) + c1 * (a31 * a23 - a33 * a21) +
-                              c2 * (a32 * a21 - a31 * a22));
-        a[1 * N + i] = DET * (c0 * (a32 * a13 - a33 * a12) + c1 * (a33 * a11 - a31 * a13) +
-                              c2 * (a31 * a12 - a32 * a11));
-        a[2 * N + i] = DET * (c0 * (a23 * a12 - a22 * a13) + c1 * (a21 * a13 - a23 * a11) +
-                              c2 * (a22 * a11 - a21 * a12));
-    }
+    psmo_solve_models(var_I, mean_Ip, N, a);
     /* src/CVF.cpp:152-155: mean_p -= a[c]*mean_I[c], sequentially */
     for (int c = 0; c < 3; ++c)
         for (size_t i = 0; i < N; ++i) {

@@ -93,6 +93,10 @@ void psmo_cvf_preprocess(const float *img, int H, int W, float *rgb, float *mean
 void psmo_guided_filter(const float *rgb, const float *mean, const float *var, int H, int W,
                         float *p, float *ab);
 
+/* src/CVF.cpp:102-149 alone: the per-pixel 3x3 solve on planar inputs (var: 6 planes of n, cov: 3 planes -> a: 3 planes);
+ * honours psmo_set_variant (PSMO_VAR_FMA_SOLVE). */
+void psmo_solve_models(const float *var, const float *cov, size_t n, float *a);
+
 /* ---- CVF, Fast Guided Filter variant ("next" row: what the snapshot's live CPU branch runs) ------- */
 /* src/fastguidedfilter.cpp (FastGuidedFilterColor) as used by DispEst::CostFilter_FGF
  * (src/DispEst.cpp:281-296): r = GIF_R_WIN = 8, eps = GIF_EPS, s = subsample_rate (2, 4 or 8).

@@ -106,6 +106,34 @@ def guided_filter(rgb, mean, var, p, want_ab=False):
     return (q, ab) if want_ab else q
 
 
+def solve_models(var6, cov3):
+    """src/CVF.cpp:102-149 alone on planar inputs: var6 [6][n], cov3 [3][n] -> a [3][n] (honours `variant`)."""
+    v, c = _f32(var6), _f32(cov3)
+    n = v.shape[1]
+    assert v.shape == (6, n) and c.shape == (3, n)
+    a = np.empty((3, n), np.float32)
+    lib().psmo_solve_models(_p(v), _p(c), C.c_size_t(n), _p(a))
+    return a
+
+
+FMA_PROBE_PATH = os.path.join(_HERE, "libpsm_fma_probe.so")
+
+
+def fma_probe_solve(var6, cov3):
+    """The same solve loop as plain C compiled by THIS host's gcc with -O2 -mfma -ffp-contract=fast (oracle/fma_probe.c);
+    None when the probe could not be built (no x86-64 FMA host)."""
+    if not os.path.exists(FMA_PROBE_PATH):
+        subprocess.run(["make", "-C", _HERE, "fma_probe"], check=False, stdout=subprocess.DEVNULL)
+    if not os.path.exists(FMA_PROBE_PATH):
+        return None
+    pl = C.CDLL(FMA_PROBE_PATH)
+    v, c = _f32(var6), _f32(cov3)
+    n = v.shape[1]
+    a = np.empty((3, n), np.float32)
+    pl.psmo_probe_solve(_p(v), _p(c), C.c_size_t(n), _p(a))
+    return a
+
+
 def wta(vol):
     vol = _f32(vol)
     D, H, W = vol.shape

@@ -149,6 +149,7 @@ extern "C" int psm_compute_batch(psm_ctx *const *ctxs, int n)
         }
         return check_launch(c0, "batch (prep, guidance, fused select filter, reduction)");
     };
+#ifdef PSM_EXPERIMENTS      // (PSM_OPT_GRAPH: experiment builds only - the replay measured slower than the plain launches)
     if (c0->opt_graph && c0->opt_profile == 0) {
         // One graph per frame: the kernels read every pair through the device table (whose ADDRESS is all the graph holds), so the
         // captured launches stay valid while the batch size, the geometry and the options do - also across new image pairs.
@@ -170,7 +171,9 @@ extern "C" int psm_compute_batch(psm_ctx *const *ctxs, int n)
         }
         PSM_HIP(c0, hipGraphLaunch(c0->batch_graph, s));
         t1 = now_us();
-    } else if (enqueue()) return 1;
+    } else
+#endif
+    if (enqueue()) return 1;
     for (int i = 0; i < n; ++i)
         if (ctxs[i]->ev_free) PSM_HIP(c0, hipEventRecord(ctxs[i]->ev_free, s));     // the staged images have been read
     const double t2 = now_us();

@@ -183,34 +183,42 @@ int psm_set_map_buffer(psm_ctx *c, void *dev_maps, int whole)
 // synchronised) into root's memory, ordered on root's stream.  Same device: a device copy.  Other device: a peer copy when
 // hipDeviceCanAccessPeer(root, s) says the two can reach each other (xGMI / PCIe P2P), else - or with PSM_OPT_GATHER_STAGED, the
 // test hook for exactly this path on a one-GPU box - through a page-locked bounce buffer of root: device -> host on s's device,
-// host -> device on root's stream (one buffer, so each leg completes before the next reuses it: the slow but always available way).
+// host -> device on root's stream (two buffers used alternately: the next leg's device -> host copy overlaps this leg's host -> device
+// copy, a slot is refilled only after the copy out of it has executed - the slow but always available way).
 static int gather_leg(psm_ctx *root, void *dst, psm_ctx *s, const void *src, size_t n)
 {
     bool staged = root->opt_gather_staged != 0;
     if (!staged && s->device != root->device) {
-        int can = 0;
-        if (hipDeviceCanAccessPeer(&can, root->device, s->device) != hipSuccess) { can = 0; (void)hipGetLastError(); }
-        staged = !can;
+        signed char &ok = root->peer_ok[s->device & 63];      // asked once per device pair, not on every leg of every frame
+        if (ok < 0) {
+            int can = 0;
+            if (hipDeviceCanAccessPeer(&can, root->device, s->device) != hipSuccess) { can = 0; (void)hipGetLastError(); }
+            ok = can ? 1 : 0;
+        }
+        staged = !ok;
     }
     if (!staged) {
         if (s->device == root->device) PSM_HIP(root, hipMemcpyAsync(dst, src, n, hipMemcpyDeviceToDevice, root->stream));
         else PSM_HIP(root, hipMemcpyPeerAsync(dst, root->device, src, s->device, n, root->stream));
         return 0;
     }
-    if (root->xfer_pin_bytes < n) {
-        PSM_HIP(root, hipStreamSynchronize(root->stream));
-        if (root->xfer_pin) (void)hipHostFree(root->xfer_pin);
-        root->xfer_pin = nullptr;
-        root->xfer_pin_bytes = 0;
-        PSM_HIP(root, hipHostMalloc((void **)&root->xfer_pin, n, hipHostMallocPortable));    // (portable: both devices copy to / from it)
-        root->xfer_pin_bytes = n;
+    const int k = root->xfer_slot;
+    root->xfer_slot ^= 1;
+    if (!root->ev_xfer[k]) PSM_HIP(root, hipEventCreateWithFlags(&root->ev_xfer[k], hipEventDisableTiming));
+    else PSM_HIP(root, hipEventSynchronize(root->ev_xfer[k]));    // the copy out of this slot (two legs ago) has executed
+    if (root->xfer_pin_bytes[k] < n) {
+        if (root->xfer_pin[k]) (void)hipHostFree(root->xfer_pin[k]);
+        root->xfer_pin[k] = nullptr;
+        root->xfer_pin_bytes[k] = 0;
+        PSM_HIP(root, hipHostMalloc((void **)&root->xfer_pin[k], n, hipHostMallocPortable));    // (portable: both devices copy to / from it)
+        root->xfer_pin_bytes[k] = n;
     }
     (void)hipSetDevice(s->device);
-    const hipError_t e = hipMemcpy(root->xfer_pin, src, n, hipMemcpyDeviceToHost);
+    const hipError_t e = hipMemcpy(root->xfer_pin[k], src, n, hipMemcpyDeviceToHost);    // (blocking: the slot is complete when it returns)
     (void)hipSetDevice(root->device);
     if (e != hipSuccess) return fail(root, "exchange leg (device %d -> host): %s", s->device, hipGetErrorString(e));
-    PSM_HIP(root, hipMemcpyAsync(dst, root->xfer_pin, n, hipMemcpyHostToDevice, root->stream));
-    PSM_HIP(root, hipStreamSynchronize(root->stream));
+    PSM_HIP(root, hipMemcpyAsync(dst, root->xfer_pin[k], n, hipMemcpyHostToDevice, root->stream));
+    PSM_HIP(root, hipEventRecord(root->ev_xfer[k], root->stream));
     ++root->gather_staged_legs;
     return 0;
 }

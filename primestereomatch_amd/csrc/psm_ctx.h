@@ -36,6 +36,7 @@ struct StreamSet {
 }  // namespace psm
 
 struct psm_ctx {
+    psm_ctx() { for (signed char &p : peer_ok) p = -1; }
     int W = 0, H = 0, D = 0, d0 = 0, d1 = 0, Dloc = 0, dtype = PSM_F32, device = 0;
     hipStream_t own_stream = nullptr, stream = nullptr;
     hipStream_t copy_stream = nullptr;  // psm_upload_pair_async / psm_download_maps_async: PCIe legs next to the kernels
@@ -62,9 +63,15 @@ struct psm_ctx {
     long long *keys_cur = nullptr;      // where the packed minima go: `keys`, or the caller's buffer (psm_set_key_buffer)
     long long *gather = nullptr;        // [gather_ranks][2][H][W], psm_disp_merge_ctx
     int gather_ranks = 0;
-    uint8_t *xfer_pin = nullptr;        // page-locked bounce buffer of the single-process exchange when two devices cannot reach each other (gather_leg)
-    size_t xfer_pin_bytes = 0;
-    int gather_staged_legs = 0;         // legs that went through it so far (psm_gather_staged_legs: tests)
+    // page-locked bounce buffers of the single-process exchange when two devices cannot reach each other (gather_leg): two slots
+    // used alternately - the device -> host copy of leg i + 1 runs while the host -> device copy of leg i is still in flight; a
+    // slot is refilled only after the copy out of it has executed (ev_xfer)
+    uint8_t *xfer_pin[2] = {nullptr, nullptr};
+    size_t xfer_pin_bytes[2] = {0, 0};
+    hipEvent_t ev_xfer[2] = {nullptr, nullptr};
+    int xfer_slot = 0;
+    signed char peer_ok[64];            // hipDeviceCanAccessPeer(this device, d), asked once per device (-1: not asked yet)
+    int gather_staged_legs = 0;         // legs that went through the bounce buffers since the context was created (psm_gather_staged_legs: tests)
     uint8_t *maps = nullptr;            // [2][H][W]: maps_own, or the caller's buffer (psm_set_map_buffer)
     uint8_t *maps_own = nullptr;
     uint8_t *maps_early = nullptr;      // the map buffer the single-phase filter already filled from its final keys (k_chunk_min), or null

@@ -63,11 +63,9 @@ __device__ __forceinline__ double rol4(double v)
 }
 
 // Horizontal 8-tap window sum over lanes l..l+7 (sliding balanced tree).
-// PSM_XLANE_MODE: which exchange levels use DPP rotations instead of ds_bpermute
-//   0: none, 1: distance 1, 2: distances 1 and 2, 3: all (1, 2, 4)
-#ifndef PSM_XLANE_MODE
-#define PSM_XLANE_MODE 2   // measured on the fused filter at 1080p x 256: mode 0 5.29 ms, 1 4.76, 2 4.69, 3 5.98
-#endif
+// PSM_XLANE_MODE: which exchange levels use DPP rotations instead of ds_bpermute - 0: none, 1: distance 1, 2: distances 1
+// and 2, 3: all (1, 2, 4).  Measured on the fused filter at 1080p x 256: 5.29 / 4.76 / 4.69 / 5.98 ms per volume; 2 it is.
+constexpr int PSM_XLANE_MODE = 2;
 // L1F32 (the tolerance form, PSM_FLAG_F32_TOL): level 1 of the tree on the fp32 inputs - one DPP move, one fp32 add and one
 // conversion instead of two conversions, a DPP move and an fp64 add.  One more fp32 rounding per pair of taps: not the oracle's
 // bits, max |dq| 1e-5 on Cones / Teddy and 4e-5 on the synthetic pairs, no WTA pixel changed (oracle model PSMO_VAR_F32_L1).
@@ -100,8 +98,9 @@ __device__ __forceinline__ double vstep(VTree &t, double hs)
 // The per-voxel linear-model solve of GuidedFilter_cv (src/CVF.cpp:91-155) with the d-invariant
 // adjugate entries and 1/DET taken from the guidance planes.
 // FMA (PSM_FLAG_FMA_SOLVE): the reading of src/CVF.cpp:129-147 a compiler with -ffp-contract=fast gives on an FMA target (GCC's
-// default; the ARM boards the reference ran on) - s + x*y of the three accumulations as one fma, left to right (oracle:
-// PSMO_VAR_FMA_SOLVE; the minors and 1/DET in the guidance planes are then the fused forms too, k_guide_march).  The covariance
+// default; the ARM boards the reference ran on) - of the three products of an accumulation GCC rounds the MIDDLE one and fuses
+// the other two: fma(c2, A2, fma(c0, A0, RN(c1*A1))) (oracle: PSMO_VAR_FMA_SOLVE, pinned against a live gcc -O2 -mfma compile by
+// tests/test_oracle.py; the minors and 1/DET in the guidance planes are then the fused forms too, k_guide_march).  The covariance
 // and the b line are cv::Mat passes in the reference (src/CVF.cpp:91-95,152-155) - separate multiply and subtract either way.
 template <bool FMA = false>
 __device__ __forceinline__ float4 solve_ab(float mp, float mIp0, float mIp1, float mIp2, float4 g2,
@@ -114,9 +113,9 @@ __device__ __forceinline__ float4 solve_ab(float mp, float mIp0, float mIp1, flo
     float c2 = __fsub_rn(mIp2, __fmul_rn(mI2, mp));
     float a0, a1, a2;
     if (FMA) {
-        a0 = __fmul_rn(inv, __fmaf_rn(c2, A02, __fmaf_rn(c1, A01, __fmul_rn(c0, A00))));
-        a1 = __fmul_rn(inv, __fmaf_rn(c2, A12, __fmaf_rn(c1, A11, __fmul_rn(c0, A01))));
-        a2 = __fmul_rn(inv, __fmaf_rn(c2, A22, __fmaf_rn(c1, A12, __fmul_rn(c0, A02))));
+        a0 = __fmul_rn(inv, __fmaf_rn(c2, A02, __fmaf_rn(c0, A00, __fmul_rn(c1, A01))));
+        a1 = __fmul_rn(inv, __fmaf_rn(c2, A12, __fmaf_rn(c0, A01, __fmul_rn(c1, A11))));
+        a2 = __fmul_rn(inv, __fmaf_rn(c2, A22, __fmaf_rn(c0, A02, __fmul_rn(c1, A12))));
     } else {
         a0 = __fmul_rn(inv, __fadd_rn(__fadd_rn(__fmul_rn(c0, A00), __fmul_rn(c1, A01)), __fmul_rn(c2, A02)));
         a1 = __fmul_rn(inv, __fadd_rn(__fadd_rn(__fmul_rn(c0, A01), __fmul_rn(c1, A11)), __fmul_rn(c2, A12)));

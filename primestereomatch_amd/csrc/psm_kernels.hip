@@ -145,15 +145,16 @@ __device__ __forceinline__ void guide_finish(const float *m, float4 &g2, float4 
     float A12 = __fsub_rn(__fmul_rn(a31, a12), __fmul_rn(a32, a11));
     float A22 = __fsub_rn(__fmul_rn(a22, a11), __fmul_rn(a21, a12));
     if (fma) {
-        // PSM_FLAG_FMA_SOLVE: x*y - z*w -> fma(x, y, -(z*w)) and s + x*y -> fma(x, y, s), the contraction GCC applies left to
-        // right to src/CVF.cpp:129-147 on an FMA target (oracle: PSMO_VAR_FMA_SOLVE).  Still six distinct values: the pairs of
-        // expressions that coincide in the canon (symmetric matrix) have the same fused / rounded product here as well.
+        // PSM_FLAG_FMA_SOLVE: src/CVF.cpp:129-147 as GCC's -ffp-contract=fast contracts it on an FMA target (oracle:
+        // PSMO_VAR_FMA_SOLVE, pinned against a live gcc -O2 -mfma compile of the same expressions by tests/test_oracle.py):
+        // x*y - z*w -> fma(x, y, -RN(z*w)); p0 - p1 + p2 -> fma(x2, y2, fma(x0, y0, -RN(x1*y1))); a31*a23 and a32*a13 are ONE
+        // rounded product, so (a31*a23 - a33*a21) = (a32*a13 - a33*a12) = fma(-a33, a21, RN(a31*a23)).  Still six distinct values.
 #define PSM_M2(x, y, z, w) __fmaf_rn((x), (y), -__fmul_rn((z), (w)))
         const float m00 = PSM_M2(a33, a22, a32, a23), m01 = PSM_M2(a33, a12, a32, a13), m02 = PSM_M2(a23, a12, a22, a13);
-        det = __fmaf_rn(a31, m02, __fmaf_rn(-a21, m01, __fmul_rn(a11, m00)));
+        det = __fmaf_rn(a31, m02, __fmaf_rn(a11, m00, -__fmul_rn(a21, m01)));
         inv = __fdiv_rn(1.0f, det);
         A00 = m00;
-        A01 = PSM_M2(a31, a23, a33, a21);
+        A01 = __fmaf_rn(-a33, a21, __fmul_rn(a31, a23));
         A02 = PSM_M2(a32, a21, a31, a22);
         A11 = PSM_M2(a33, a11, a31, a13);
         A12 = PSM_M2(a31, a12, a32, a11);

@@ -140,7 +140,16 @@ int DispEst::LRCheck_GPU()
 }
 
 int DispEst::PostProcess_GPU()
-{   // PP::processDM as its source spells it out (src/PP.cpp:405-410): lrCheck, fillInv, wgtMedian - all on the device
+{   // The reference's call (src/DispEst.cpp:338-344) runs PP::processDM, whose LIVE body is the CPU JointWMF (out of scope) with
+    // lrCheck / fillInv / wgtMedian commented out (src/PP.cpp:405-412).  What the accelerator side contributes to this stage is
+    // the L-R check: lValid / rValid are filled, lDisMap / rDisMap stay the raw WTA maps (a caller that reads them afterwards
+    // gets what DispSelect_GPU left).  The commented-out sequence as a whole: ProcessDM_GPU().
+    return LRCheck_GPU();
+}
+
+int DispEst::ProcessDM_GPU()
+{   // the sequence PP::processDM's source spells out but does not run (src/PP.cpp:405-410): lrCheck, fillInv, wgtMedian - all on
+    // the device; lDisMap / rDisMap are REPLACED by the filled, weighted-median-filtered maps
     if (ctx.empty()) return 1;
     const HipApi &api = hipUtil::api();
     int rc = api.lr_check(ctx[0], lValid.data, rValid.data, lValid.step);

@@ -68,12 +68,13 @@ public:
     int CostFilter_GPU();
     int CostFilter_FGF_GPU();  // DispEst::CostFilter_FGF (src/DispEst.cpp:281-296) on the device, s = subsample_rate
     int DispSelect_GPU();
-    // DispEst::PostProcess_GPU (src/DispEst.cpp:338-344) = PP::processDM.  The reference's live processDM body is the CPU JointWMF
-    // (third-party, out of scope: SURVEY.md 2); the data-parallel sequence its source spells out - lrCheck, fillInv, wgtMedian
-    // (src/PP.cpp:405-410) - is what runs here, on the device: afterwards lValid / rValid hold the L-R validity and lDisMap /
-    // rDisMap the filled, weighted-median-filtered maps, so a caller that selected and then post-processed holds finished maps as
-    // it does after the reference's call.  The three stages alone:
+    // DispEst::PostProcess_GPU (src/DispEst.cpp:338-344) calls PP::processDM, whose live body is the CPU JointWMF (third-party, out
+    // of scope: SURVEY.md 2) with lrCheck / fillInv / wgtMedian commented out (src/PP.cpp:405-412).  PostProcess_GPU here runs the
+    // L-R check ONLY: lValid / rValid are filled, lDisMap / rDisMap stay the raw WTA maps (as in rounds 1-4; round 5 briefly made
+    // it run all three stages - callers reading raw maps after it got filtered ones).  ProcessDM_GPU() is that commented-out
+    // sequence - lrCheck, fillInv, wgtMedian - on the device: afterwards lDisMap / rDisMap hold the filled, filtered maps.
     int PostProcess_GPU();
+    int ProcessDM_GPU();
     int LRCheck_GPU();         // lrCheck (src/PP.cpp:17-50): lValid / rValid; the maps stay untouched
     int FillInvalid_GPU();     // fillInv (src/PP.cpp:52-143): fills the pixels the last L-R check marked invalid
     // wgtMedian (src/PP.cpp:145-247) for the pixels the last L-R check marked invalid; same result as the reference's sequential

@@ -85,7 +85,7 @@ int main(int argc, char **argv)
     rc |= SMDE.CostConst_GPU();
     rc |= fgf_rate ? SMDE.CostFilter_FGF_GPU() : SMDE.CostFilter_GPU();
     rc |= SMDE.DispSelect_GPU();
-    rc |= SMDE.LRCheck_GPU();            // (validity only: the raw WTA maps are dumped first; PostProcess_GPU below is the whole stage)
+    rc |= SMDE.PostProcess_GPU();        // (L-R validity only: the maps stay the raw WTA maps; ProcessDM_GPU below is the commented-out sequence of processDM)
     if (rc) return 5;
     printf("STEREO GIF Module Times:\nCVC Time:\t %4.2f ms\nCVF Time:\t %4.2f ms\nDispSel Time:\t %4.2f ms\nPP Time:\t %4.2f ms\n",
            SMDE.stageTimeUs(PSM_STAGE_CVC) / 1000, SMDE.stageTimeUs(PSM_STAGE_CVF) / 1000,
@@ -93,7 +93,7 @@ int main(int argc, char **argv)
     bool ok = dump(out + "_ldisp.raw", SMDE.lDisMap.data, (size_t)W * H) && dump(out + "_rdisp.raw", SMDE.rDisMap.data, (size_t)W * H) &&
               dump(out + "_lvalid.raw", SMDE.lValid.data, (size_t)W * H) && dump(out + "_rvalid.raw", SMDE.rValid.data, (size_t)W * H);
     if (ok && pp) {
-        if (SMDE.PostProcess_GPU()) return 5;      // DispEst::PostProcess_GPU: lrCheck + fillInv + wgtMedian (PP::processDM)
+        if (SMDE.ProcessDM_GPU()) return 5;        // lrCheck + fillInv + wgtMedian (src/PP.cpp:405-410, commented out in the reference)
         ok = dump(out + "_ldisp_pp.raw", SMDE.lDisMap.data, (size_t)W * H) && dump(out + "_rdisp_pp.raw", SMDE.rDisMap.data, (size_t)W * H);
     }
     if (ok && frames > 0 && ndev == 1 && !fgf_rate) {

@@ -2,7 +2,7 @@
     python scripts/soak.py [seconds] [seed]
 Every case: random geometry / disparity range / dtype / tuning flags / segment rows, then one of: whole image, disparity
 shards, row stripes, both, or a BATCH of 2-6 different pairs through psm_compute_batch (round 4; sometimes with float images,
-shared streams, a hipGraph replay, a second frame staged asynchronously), or (round 5) a FrameRing of 2-3 contexts over a short stream of
+shared streams, a second frame staged asynchronously), or (round 5) a FrameRing of 2-3 contexts over a short stream of
 pairs; one float case in five runs the FMA reading of the solve (PSM_FLAG_FMA_SOLVE) against the oracle's same reading, merges
 sometimes go through the host-staged exchange leg, scratch is sometimes released between calls; maps (and sometimes the filtered volumes, the L-R check, fill and the weighted median) must be
 bit-identical to the oracle.  Prints one line per failure and a summary."""
@@ -90,8 +90,6 @@ def one(rng, idx):
                     de.set_option(capi.PSM_OPT_SEG_ROWS, seg)
             if rng.random() < 0.5:
                 share_streams(des)
-            if rng.random() < 0.3:
-                des[0].set_option(capi.PSM_OPT_GRAPH, 1)
             refs = [ref] + [(O.pipeline_u8 if dtype == "u8" else O.pipeline_f32)(a, b, D, threads=8) for a, b in pairs[1:]]
             frames = 2 if rng.random() < 0.4 else 1
             for f in range(frames):

@@ -8,6 +8,12 @@ import pytest
 from conftest import ROOT
 
 
+def _round_of(name):
+    rounds = sorted(d for d in os.listdir(os.path.join(ROOT, "profiles")) if d.startswith("r") and d[1:].isdigit())
+    have = [d for d in rounds if os.path.exists(os.path.join(ROOT, "profiles", d, name))]
+    return have[-1] if have else "r01"
+
+
 def _line(name):
     rounds = sorted(d for d in os.listdir(os.path.join(ROOT, "profiles")) if d.startswith("r") and d[1:].isdigit())
     have = [d for d in rounds if os.path.exists(os.path.join(ROOT, "profiles", d, name))]
@@ -32,7 +38,10 @@ def test_headline_line_has_the_contract_keys():
     r = j["roofline"]
     for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
         assert k in r, k
-    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
+    # achieved / peak / frac: the HBM figures on SURVEY 8d's algorithmic bytes.  `bound` names what binds: "hbm", or - from round 6
+    # on, for the fused select kernel - "valu", in agreement with `binding` (the round-5 verdict's item 9)
+    assert r["bound"] in ("hbm", "valu") and r["unit"] == "GB/s" and r["peak"] == 8000.0
+    assert r.get("binding", r["bound"]) == r["bound"] or "r05" >= _round_of("bench_c4_n1.json")
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
     assert abs(r["achieved"] - r["alg_bytes_per_launch"] / (r["avg_launch_ms"] * 1e-3) / 1e9) / r["achieved"] < 1e-3
     assert r["traffic"] is None or r["traffic"] > 0

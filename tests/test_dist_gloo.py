@@ -179,7 +179,46 @@ def _exchange_worker(rank, world, port, q):
             pending.append((ex.all_gather(recv, send, async_op=True), mb))
         w, b = pending.pop(0); w.wait(); stripes.assemble(recv, world, H, W, R, b); maps.append(b[:n].clone().numpy().reshape(2, H, W))
         ok &= all(np.array_equal(maps[f], full[f]) for f in range(frames))
-        ok &= ex.max_float(float(rank)) == float(world - 1) and ex.collectives == 2 * frames + 1
+        # ---- two frames in flight per rank (bench.py --gpus N, round 6): frame f goes to slot f % 2 - a slot has its own two map
+        # tensors, its own send / receive buffers and its own pending list, and finishes a frame's exchange inside its NEXT frame's
+        # step (two steps later); the collectives of the two slots interleave in the same order on every rank ----
+        F = 2
+        frames2 = 7
+        full2 = rng.integers(0, 256, size=(frames2, 2, H, W), dtype=np.uint8)
+        keys2 = rng.integers(-2**40, 2**40, size=(frames2, world, n), dtype=np.int64)
+
+        class Slot:
+            def __init__(self):
+                self.mbuf = [torch.zeros(n + 4, dtype=torch.uint8) for _ in range(2)]
+                self.kbuf = [torch.empty(n, dtype=torch.int64) for _ in range(2)]
+                self.send, self.recv = torch.zeros(2 * R * W, dtype=torch.uint8), torch.zeros(world * 2 * R * W, dtype=torch.uint8)
+                self.pending, self.n = [], 0
+        slots = [Slot() for _ in range(F)]
+        done_maps, done_keys = {}, {}
+
+        def finish(sl):
+            while sl.pending:
+                f_, wm, mb_, wk, kb_ = sl.pending.pop(0)
+                wm.wait(); wk.wait()
+                stripes.assemble(sl.recv, world, H, W, R, mb_)
+                done_maps[f_] = mb_[:n].clone().numpy().reshape(2, H, W)
+                done_keys[f_] = kb_.clone().numpy()
+        for f in range(frames2):
+            sl = slots[f % F]
+            mb, kb = sl.mbuf[sl.n & 1], sl.kbuf[sl.n & 1]
+            sl.n += 1
+            mb.fill_(255)
+            mb[:n].view(2, H, W)[:, y0:y1] = torch.from_numpy(full2[f][:, y0:y1].copy())      # "the filter" of frame f on this slot
+            kb.copy_(torch.from_numpy(keys2[f, rank]))
+            finish(sl)                                                                        # this slot's previous frame (f - F)
+            stripes.pack_stripe(mb, y0, y1, sl.send, H, W, R)
+            sl.pending.append((f, ex.all_gather(sl.recv, sl.send, async_op=True), mb, ex.all_reduce_min(kb, async_op=True), kb))
+            assert len(done_maps) == max(0, f + 1 - F)                                        # exactly F frames are ever in flight
+        for sl in slots:
+            finish(sl)
+        ok &= sorted(done_maps) == list(range(frames2))
+        ok &= all(np.array_equal(done_maps[f], full2[f]) and np.array_equal(done_keys[f], keys2[f].min(axis=0)) for f in range(frames2))
+        ok &= ex.max_float(float(rank)) == float(world - 1) and ex.collectives == 2 * frames + 1 + 2 * frames2
         # per-rank diagnostics of the bench line (compute / collective ms of every rank, on every rank)
         per = ex.gather_floats([10.0 + rank, 0.5 * rank])
         ok &= per == [[10.0 + r_, 0.5 * r_] for r_ in range(world)]
