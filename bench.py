@@ -138,6 +138,10 @@ def parse_args():
     ap.add_argument("--shard", default="rows", choices=["rows", "disp"],
                     help="N > 1: what a rank owns in the headline measurement - 'rows': a stripe of H/N output rows of both volumes, "
                          "all D slices; 'disp': D/N slices of both volumes, whole image.  The other axis is timed as alt_shard")
+    ap.add_argument("--strided", action="store_true",
+                    help="--shard disp (and the alt_shard record of a rows run): rank g owns the slices d = g (mod N) instead of the contiguous "
+                         "range [D g / N, D (g + 1) / N) - psm_create_shard_strided; its slices span the whole disparity range, so the two-phase "
+                         "selection's seeds bound every pixel")
     ap.add_argument("--no-alt-shard", action="store_true", help="N > 1: do not time the other sharding axis")
     ap.add_argument("--lr-check", type=int, default=-1, choices=[-1, 0, 1],
                     help="PP left-right check on the GPU inside the step (BASELINE configs[4]); -1: on for config c5 only")
@@ -308,8 +312,13 @@ def main():
             d0, d1 = 0, D // args.shard_sim
         else:
             d0, d1 = 0, D
+        strided = None
+        if args.strided and not rows_mode and (use_dist or args.shard_sim > 1):
+            strided = (rank, world) if use_dist else (0, args.shard_sim)
+            d0, d1 = strided[0], D
+
         def new_ctx(pl_=l, pr_=r, dr=(d0, d1)):
-            o_ = P.DispEst(pl_, pr_, D, 8, True, device=dev_index, d_range=dr, dtype=dtype)
+            o_ = P.DispEst(pl_, pr_, D, 8, True, device=dev_index, d_range=dr, dtype=dtype, d_stride=(strided if dr == (d0, d1) else None))
             if args.seg_rows >= 0:
                 o_.set_option(capi.PSM_OPT_SEG_ROWS, args.seg_rows)
             o_.set_option(capi.PSM_OPT_KERNEL_VARIANT, args.variant)
@@ -566,7 +575,9 @@ def main():
             for _ in ring:
                 step()
             sync()                               # (leave every context as a complete step does: final maps of this pair)
-        rec["geometry"] = {"rows": [y0, y1], "slices": [d0, d1], "rows_max": rows_max, "parts": parts, "rows_mode": rows_mode}
+        nsl = len(range(strided[0], D, strided[1])) if strided else d1 - d0
+        rec["geometry"] = {"rows": [y0, y1], "slices": [d0, d1], "n_slices": nsl, "strided": list(strided) if strided else None,
+                           "rows_max": rows_max, "parts": parts, "rows_mode": rows_mode}
         rec["sync"], rec["step"], rec["de"], rec["batch_all"] = sync, step, de, batch_all + ring[1:]
         rec["ring"] = ring
         return rec
@@ -599,7 +610,7 @@ def main():
         for _ in head["ring"]:
             step()
     geo = head["geometry"]
-    (y0, y1), (d0, d1), rows_mode = geo["rows"], geo["slices"], geo["rows_mode"]
+    (y0, y1), (d0, d1), rows_mode, n_slices = geo["rows"], geo["slices"], geo["rows_mode"], geo["n_slices"]
     ms_per_step, value = head["ms_per_step"], head["value"]
 
     # ---- the maps the timed region left on the device (before anything else runs on this context) ----
@@ -738,7 +749,7 @@ def main():
         algb["cvf_fgf"], algb["wta"], pipe_alg = 60.0 / s2_, 8.0 + 16.0 / s2_, 12.0 + 76.0 / s2_
     dom = max(("cvf_fgf", "wta") if args.fgf else ("cvf_fused", "cvf_a"), key=lambda k: kern.get(k, {"avg_ms": 0})["avg_ms"])
     lps = max(1, round(kern[dom]["launches_per_step"]))
-    vox_per_launch = 2.0 * W * (y1 - y0) * (d1 - d0) * B / lps                    # (this rank's rows and slices; all pairs of a batch)
+    vox_per_launch = 2.0 * W * (y1 - y0) * n_slices * B / lps                    # (this rank's rows and slices; all pairs of a batch)
     dom_ms = kern[dom]["avg_ms"]
     achieved = algb[dom] * vox_per_launch / (dom_ms * 1e-3) / 1e9
     two_phase = select_mode and "keys" in fl and "planes" in fl
@@ -939,7 +950,8 @@ def main():
                 o_ = P.DispEst(l, r, D, 8, True, device=dev_index, dtype=dtype)
                 o_.set_rows(ya, yb)
             else:
-                o_ = P.DispEst(l, r, D, 8, True, device=dev_index, d_range=(D * g_ // G, D * (g_ + 1) // G), dtype=dtype)
+                o_ = P.DispEst(l, r, D, 8, True, device=dev_index, d_range=(D * g_ // G, D * (g_ + 1) // G), dtype=dtype,
+                               d_stride=((g_, G) if args.strided else None))
             if args.flags >= 0:
                 o_.set_option(capi.PSM_OPT_FLAGS, args.flags)
             o_.CostConst_GPU()
@@ -1052,7 +1064,7 @@ def main():
                                        if rows_mode else f"D sharded over {world} ranks + 1 {xname} {exchange} of packed minima"),
                        "kernel_variant": args.variant, "shard_sim": args.shard_sim, "lr_check_on_gpu": bool(lrc),
                        "shard": head["shard"], "batch": B, "ranks": world, "same_device": bool(args.same_device),
-                       "frames_in_flight": len(head["ring"]),
+                       "frames_in_flight": len(head["ring"]), "strided_disparity_shards": bool(geo["strided"]),
                        "exchange_backend": (backend if use_dist else None)},
             "roofline": roofline, "cpu_baseline": cpu, "kernels": kern,
             "kernels_sum_ms_per_step": round(kernels_sum, 4), "kernels_sum_le_step": bool(kernels_sum <= ms_per_step * 1.005),

@@ -123,6 +123,16 @@ int psm_create(psm_ctx **out, int width, int height, int max_disp, int dtype, in
  * max_disp. */
 int psm_create_shard(psm_ctx **out, int width, int height, int max_disp, int d_begin, int d_end,
                      int dtype, int device);
+/* The same job cut the other way (round 6): this context holds the slices d_first, d_first + d_step, d_first + 2 d_step, ... <
+ * max_disp of both volumes - rank g of G owns d = g (mod G).  A rank's slices then span the whole disparity range, so the
+ * slices that seed its key plane bound EVERY pixel's minimum and the two-phase selection works on a shard as it does on the
+ * whole volume (a contiguous shard's seeds bound little: most pixels' minima lie in other ranks' slices).  The merge
+ * (psm_disp_merge / psm_disp_merge_ctx: a signed minimum of packed keys) does not care how the slices were dealt
+ * (DispSel::CVSelect, src/DispSel.cpp:96-104, is a minimum over d in any order with ties to the lowest d).  Such a context
+ * runs the default select path only: CostConst / CostFilter / psm_disp_select_partial; everything that reads or writes a
+ * volume refuses it.  0 <= d_first < max_disp, d_step >= 1 (1: the contiguous shard [d_first, max_disp)). */
+int psm_create_shard_strided(psm_ctx **out, int width, int height, int max_disp, int d_first, int d_step,
+                             int dtype, int device);
 
 /* Releases everything the context owns (DispEst::~DispEst, src/DispEst.cpp:143-162). */
 void psm_destroy(psm_ctx *ctx);

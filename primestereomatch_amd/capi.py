@@ -35,6 +35,7 @@ SYMBOLS = [
     ("psm_device_count", _i, []),
     ("psm_create", _i, [C.POINTER(_vp), _i, _i, _i, _i, _i]),
     ("psm_create_shard", _i, [C.POINTER(_vp), _i, _i, _i, _i, _i, _i, _i]),
+    ("psm_create_shard_strided", _i, [C.POINTER(_vp), _i, _i, _i, _i, _i, _i, _i]),
     ("psm_destroy", None, [_vp]),
     ("psm_last_error", C.c_char_p, [_vp]),
     ("psm_set_option", _i, [_vp, _i, _i]),

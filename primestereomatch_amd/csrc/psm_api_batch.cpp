@@ -25,7 +25,7 @@ extern "C" int psm_compute_batch(psm_ctx *const *ctxs, int n)
             return fail(c0, "psm_compute_batch: context %d has another geometry / type / device than context 0", i);
         if (c->opt_variant != 0 || (c->march.flags & (PSM_FLAG_STORE_FILTERED | PSM_FLAG_MATERIALISE_COSTS)))
             return fail(c0, "psm_compute_batch: context %d asks for a storing form (the batch runs the default select path)", i);
-        if (c->march.flags != c0->march.flags || c->march.seg_rows != c0->march.seg_rows)
+        if (c->march.flags != c0->march.flags || c->march.seg_rows != c0->march.seg_rows || c->march.dstep != c0->march.dstep)
             return fail(c0, "psm_compute_batch: context %d has other options than context 0", i);
         // the batched launches exist in the bit-exact form only: a silently ignored flag would break "same maps as the three
         // single-pair calls" (which DO run the tolerance form with this flag)

@@ -304,6 +304,20 @@ int psm_create_shard(psm_ctx **out, int width, int height, int max_disp, int d_b
     return 0;
 }
 
+int psm_create_shard_strided(psm_ctx **out, int width, int height, int max_disp, int d_first, int d_step, int dtype, int device)
+{
+    if (!out) return fail(nullptr, "psm_create: out is NULL");
+    *out = nullptr;
+    if (d_step < 1 || d_first < 0 || d_first >= max_disp) return fail(nullptr, "psm_create: bad strided slice set (first %d, step %d, of %d)", d_first, d_step, max_disp);
+    const int n = (max_disp - d_first + d_step - 1) / d_step;          // d_first, d_first + d_step, ... < max_disp
+    // (created as the contiguous shard of the same slice COUNT - the buffers depend on nothing else -, then re-labelled)
+    if (psm_create_shard(out, width, height, max_disp, d_first, d_first + n, dtype, device)) return 1;
+    psm_ctx *c = *out;
+    c->march.dstep = d_step;
+    c->d1 = d_first + (n - 1) * d_step + 1;
+    return 0;
+}
+
 int psm_create(psm_ctx **out, int width, int height, int max_disp, int dtype, int device)
 {
     return psm_create_shard(out, width, height, max_disp, 0, max_disp, dtype, device);
@@ -541,6 +555,7 @@ int psm_upload_volume(psm_ctx *c, int side, int d0, int d1, const void *host)
 {
     if (!c || !host) return 1;
     if (check_slices(c, "psm_upload_volume", side, d0, d1)) return 1;
+    PSM_NOT_STRIDED(c, "psm_upload_volume");
     if (bind(c)) return 1;
     // a partial upload must not leave virtual slices behind: whatever of this side exists only as a recipe (lazy costs - also
     // after a striped psm_cost_construct, which leaves have_g1 false -, packed minima, FGF models) becomes real data first

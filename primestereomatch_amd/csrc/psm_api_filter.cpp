@@ -185,6 +185,7 @@ namespace psm {
 // make sure the whole volume of `side` (unfiltered, or filtered by psm_cost_filter / psm_cost_filter_fgf) is in memory
 int materialize(psm_ctx *c, int side)
 {
+    PSM_NOT_STRIDED(c, "materialising a cost volume");
     if (fgf_flush(c, side)) return 1;
     if ((c->gf_virtual[side] || c->raw_rows[side] != psm_ctx::RAW_ALL) && ensure_whole_planes(c)) return 1;
     if (c->dtype == PSM_U8) {
@@ -231,6 +232,7 @@ namespace {
 // form, the direct variant and for stage A alone.
 int filter_side(psm_ctx *c, int side, bool stage_b)
 {
+    PSM_NOT_STRIDED(c, "filtering one side / a materialised volume / the storing form");
     c->maps_early = nullptr;
     const size_t V = (size_t)c->W * c->H * c->Dloc;
     const int W = c->W, H = c->H;
@@ -414,6 +416,7 @@ int psm_cost_construct(psm_ctx *c)
                       (c->dtype == PSM_F32 || !(c->march.flags & PSM_FLAG_STORE_FILTERED));
     // CVC::preprocess belongs to this stage (src/DispEst.cpp:232-233).  A row stripe [y0, y1) with lazy costs reads the image
     // planes of rows y0 - 8 .. y1 + 7 only (costs of the model rows y0 - 4 .. y1 + 2, +- 4 for their box sums, and the guidance)
+    if (!lazy) PSM_NOT_STRIDED(c, "psm_cost_construct with materialised costs");
     const bool striped = c->march.yend > c->march.ybeg;
     if (striped && lazy ? run_prep(c, c->march.ybeg - 8, c->march.yend + 8) : run_prep(c)) return 1;
     if (c->ev_free) PSM_HIP(c, hipEventRecord(c->ev_free, c->stream));   // the staged images have been read: their slot may be refilled
@@ -494,6 +497,7 @@ int psm_cost_filter_fgf(psm_ctx *c, int sub)
     if (!c->have_images) return fail(c, "psm_cost_filter_fgf: no image pair uploaded (guidance)");
     // (the low-resolution models of a stripe would need their own halo arithmetic; a striped host filters whole images here)
     if (c->march.yend > c->march.ybeg) return fail(c, "psm_cost_filter_fgf: row stripes (psm_set_rows) are not supported by the Fast Guided Filter path");
+    PSM_NOT_STRIDED(c, "psm_cost_filter_fgf");
     const int ws = c->W / sub, hs = c->H / sub, rad = 8 / sub;
     if (ws <= rad || hs <= rad) return fail(c, "psm_cost_filter_fgf: %dx%d too small for subsample_rate %d", c->W, c->H, sub);
     if (bind(c)) return 1;

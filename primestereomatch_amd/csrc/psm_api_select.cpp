@@ -322,7 +322,7 @@ int psm_disp_merge_ctx(psm_ctx *root, psm_ctx *const *shards, int nshards, uint8
             return fail(root, "psm_disp_merge_ctx: shard %d has no partial minima for this frame (call psm_disp_select_partial(ctx, NULL) first)", i);
         if (s->have_rows != shards[0]->have_rows || (s->have_rows && (s->rows_y0 != shards[0]->rows_y0 || s->rows_y1 != shards[0]->rows_y1)))
             return fail(root, "psm_disp_merge_ctx: shard %d was filtered under another row stripe than shard 0", i);
-        for (int d = s->d0; d < s->d1; ++d) {
+        for (int d = s->d0; d < s->d1; d += s->march.dstep) {       // (a strided shard holds d0, d0 + dstep, ...)
             if (covered[d]) return fail(root, "psm_disp_merge_ctx: slice %d is held by more than one shard", d);
             covered[d] = 1;
         }

@@ -217,6 +217,12 @@ int range_enqueue(psm_ctx *c, hipStream_t stream, int slot, const float *p0, siz
 bool range_inside(const psm_ctx *c, int slot, int lo_exp, int hi_exp);     // after the stream has been synchronised
 // PSM_FLAG_FMA_SOLVE applies to float mode only (8-bit contexts never carry the bit: psm_set_option)
 inline bool fma_solve(const psm_ctx *c) { return c->dtype == PSM_F32 && (c->march.flags & PSM_FLAG_FMA_SOLVE) != 0; }
+// psm_create_shard_strided: the slices of such a context exist in the select forms of the fused kernel only
+inline bool strided(const psm_ctx *c) { return c->march.dstep != 1; }
+#define PSM_NOT_STRIDED(c, what)                                                                                               \
+    do {                                                                                                                        \
+        if (psm::strided(c)) return psm::fail((c), "%s: a strided disparity shard (psm_create_shard_strided) runs the default select path only", (what)); \
+    } while (0)
 inline bool scaled_forms_ok(const psm_ctx *c) { return c->img_domain_ok && c->vol_domain_ok[0] && c->vol_domain_ok[1]; }
 constexpr int PSM_IMG_EXP = 10, PSM_VOL_EXP = 60;
 constexpr size_t PSM_COPY_KERNEL_MAX = (size_t)2 << 20;     // asynchronous PCIe legs up to this size go through k_copy16 instead of the copy engines

@@ -22,6 +22,7 @@ struct March {       // geometry of the marching kernels
     int seg_rows;    // output rows per y-segment (0 = auto)
     int waves;       // waves (= disparity slices) per workgroup: 1,2,4,8
     int flags;       // PSM_OPT_FLAGS (include/primesm_hip.h)
+    int dstep = 1;            // psm_create_shard_strided: local slice i is the global disparity d_begin + i * dstep (select forms only)
     int inflight = 1;         // PSM_OPT_FRAMES_IN_FLIGHT: pairs other contexts filter at the same time on their own streams (a planning hint only)
     int ybeg = 0, yend = 0;   // row stripe of the select-form filter (psm_set_rows): output rows [ybeg, yend) of the whole
                               // image; yend <= ybeg: all rows

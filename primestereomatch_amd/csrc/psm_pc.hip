@@ -68,7 +68,11 @@ template <> struct PcLayout<2, true> : PcLayout<1, true> {};
 constexpr int PC_K_LD_AUX = 0;     // cache policy of MODE 1's record loads.  A record is only ever read by the lane that wrote it
                                    // (one slice earlier), and a thread always observes its own stores: plain cached loads are
                                    // coherent here.  (16 = sc1 bypasses the L2 as well: measured 25 % slower kernel.)
-constexpr int PC_KEY_LD_AUX = 16;  // cache policy of MODE 2's key loads: 16 = sc1 (agent scope: never from this CU's L1)
+// cache policy of MODE 2's key loads.  A stale key only costs a redundant atomic (the atomicMin decides), so the loads need not be
+// device-coherent: 1 = sc0 - served by the XCD's L2, never by this CU's L1.  Round 6, same box, 16 (sc1: always from the memory
+// side, rounds 2-5) / 0 / 1: 1280 x 720 x 128 1.785 / 1.743 / 1.745 ms, 1920 x 1080 x 256 6.751 / 6.758 / 6.743, 3840 x 2160 x 256
+// 27.38 / 27.37 / 27.25 (profiles/r06/exp_key_load_policy.txt) - and the key plane's share of the fabric traffic at 4K goes away.
+constexpr int PC_KEY_LD_AUX = 1;
 
 typedef unsigned pc_u2 __attribute__((ext_vector_type(2)));
 typedef unsigned pc_u4 __attribute__((ext_vector_type(4)));
@@ -122,6 +126,7 @@ struct PcSel {
     int spread;    // key form: dispatch the slices of a pair in `spread` interleaved passes (0 / 1: ascending)
     int n;         // ... over n slices
     unsigned long long rec_total;   // BATCH launches: float4 cost records per side in a pair's scratch (the disparities follow them)
+    int dstep;     // global disparity of local slice i: d_begin + i * dstep (1: a contiguous range; psm_create_shard_strided: the rank count)
 };
 __device__ __forceinline__ int pc_slice(const PcSel &o, int i)
 {
@@ -262,7 +267,7 @@ void k_cvf_pc(
         const int xac = xa < 0 ? 0 : (xa > W - 1 ? W - 1 : xa);
         const bool mvalid = lane < PC_OUT_A;
         const float *vd = vin + (size_t)pc_slice(dyn, d) * HW;
-        const int dg = d_begin + pc_slice(dyn, d);    // global disparity of this slice
+        const int dg = d_begin + dyn.dstep * pc_slice(dyn, d);    // global disparity of this slice
         // buildCV_left: partner x-d while x >= d; buildCV_right: partner x+d while x < W-d (src/CVC.cpp:135-146,165-176)
         const bool inb = right ? (ci < W - dg) : (ci >= dg);
         const int cpart = right ? min(ci + dg, W - 1) : max(ci - dg, 0);
@@ -433,7 +438,7 @@ void k_cvf_pc(
     }
         const __amdgpu_buffer_rsrc_t rG1 = pc_rsrc(G1, (unsigned)HW * 16u);
         const int vxb = xbc * 16;
-        const int dg = d_begin + pc_slice(dyn, d);
+        const int dg = d_begin + dyn.dstep * pc_slice(dyn, d);
         const bool lane_out = lane < bwidth && xb < W;   // this lane owns an output pixel
 #define PSM_ISSUE_PB(SLOT, J)                                                           \
     {                                                                                   \
@@ -757,7 +762,7 @@ void launch_cvf_fused(hipStream_t s, March m, const float *vin, float *vout, Gui
 #define PSM_LAUNCH_PC(V4, CV, VR)                                                                                          \
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_cvf_pc<V4, CV, 0, false, false, VR>), grid, blk, 0, s, vin, vout, (const float4 *)gd.g1, \
                        (const float4 *)gd.g2, (const float4 *)gd.g3, (const float2 *)gd.g4, W, H, Dloc, pl.ngroups, pl.nsegs, \
-                       pl.seg_rows, ybeg, yend, g1_other, d_begin, 1, (float *)nullptr, (unsigned *)nullptr, 0, PcSide{}, PcSel{0, 1, pl.nxcd, 0, Dloc, 0}, ts, (const PcPair *)nullptr)
+                       pl.seg_rows, ybeg, yend, g1_other, d_begin, 1, (float *)nullptr, (unsigned *)nullptr, 0, PcSide{}, PcSel{0, 1, pl.nxcd, 0, Dloc, 0, 1}, ts, (const PcPair *)nullptr)
 #define PSM_LAUNCH_PCV(V4, CV) { if (m.flags & PSM_FLAG_FMA_SOLVE) PSM_LAUNCH_PC(V4, CV, 2); else PSM_LAUNCH_PC(V4, CV, 0); }
     const bool v4 = (W & 3) == 0;
     if (cvc_mode == 1) { if (v4) PSM_LAUNCH_PCV(true, 1) else PSM_LAUNCH_PCV(false, 1) }
@@ -773,7 +778,7 @@ void launch_cvf_select(hipStream_t s, March m, const float *vin, Guidance gd, in
                        int d_begin, int cvc_mode, void *scratch, unsigned long long *ts, const uint8_t *p4_own, const uint8_t *p4_other)
 {
     const PcPlan pl = pc_plan(W, m.rows(H), Dloc, m.seg_rows, PC_PLANES);
-    const PcSel sel = {0, 1, pl.nxcd, 0, Dloc, 0};
+    const PcSel sel = {0, 1, pl.nxcd, 0, Dloc, 0, 1};
     float *kcost = (float *)scratch;                                           // nchunks * rec_per_chunk float4
     unsigned *kdisp = (unsigned *)(kcost + 4 * pl.rec_per_chunk * pl.nchunks);  // nchunks * rec_per_chunk uchar4
     const dim3 grid(pc_blocks(pl, pl.nchunks)), blk(64 * (PcLayout<1>::NA + PcLayout<1>::NB));
@@ -810,7 +815,7 @@ void launch_cvf_select2(hipStream_t s, March m, const Guidance *g, int W, int H,
 {
     const bool tol = !p4 && (m.flags & PSM_FLAG_F32_TOL), fma = !p4 && (m.flags & PSM_FLAG_FMA_SOLVE);
     const PcPlan pl = pc_plan(W, m.rows(H), Dloc, m.seg_rows, PC_PLANES | PC_BOTH, 1, m.inflight);
-    const PcSel ps = {sel, step, pl.nxcd, 0, Dloc, 0};
+    const PcSel ps = {sel, step, pl.nxcd, 0, Dloc, 0, m.dstep};
     float *kcost0 = (float *)scratch;
     unsigned *kdisp0 = (unsigned *)(kcost0 + 4 * pl.rec_per_chunk * pl.nchunks);
     float *kcost1 = (float *)((char *)scratch + pl.scratch_bytes());
@@ -848,7 +853,7 @@ void launch_cvf_select_keys2(hipStream_t s, March m, const Guidance *g, int W, i
                              unsigned long long *ts, const uint8_t *const *p4, int init, int sel, int step)
 {
     const PcPlan pl = pc_plan(W, m.rows(H), Dloc, m.seg_rows, PC_KEYS | PC_BOTH, 1, m.inflight);
-    const PcSel ps = {sel, step, pl.nxcd, PSM_KNOB("PSM_PC_SPREAD", PC_KEY_SPREAD), Dloc, 0};
+    const PcSel ps = {sel, step, pl.nxcd, PSM_KNOB("PSM_PC_SPREAD", PC_KEY_SPREAD), Dloc, 0, m.dstep};
     const size_t HW = (size_t)W * H;
     if (init) hipLaunchKernelGGL(k_fill_keys, dim3((unsigned)((2 * HW + 255) / 256)), dim3(256), 0, s, keys, 2 * HW);
     const dim3 grid(pc_blocks(pl, Dloc), 2), blk(pl.narrow ? 64 * (PcLayout<2, true>::NA + PcLayout<2, true>::NB) : 64 * (PcLayout<2>::NA + PcLayout<2>::NB));
@@ -872,7 +877,7 @@ void launch_cvf_select2_batch(hipStream_t s, March m, const PcPair *tab, int npa
                               unsigned long long *ts, bool u8, int sel, int step)
 {
     const PcPlan pl = pc_plan(W, m.rows(H), Dloc, m.seg_rows, PC_PLANES | PC_BOTH, npairs);
-    const PcSel ps = {sel, step, pl.nxcd, 0, Dloc, (unsigned long long)pl.rec_per_chunk * pl.nchunks};
+    const PcSel ps = {sel, step, pl.nxcd, 0, Dloc, (unsigned long long)pl.rec_per_chunk * pl.nchunks, m.dstep};
     const dim3 grid(pc_blocks(pl, pl.nchunks), 2, npairs), blk(pl.narrow ? 64 * (PcLayout<1, true>::NA + PcLayout<1, true>::NB) : 64 * (PcLayout<1>::NA + PcLayout<1>::NB));
 #define PSM_LAUNCH_PCB(U8V) { if (pl.narrow) PSM_LAUNCH_PCBN(U8V, true); else PSM_LAUNCH_PCBN(U8V, false); }
 #define PSM_LAUNCH_PCBN(U8V, NW)                                                                                              \
@@ -897,7 +902,7 @@ void launch_cvf_select_keys2_batch(hipStream_t s, March m, const PcPair *tab, in
                                    unsigned long long *ts, bool u8, int sel, int step)
 {
     const PcPlan pl = pc_plan(W, m.rows(H), Dloc, m.seg_rows, PC_KEYS | PC_BOTH, npairs);
-    const PcSel ps = {sel, step, pl.nxcd, PC_KEY_SPREAD, Dloc, 0};
+    const PcSel ps = {sel, step, pl.nxcd, PC_KEY_SPREAD, Dloc, 0, m.dstep};
     const dim3 grid(pc_blocks(pl, Dloc), 2, npairs), blk(pl.narrow ? 64 * (PcLayout<2, true>::NA + PcLayout<2, true>::NB) : 64 * (PcLayout<2>::NA + PcLayout<2>::NB));
 #define PSM_LAUNCH_PCB(U8V) { if (pl.narrow) PSM_LAUNCH_PCBN(U8V, true); else PSM_LAUNCH_PCBN(U8V, false); }
 #define PSM_LAUNCH_PCBN(U8V, NW)                                                                                              \

@@ -27,7 +27,7 @@ def _ptr(a):
 
 class DispEst:
     def __init__(self, l, r, d: int, t: int = 8, ocl: bool = True, *, dtype: str = "f32",
-                 device: int = 0, d_range=None):
+                 device: int = 0, d_range=None, d_stride=None):
         """l, r: H x W x 3 images (uint8 as loaded by imread, or float32 scaled by 1/255 as
         StereoMatch::compute hands them over, src/StereoMatch.cpp:193-198); d: maxDis;
         t: host threads (kept for interface parity; unused by the GPU path); ocl: must be true
@@ -53,8 +53,14 @@ class DispEst:
         self.options = {}
         d0, d1 = (0, self.maxDis) if d_range is None else (int(d_range[0]), int(d_range[1]))
         self.d_begin, self.d_end = d0, d1
-        rc = self._lib.psm_create_shard(C.byref(self._h), self.wid, self.hei, self.maxDis, d0, d1,
-                                        self._dtype, int(device))
+        if d_stride is not None:
+            # strided ownership (psm_create_shard_strided): this object holds the slices d_stride[0], + d_stride[1], ... < maxDis
+            self.d_begin, self.d_end = int(d_stride[0]), self.maxDis
+            rc = self._lib.psm_create_shard_strided(C.byref(self._h), self.wid, self.hei, self.maxDis, int(d_stride[0]), int(d_stride[1]),
+                                                    self._dtype, int(device))
+        else:
+            rc = self._lib.psm_create_shard(C.byref(self._h), self.wid, self.hei, self.maxDis, d0, d1,
+                                            self._dtype, int(device))
         if rc != 0:
             self._h = C.c_void_p()
             raise capi.PsmError("DispEst: " + capi.last_error(None))

