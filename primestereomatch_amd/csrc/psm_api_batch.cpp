@@ -53,7 +53,7 @@ extern "C" int psm_compute_batch(psm_ctx *const *ctxs, int n)
 
     // ---- plan and scratch (before any launch: growing a scratch buffer synchronises its context's stream) ----
     const bool two_phase = !(c0->march.flags & PSM_FLAG_TWO_PHASE_OFF) && Dloc >= 2 && (Dloc >= 112 || (c0->march.flags & PSM_FLAG_TWO_PHASE_ON));
-    const int S = pc_seed_stride(W, H);
+    const int S = pc_seed_stride(W, H, c0->dtype == PSM_U8);
     const int n1 = two_phase ? (Dloc + S - 1) / S : Dloc, n2 = Dloc - n1;
     const PcPlan pl = pc_plan(W, H, n1, c0->march.seg_rows, PC_PLANES | PC_BOTH, n);
     for (int i = 0; i < n; ++i)

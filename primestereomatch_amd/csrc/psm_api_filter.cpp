@@ -355,12 +355,11 @@ int filter_both(psm_ctx *c)
     // 720p x 128, worse at 64 slices and below; PSM_FLAG_TWO_PHASE_ON / _OFF force it for any Dloc >= 2 / disable it): every
     // S-th slice goes through the minima planes -> k_chunk_min -> keys; the other slices then run against that seeded key
     // plane (key form: one key load per voxel, an atomic only where a slice beats the current minimum - rare after the
-    // seeding), so they write no planes and need no reduction.  S = 5, 4 from 4 Mpixel up (measured, S = 4 / 5 / 6: 1080p x
-    // 256 7.60 / 7.20-7.36 / 7.43-7.60 ms, 4K x 256 28.6-29.4 / 30.0-30.8 / 29.6-30.4, 720p x 128 1.97 / 1.90 / 1.90, 1/8
-    // stripe of 1080p 1.08 / 1.10 / 1.10: the optimum moves with how the two launches fill their rounds of workgroups).
+    // seeding), so they write no planes and need no reduction.  S = pc_seed_stride: 8 since round 6 (5, and 4 from 4 Mpixel up,
+    // while the key loads came from the memory side).
     const bool two_phase = !(c->march.flags & PSM_FLAG_TWO_PHASE_OFF) && c->Dloc >= 2 && (c->Dloc >= 112 || (c->march.flags & PSM_FLAG_TWO_PHASE_ON));
     if (two_phase) {
-        const int S = pc_seed_stride(c->W, c->H);
+        const int S = pc_seed_stride(c->W, c->march.rows(c->H), c->dtype == PSM_U8);
         const int n1 = (c->Dloc + S - 1) / S, n2 = c->Dloc - n1;
         const PcPlan pl1 = pc_plan(c->W, c->march.rows(c->H), n1, c->march.seg_rows, PC_PLANES | PC_BOTH, 1, c->march.inflight);
         if (ensure_gf_scratch(c, 2 * pl1.scratch_bytes())) return 1;

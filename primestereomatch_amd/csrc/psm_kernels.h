@@ -83,7 +83,7 @@ struct PcPlan {
     size_t scratch_bytes() const { return rec_per_chunk * (size_t)nchunks * rec_bytes; }
 };
 PcPlan pc_plan(int W, int rows, int Dloc, int seg_rows_opt, int form, int batch = 1, int inflight = 1);   // batch: pairs per launch (psm_compute_batch); inflight: March::inflight
-int pc_seed_stride(int W, int H);                                // S of the two-phase selection: every S-th slice seeds the key plane
+int pc_seed_stride(int W, int rows, bool u8);                     // S of the two-phase selection: every S-th slice seeds the key plane (rows: of the stripe being filtered)
 // ts (may be NULL): slot of this launch in a buffer of 3 x PC_TS_SLOTS 64-bit words {first workgroup start | last workgroup
 // end | form} in ticks of the device's constant-rate clock (PSM_OPT_PROFILE 2, psm_filter_launch_times)
 constexpr int PC_TS_SLOTS = 4096;

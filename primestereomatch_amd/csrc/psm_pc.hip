@@ -678,6 +678,8 @@ PcPlan pc_plan(int W, int rows, int Dloc, int seg_rows_opt, int form, int batch,
 {   // form: PC_STORE; PC_PLANES (select with chunk planes) / PC_KEYS (select against a shared key plane, one slice per
     // workgroup, no reduction afterwards), each + PC_BOTH when one launch covers both volumes (twice the work items)
     const bool planes = (form & 3) == PC_PLANES, keys = (form & 3) == PC_KEYS;
+    if (PSM_KNOB(planes ? "PSM_PC_SEGP" : "PSM_PC_SEGK", 0) > 0 && (planes || keys))      // (experiment builds: segment rows per form)
+        seg_rows_opt = PSM_KNOB(planes ? "PSM_PC_SEGP" : "PSM_PC_SEGK", 0);
     const int sides = ((form & PC_BOTH) ? 2 : 1) * (batch > 1 ? batch : 1);   // volumes per launch
     const PcDev dev = pc_dev();
     PcPlan pl;
@@ -715,6 +717,13 @@ PcPlan pc_plan(int W, int rows, int Dloc, int seg_rows_opt, int form, int batch,
             return (long)(c * 16.0);
         }
         const long per_xcd = ((long)sides * pl.ngroups * kk * nch + dev.nxcd - 1) / dev.nxcd;
+        if (keys) {
+            // Key form (round 6, profiles/r06/exp_plan_two_phase.txt): one slice per item, an item walks its rows + 14 halo rows + ~16
+            // rows of pipeline fill, and a launch ends with a round and a half of stragglers - (rounds + 3/2) x (rows / k + 30).
+            // 1080p x 256 with 224 key slices: 3 segments (6.79 ms) where the older (rounds + 1/2) x (rows / k + 14) cut 4 (6.89) or
+            // 2 (6.93); 720p x 128: 3; 4K x 256: 4.
+            return (2 * ((per_xcd + slots - 1) / slots) + 3) * ((rows + kk - 1) / kk + 30) / 2;
+        }
         const long rounds2 = 2 * ((per_xcd + slots - 1) / slots) + 1;   // 2 x (rounds + 1/2)
         long c = rounds2 * dc * ((rows + kk - 1) / kk + 14) / 2 + (planes ? 2L * sides * nch : 0);
         // one slice per plane rewrites every record (a chunk's later slices only the improved ones): +6 % once the planes of
@@ -744,10 +753,17 @@ PcPlan pc_plan(int W, int rows, int Dloc, int seg_rows_opt, int form, int batch,
 
 constexpr int PC_KEY_SPREAD = 4;    // passes of the key form's slice order (pc_slice; measured 1 / 2 / 4 / 8 / 16: f32 5.12 / 5.07 / 5.06 / 5.08 / 5.10 ms, 8-bit 5.94 / 5.82 / 5.80 / 5.81 / 5.83)
 
-int pc_seed_stride(int W, int H)
-{   // every S-th slice goes through the minima planes and seeds the key plane: 5, 4 from 4 Mpixel up
+int pc_seed_stride(int W, int rows, bool u8)
+{   // every S-th slice goes through the minima planes and seeds the key plane.  Rounds 3-5: 5, and 4 from 4 Mpixel up (flat from 5 to
+    // 12 then).  Round 6, with the key loads served by the L2 (PC_KEY_LD_AUX) a pixel's key costs less to read and fewer seeds pay:
+    // S = 8 - same-box A/B against 5 (4 at 4K): 4K x 256 27.63 -> 26.43 ms, 1080p x 256 6.81 -> 6.72 (with the key launch's
+    // three-segment cut, pc_plan), 720p x 128 1.706 -> 1.661, 8-bit 720p 1.949 -> 1.817; 10 and 12 lose again.  Two places keep 5,
+    // where how the two launches fill their rounds of workgroups weighs more: stripes under 200 rows (1/8 of 1080p: 0.951 vs 0.963)
+    // and 8-bit mode from 2 Mpixel up, whose key form is the dearer one (1080p x 256: 7.38 vs 7.54).  profiles/r06/exp_plan_two_phase.txt
     const int e = PSM_KNOB("PSM_PC_S", 0);
-    return e > 1 ? e : ((size_t)W * H >= ((size_t)1 << 22) ? 4 : 5);
+    if (e > 1) return e;
+    if (rows < 200 || (u8 && (size_t)W * rows >= ((size_t)1 << 21))) return 5;
+    return 8;
 }
 
 static int pc_blocks(const PcPlan &pl, int chunks) { return pl.nxcd * ((pl.ngroups * pl.nsegs * chunks + pl.nxcd - 1) / pl.nxcd); }

@@ -106,7 +106,7 @@ def test_random_geometry_u8_mode(psm, oracle, W, H, D, seed):
 
 @pytest.mark.parametrize("W,H,D,seed", _geometries(24, 424242))
 def test_random_geometry_two_phase_and_stripes(psm, oracle, W, H, D, seed):
-    """Forced two-phase selection (planes for every 5th slice, keys for the rest) on random geometries, whole image and as
+    """Forced two-phase selection (planes for every 8th slice, keys for the rest) on random geometries, whole image and as
     row stripes cut at random rows (psm_set_rows / psm_gather_rows_ctx); float and 8-bit mode.  Maps bit-identical."""
     from primestereomatch_amd import capi, synth
     rng = np.random.default_rng(seed)

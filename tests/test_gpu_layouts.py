@@ -37,7 +37,7 @@ def test_both_select_forms_at_layout_boundaries(psm, oracle, W):
     H, D = 37 + W % 23, min(24, max(4, W // 3))
     l, r, _ = synth.make_pair(W, H, D, seed=W)
     ref = oracle.pipeline_f32(l, r, D, threads=8, want_volumes=True)
-    for flags in (0, TWO_ON):                      # chunk planes only; every 5th slice through planes, the rest against the keys
+    for flags in (0, TWO_ON):                      # chunk planes only; every 8th slice through planes, the rest against the keys
         with psm.DispEst(l, r, D) as de:
             de.set_option(capi.PSM_OPT_FLAGS, flags)
             de.CostConst_GPU(); de.CostFilter_GPU(); de.DispSelect_GPU()

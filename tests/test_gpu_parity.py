@@ -619,7 +619,7 @@ def test_per_side_calls_equal_whole_stage_calls(psm, oracle):
                                                (108, 20, 7, "f32", 1048576)])
 def test_two_phase_selection(psm, oracle, W, H, D, dtype, flags):
     """psm_cost_filter's two-phase selection (default from 112 local slices; flag 1048576 forces it, 2097152 disables it):
-    every 5th slice through the minima planes, the others against the seeded key plane.  Same maps as DispSel::CVSelect
+    every 8th slice through the minima planes, the others against the seeded key plane.  Same maps as DispSel::CVSelect
     over the whole volume (src/DispSel.cpp:96-104), and the volumes re-materialise bit-exactly afterwards."""
     from primestereomatch_amd import capi, synth
     l, r, _ = synth.make_pair(W, H, D, seed=W + D)
