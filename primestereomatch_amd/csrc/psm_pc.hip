@@ -759,10 +759,10 @@ int pc_seed_stride(int W, int rows, bool u8)
     // S = 8 - same-box A/B against 5 (4 at 4K): 4K x 256 27.63 -> 26.43 ms, 1080p x 256 6.81 -> 6.72 (with the key launch's
     // three-segment cut, pc_plan), 720p x 128 1.706 -> 1.661, 8-bit 720p 1.949 -> 1.817; 10 and 12 lose again.  Two places keep 5,
     // where how the two launches fill their rounds of workgroups weighs more: stripes under 200 rows (1/8 of 1080p: 0.951 vs 0.963)
-    // and 8-bit mode from 2 Mpixel up, whose key form is the dearer one (1080p x 256: 7.38 vs 7.54).  profiles/r06/exp_plan_two_phase.txt
+    // and 8-bit mode from 1.5 Mpixel up, whose key form is the dearer one (1080p x 256: 7.38 vs 7.54).  profiles/r06/exp_plan_two_phase.txt
     const int e = PSM_KNOB("PSM_PC_S", 0);
     if (e > 1) return e;
-    if (rows < 200 || (u8 && (size_t)W * rows >= ((size_t)1 << 21))) return 5;
+    if (rows < 200 || (u8 && (size_t)W * rows >= 1500000)) return 5;      // (8-bit: 1280 x 720 takes 8, 1920 x 1080 takes 5)
     return 8;
 }
 

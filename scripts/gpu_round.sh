@@ -1,7 +1,7 @@
 #!/bin/bash
 # One full GPU-box session of a round: parity tests, smoke, benches of every config, the torch.distributed path on
 # one GPU, rocprofv3 kernel trace + PMC passes (each in its own run).  Usage (via gpurun): bash scripts/gpu_round.sh r03
-TAG=${1:-r05}
+TAG=${1:-r06}
 OUT=$GRAFT_REPO_ROOT/gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
@@ -36,7 +36,7 @@ for v in exact tol; do
 done
 echo "== PMC passes for BASELINE configs[2] (c3: 1280x720x128), c2 and c5 as well"
 for cfg in c3 c2 c5; do
-  for pass in "rd:TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum" "wr:WRITE_SIZE TCC_EA0_WRREQ_sum" "sq:SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY"; do
+  for pass in "rd:TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum" "wr:WRITE_SIZE TCC_EA0_WRREQ_sum" "sq:SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY" "tcc:TCC_ATOMIC_sum TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum"; do
     n=${pass%%:*}; c=${pass#*:}
     timeout 300 rocprofv3 --kernel-trace --pmc $c -d $OUT/pmc_${cfg}_$n -o $n -- python $GRAFT_REPO_ROOT/scripts/prof_run.py $cfg > $OUT/pmc_${cfg}_$n.log 2>&1 || echo "pmc pass $cfg $n failed"
     fdb=$(find $OUT/pmc_${cfg}_$n -name "*.db" | head -1); [ -n "$fdb" ] && python $GRAFT_REPO_ROOT/scripts/rocpd_summary.py $fdb > $OUT/pmc_${cfg}_$n.summary.txt 2>&1
@@ -79,12 +79,11 @@ for rep in 1 2; do
 done
 echo "== batches of Middlebury-size pairs (psm_compute_batch)"
 for cfg in c2 c1 c1x; do for b in 2 4 8 16; do $B --config $cfg --batch $b --steps 30 --warmup 5 --no-cpu-wide > $OUT/bench_${cfg}_batch$b.json 2>> $OUT/bench_var.err; done; done
-$B --config c2 --batch 8 --graph --steps 30 --warmup 5 --no-cpu-baseline > $OUT/bench_c2_batch8_graph.json 2>> $OUT/bench_var.err
-$B --config c2 --batch -1 --graph --steps 30 --warmup 5 --no-cpu-baseline > $OUT/bench_c2_batch1_graph.json 2>> $OUT/bench_var.err
 for g in 2 4 8; do $B --shard-sim $g --steps 40 > $OUT/bench_c4_shardsim_1of$g.json 2>> $OUT/bench_var.err; done
 for g in 2 4 8; do $B --shard-sim $g --shard disp --steps 40 > $OUT/bench_c4_shardsim_disp_1of$g.json 2>> $OUT/bench_var.err; done
 $B --shard-sim 8 --frames-in-flight 2 --steps 40 > $OUT/bench_c4_shardsim_1of8_fif2.json 2>> $OUT/bench_var.err
 $B --shard-sim 8 --shard disp --frames-in-flight 2 --steps 40 > $OUT/bench_c4_shardsim_disp_1of8_fif2.json 2>> $OUT/bench_var.err
+$B --shard-sim 8 --shard disp --strided --steps 40 > $OUT/bench_c4_shardsim_disp_strided_1of8.json 2>> $OUT/bench_var.err
 $B --config c5 --shard-sim 8 --steps 6 --warmup 2 > $OUT/bench_c5_shardsim_1of8.json 2>> $OUT/bench_var.err
 echo "== weighted median timing (hybrid sweeps form / dataflow form)"
 timeout 300 python scripts/dbg_wmf.py big > $OUT/wmf_timing.txt 2>&1; WM_FLAGS=4194304 timeout 300 python scripts/dbg_wmf.py >> $OUT/wmf_timing.txt 2>&1; tail -22 $OUT/wmf_timing.txt
@@ -93,6 +92,7 @@ D="timeout 600 python bench.py --gpus 1 --force-dist --steps 10 --warmup 3 --no-
 $D > $OUT/bench_c4_dist_world1.json 2> $OUT/bench_dist1.err
 $D --shard disp > $OUT/bench_c4_dist_world1_disp.json 2>> $OUT/bench_dist1.err
 $D --no-frame-pipeline > $OUT/bench_c4_dist_world1_nopipeline.json 2>> $OUT/bench_dist1.err
+$D --frames-in-flight 1 > $OUT/bench_c4_dist_world1_fif1.json 2>> $OUT/bench_dist1.err
 echo "== the N > 1 protocol with TWO ranks on this one GPU (RCCL first; gloo-staged exchange when RCCL refuses the duplicate device)"
 W2="timeout 900 python bench.py --gpus 2 --same-device --steps 10 --warmup 3"
 $W2 > $OUT/bench_c4_world2_same_device.json 2> $OUT/bench_world2.err
