@@ -292,3 +292,35 @@ def test_round5_lines():
     f = _line_r("r05", "bench_c4_fma_solve.json")
     assert f["fma_solve_form"]["maps_equal_its_oracle_reading"] is True and sum(f["fma_solve_form"]["pixels_differing_from_the_canonical_oracle"]) < 50
 
+
+
+def test_round6_lines():
+    """profiles/r06: `bound` agrees with `binding`, the distributed lines run two frames in flight per rank on both axes, the strided
+    disparity shard is verified, the 4K key phase's fabric reads fell, and no line prints an HBM fraction above 1."""
+    import glob
+    j = _line_r("r06", "bench_c4_n1.json")
+    W, H, D = j["config"]["W"], j["config"]["H"], j["config"]["D"]
+    assert (W, H, D) == (1920, 1080, 256) and j["dtype"] == "f32" and j["n_gpus"] == 1 and j["vs_baseline"] is None
+    assert abs(j["value"] - 2.0 * W * H * D / (j["ms_per_step"] * 1e-3)) / j["value"] < 1e-6
+    assert j["oracle_maps_equal"] is True and j["verified_vs_single_gpu"] is True and j["config"]["frames_in_flight"] == 1
+    r = j["roofline"]
+    assert r["bound"] == r["binding"] == "valu" and "hbm" in r["frac_of"] and r["unit"] == "GB/s" and r["peak"] == 8000.0
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and 0.7 < r["binding_frac"] <= 1.0 and r["traffic_session"].startswith("r06")
+    assert j["ms_per_step"] < _line_r("r05", "bench_c4_n1.json")["ms_per_step"]
+    assert j["cpu_baseline"]["kind"] == "port" and j["cpu_baseline"]["cores"] == 8
+    for f in glob.glob(os.path.join(ROOT, "profiles", "r06", "bench_*.json")):
+        k = json.loads([ln for ln in open(f).read().strip().splitlines() if ln.startswith("{")][-1])
+        fr = k["roofline"]["frac"]
+        assert fr is None or fr <= 1.0, (f, fr)
+    for name, ranks in (("bench_c4_dist_world1.json", 1), ("bench_c4_world2_same_device.json", 2), ("bench_c4_world2_same_device_disp.json", 2)):
+        k = _line_r("r06", name)
+        assert k["ranks"] == ranks and k["config"]["frames_in_flight"] == 2 and k["alt_shard"]["frames_in_flight"] == 2
+        assert k["verified_vs_single_gpu"] is True and k["alt_shard"]["verified_vs_single_gpu"] is True and k["frames_in_flight_maps_equal"] is True
+    assert _line_r("r06", "bench_c4_dist_world1_fif1.json")["config"]["frames_in_flight"] == 1
+    s_ = _line_r("r06", "bench_c4_shardsim_disp_strided_1of8.json")
+    assert s_["config"]["strided_disparity_shards"] is True and s_["verified_vs_single_gpu"] is True and s_["oracle_maps_equal"] is True
+    c5, c5old = _line_r("r06", "bench_c5_n1.json"), _line_r("r05", "bench_c5_n1.json")
+    assert c5["oracle_maps_equal"] is True and c5["ms_per_step"] < c5old["ms_per_step"]
+    assert c5["roofline"]["traffic"] < 0.7 * c5old["roofline"]["traffic"]          # the key loads no longer come from the memory side
+    for n in ("exp_in_kernel_reduction.txt", "exp_key_load_policy.txt", "exp_plan_two_phase.txt", "exp_strided_shards.txt"):
+        assert os.path.exists(os.path.join(ROOT, "profiles", "r06", n)), n
