@@ -597,6 +597,7 @@ int psm_download_guidance(psm_ctx *c, int side, float *host)
     const size_t HW = (size_t)c->W * c->H;
     std::vector<float4> b1(HW), b2(HW), b3(HW);
     std::vector<float2> b4(HW);
+    if (c->have_images && !c->have_g1 && run_prep(c)) return 1;     // (image preparation is lazy: psm_cost_construct may have left it to the filter)
     PSM_HIP(c, hipStreamSynchronize(c->stream));
     PSM_HIP(c, hipMemcpy(b1.data(), c->g[side].g1, HW * sizeof(float4), hipMemcpyDeviceToHost));
     PSM_HIP(c, hipMemcpy(b2.data(), c->g[side].g2, HW * sizeof(float4), hipMemcpyDeviceToHost));

@@ -32,6 +32,7 @@ int run_prep(psm_ctx *c, int ya, int yb)
         launch_prep_u8(c->stream, (const uint8_t *)c->raw[s] + ya * row, row, c->W, yb - ya, c->p4[s] + 4 * o, c->g[s].g1 + o);
     }
     if (check_launch(c, "prep")) return 1;
+    if (c->ev_free) PSM_HIP(c, hipEventRecord(c->ev_free, c->stream));   // the staged images have been read: their slot may be refilled
     c->have_guid[0] = c->have_guid[1] = false;
     c->guid_y0 = c->guid_y1 = 0;
     c->have_g1 = whole;
@@ -332,22 +333,39 @@ int filter_both(psm_ctx *c)
 {
     c->maps_early = nullptr;
     const bool striped = c->march.yend > c->march.ybeg;
-    {   // g1 rows this launch reads: everything, or the stripe's rows - 8 .. + 8
+    {   // g1 rows this launch reads: everything, or the stripe's rows - 8 .. + 8; guidance rows: the model rows y0 - 4 .. y1 + 2
         const int ya = striped ? (c->march.ybeg - 8 > 0 ? c->march.ybeg - 8 : 0) : 0;
         const int yb = striped ? (c->march.yend + 8 < c->H ? c->march.yend + 8 : c->H) : c->H;
-        if (!c->have_g1 && !(c->g1_y1 > c->g1_y0 && c->g1_y0 <= ya && c->g1_y1 >= yb) && run_prep(c)) return 1;
-    }
-    if (!(c->have_guid[0] && c->have_guid[1])) {
-        // a row stripe needs the guidance of its model rows only: y0 - 4 .. y1 + 2 (have_guid stays false: the planes are not
-        // whole, any other consumer recomputes them; guid_y0/1 remember what is there for the next frame's check)
         const int gy0 = striped ? (c->march.ybeg - 4 > 0 ? c->march.ybeg - 4 : 0) : 0;
         const int gy1 = striped ? (c->march.yend + 4 < c->H ? c->march.yend + 4 : c->H) : c->H;
-        if (!(c->guid_y1 > c->guid_y0 && c->guid_y0 <= gy0 && c->guid_y1 >= gy1)) {
-            Prof p(c, PSM_K_GUIDE);
-            launch_guidance(c->stream, c->g[0], c->W, c->H, &c->g[1], gy0, gy1, fma_solve(c));
-            c->guid_y0 = gy0;
-            c->guid_y1 = gy1;
-            if (gy0 == 0 && gy1 == c->H) c->have_guid[0] = c->have_guid[1] = true;
+        const bool need_g1 = !c->have_g1 && !(c->g1_y1 > c->g1_y0 && c->g1_y0 <= ya && c->g1_y1 >= yb);
+        const bool need_guid = !(c->have_guid[0] && c->have_guid[1]) && !(c->guid_y1 > c->guid_y0 && c->guid_y0 <= gy0 && c->guid_y1 >= gy1);
+        if (need_g1 && need_guid && c->dtype == PSM_F32) {
+            // image planes AND guidance in one launch, straight from the staged images (psm_cost_construct left the preparation to
+            // us): rows [ya, yb) of g1 are written, and the guidance of the same rows (a stripe: 4 rows more either side than it needs)
+            const size_t row = (size_t)c->W * 3 * (c->raw_depth == PSM_IMG_F32 ? 4 : 1);
+            {
+                Prof p(c, PSM_K_GUIDE);
+                launch_guidance(c->stream, c->g[0], c->W, c->H, &c->g[1], ya, yb, fma_solve(c), c->raw[0], c->raw[1], row, c->raw_depth == PSM_IMG_F32);
+            }
+            if (check_launch(c, "prep + guidance")) return 1;
+            if (c->ev_free) PSM_HIP(c, hipEventRecord(c->ev_free, c->stream));   // the staged images have been read: their slot may be refilled
+            const bool whole = ya == 0 && yb == c->H;
+            c->have_g1 = whole;
+            c->g1_y0 = c->guid_y0 = ya;
+            c->g1_y1 = c->guid_y1 = yb;
+            c->have_guid[0] = c->have_guid[1] = whole;
+        } else {
+            if (need_g1 && (striped ? run_prep(c, c->march.ybeg - 8, c->march.yend + 8) : run_prep(c))) return 1;
+            // a row stripe needs the guidance of its model rows only (have_guid stays false: the planes are not whole, any other
+            // consumer recomputes them; guid_y0/1 remember what is there for the next frame's check)
+            if (!(c->have_guid[0] && c->have_guid[1]) && !(c->guid_y1 > c->guid_y0 && c->guid_y0 <= gy0 && c->guid_y1 >= gy1)) {
+                Prof p(c, PSM_K_GUIDE);
+                launch_guidance(c->stream, c->g[0], c->W, c->H, &c->g[1], gy0, gy1, fma_solve(c));
+                c->guid_y0 = gy0;
+                c->guid_y1 = gy1;
+                if (gy0 == 0 && gy1 == c->H) c->have_guid[0] = c->have_guid[1] = true;
+            }
         }
     }
     const uint8_t *const *p4 = c->dtype == PSM_U8 ? c->p4 : nullptr;
@@ -417,8 +435,16 @@ int psm_cost_construct(psm_ctx *c)
     // planes of rows y0 - 8 .. y1 + 7 only (costs of the model rows y0 - 4 .. y1 + 2, +- 4 for their box sums, and the guidance)
     if (!lazy) PSM_NOT_STRIDED(c, "psm_cost_construct with materialised costs");
     const bool striped = c->march.yend > c->march.ybeg;
-    if (striped && lazy ? run_prep(c, c->march.ybeg - 8, c->march.yend + 8) : run_prep(c)) return 1;
-    if (c->ev_free) PSM_HIP(c, hipEventRecord(c->ev_free, c->stream));   // the staged images have been read: their slot may be refilled
+    if (lazy && c->dtype == PSM_F32) {
+        // CVC::preprocess is lazy too (round 6): with the cost volume virtual, the first thing that needs the image planes is the
+        // guidance precompute of psm_cost_filter - and k_guide_march forms them itself from the staged images (one launch instead of
+        // k_prep + k_guide_march; launch_guidance with raw images).  Everything else that reads g1 finds have_g1 false and runs
+        // run_prep first, as after a striped frame.
+        c->have_g1 = false;
+        c->g1_y0 = c->g1_y1 = 0;
+        c->have_guid[0] = c->have_guid[1] = false;
+        c->guid_y0 = c->guid_y1 = 0;
+    } else if (striped && lazy ? run_prep(c, c->march.ybeg - 8, c->march.yend + 8) : run_prep(c)) return 1;
     c->fgf_virtual[0] = c->fgf_virtual[1] = 0;   // a new cost volume replaces whatever was pending
     c->gf_virtual[0] = c->gf_virtual[1] = false;
     c->vol_domain_ok[0] = c->vol_domain_ok[1] = true;   // (uploaded volumes are gone; the costs now follow from the images)

@@ -54,7 +54,10 @@ void launch_prep(hipStream_t s, const void *src, size_t pitch, int depth_f32, in
                  float4 *g11 = nullptr);
 // g1 -> g2,g3,g4 (second != NULL: both images in one launch; [ybeg, yend): rows of g2..g4 to produce, default all)
 void launch_guidance(hipStream_t s, Guidance g, int W, int H, const Guidance *second = nullptr, int ybeg = 0, int yend = 0,
-                     bool fma = false);   // fma: PSM_FLAG_FMA_SOLVE - minors and DET in their fused forms
+                     bool fma = false,    // fma: PSM_FLAG_FMA_SOLVE - minors and DET in their fused forms
+                     const void *raw0 = nullptr, const void *raw1 = nullptr, size_t pitch = 0, int raw_f32 = 0);
+// raw0 / raw1 (device copies of the interleaved images, row pitch `pitch`): image preparation (launch_prep) in the same launch -
+// the g1 rows [ybeg, yend) of both images are written from them
 // cost volume slices [d_begin, d_begin+Dloc) of one side.  base: g1 of the side's own image.
 void launch_cvc(hipStream_t s, const float4 *g1_base, const float4 *g1_other, float *vol, int W, int H,
                 int d_begin, int Dloc, int right, int ybeg, int yend);

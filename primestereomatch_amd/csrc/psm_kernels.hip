@@ -171,13 +171,21 @@ __device__ __forceinline__ void guide_finish(const float *m, float4 &g2, float4 
 // after each batch of four rows all 192 threads share the per-pixel finish (variances, adjugate, 1/DET) of the batch's
 // 4 x 56 pixels.  Round 2 ran one wave per (strip, segment) with all nine trees: one resident round of two waves per SIMD,
 // i.e. the kernel took as long as ONE wave's serial march (54 us at 1080p, 19 us at 450 x 375).  Same arithmetic, same bits.
+// SRC 0: the image planes come from g1 (k_prep ran).  SRC 1 / 2 (round 6): CVC::preprocess (src/CVC.cpp:41-46, and the convertTo of
+// src/StereoMatch.cpp:195-196 for 8-bit images) is done HERE - every wave converts the staged interleaved pixel of its column itself
+// (u8: (float)b * (1/255.0f) as load_px; float: as it is), and wave 0 also forms gray and the x-gradient from its lane neighbours
+// (the lanes of a wave hold consecutive columns, reflected at the image border exactly as r101 asks) and writes the g1 rows the
+// workgroup owns: one launch instead of k_prep + k_guide_march, and g1 is written once instead of written and read back.
+template <int SRC>
 __global__ __launch_bounds__(192) void k_guide_march(const float4 *g1, int W, int H, int nstrips, int seg_rows,
                                                     float4 *g2, float4 *g3, float2 *g4, Guidance second, int ybeg, int yend,
-                                                    const PcPair *__restrict__ tab, int fma)
+                                                    const PcPair *__restrict__ tab, int fma, const void *raw0, const void *raw1, size_t pitch)
 {
     __shared__ float ms[2][4][9][64];            // [batch parity][row of the batch][channel][lane]
+    const void *raw = raw0;
+    float4 *g1w = const_cast<float4 *>(g1);      // SRC != 0: g1 is an OUTPUT
     if (tab) { const Guidance gg = tab[blockIdx.y >> 1].g[blockIdx.y & 1]; g1 = gg.g1; g2 = gg.g2; g3 = gg.g3; g4 = gg.g4; }   // batch: image y & 1 of pair y >> 1
-    else if (blockIdx.y == 1) { g1 = second.g1; g2 = second.g2; g3 = second.g3; g4 = second.g4; }   // second image of a two-image launch
+    else if (blockIdx.y == 1) { g1 = second.g1; g1w = second.g1; g2 = second.g2; g3 = second.g3; g4 = second.g4; raw = raw1; }   // second image of a two-image launch
     const int strip = blockIdx.x % nstrips, seg = blockIdx.x / nstrips;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int x0 = strip * 56;
@@ -185,21 +193,44 @@ __global__ __launch_bounds__(192) void k_guide_march(const float4 *g1, int W, in
     const int y0 = ybeg + seg * seg_rows, y1 = min(yend, y0 + seg_rows);   // output rows [y0, y1) of the rows [ybeg, yend) asked for
     const int n = (y1 - y0) + 7, ybase = y0 - 4;
     const int i1 = ((lane + 1) & 63) << 2, i2 = ((lane + 2) & 63) << 2, i4 = ((lane + 4) & 63) << 2;
-    (void)i1;
+    const int im1 = ((lane + 63) & 63) << 2;
+    (void)i1; (void)im1;
     VTree t[3] = {};
     // the image rows of the next batch of four steps are in flight while this batch computes
+    auto load_row = [&](int yy) -> float4 {
+        if constexpr (SRC == 0) return g1[(size_t)yy * W + cs];
+        else if constexpr (SRC == 1) {
+            // three bytes of an interleaved B,G,R pixel as one (unaligned) dword: the staged image buffers are 12 bytes per pixel
+            // long whatever the depth (psm_create), so the byte past the last pixel exists
+            const uint8_t *p = (const uint8_t *)raw + (size_t)yy * pitch + 3 * cs;
+            unsigned v;
+            __builtin_memcpy(&v, p, 4);
+            const float alpha = 1 / 255.0f;
+            return make_float4(__fmul_rn((float)(v & 0xffu), alpha), __fmul_rn((float)((v >> 8) & 0xffu), alpha), __fmul_rn((float)((v >> 16) & 0xffu), alpha), 0.0f);
+        } else {
+            const float *p = (const float *)((const char *)raw + (size_t)yy * pitch) + 3 * cs;
+            return make_float4(p[0], p[1], p[2], 0.0f);
+        }
+    };
     float4 gq[4];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) gq[k] = g1[(size_t)r101c(ybase + k, H) * W + cs];
+    for (int k = 0; k < 4; ++k) gq[k] = load_row(r101c(ybase + k, H));
     for (int i = 0, b = 0; i < n; i += 4, ++b) {
         float4 gc[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) gc[k] = gq[k];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) gq[k] = g1[(size_t)r101c(ybase + i + 4 + k, H) * W + cs];
+        for (int k = 0; k < 4; ++k) gq[k] = load_row(r101c(ybase + i + 4 + k, H));
 #define PSM_STEP_G(K)                                                                              \
     {                                                                                              \
         const float4 g = gc[K];                                                                    \
+        if (SRC != 0 && wave == 0) {   /* CVC::preprocess of the rows this workgroup owns (step i + K is image row ybase + i + K) */ \
+            const float gr_ = gray_of(g.x, g.y, g.z);                                              \
+            const float grd_ = __fsub_rn(rol1(gr_), lane_get(gr_, im1));   /* gray(x + 1) - gray(x - 1): lanes l + 1 / l - 1 */ \
+            const int st_ = i + K, xo_ = x0 - 4 + lane;                                            \
+            if (st_ >= 4 && st_ < n - 3 && lane >= 4 && lane < 60 && xo_ < W)                      \
+                g1w[(size_t)(ybase + st_) * W + xo_] = make_float4(g.x, g.y, g.z, grd_);            \
+        }                                                                                          \
         /* channels I0,I1,I2 | I0I0,I0I1,I0I2 | I1I1,I1I2,I2I2: wave w takes the w-th triple */      \
         const float v0 = wave == 0 ? g.x : (wave == 1 ? __fmul_rn(g.x, g.x) : __fmul_rn(g.y, g.y)); \
         const float v1 = wave == 0 ? g.y : (wave == 1 ? __fmul_rn(g.x, g.y) : __fmul_rn(g.y, g.z)); \
@@ -228,9 +259,11 @@ __global__ __launch_bounds__(192) void k_guide_march(const float4 *g1, int W, in
     }
 }
 
-void launch_guidance(hipStream_t s, Guidance g, int W, int H, const Guidance *second, int ybeg, int yend, bool fma)
+void launch_guidance(hipStream_t s, Guidance g, int W, int H, const Guidance *second, int ybeg, int yend, bool fma,
+                     const void *raw0, const void *raw1, size_t pitch, int raw_f32)
 {   // second != NULL: the guidance of both images in one launch; [ybeg, yend) (yend <= ybeg: all rows): the rows of g2..g4
-    // to produce - a row stripe of the filter needs its own rows + 4 either side
+    // to produce - a row stripe of the filter needs its own rows + 4 either side.  raw0 / raw1 != NULL: CVC::preprocess in the
+    // same launch - the images are read from the staged interleaved copies, and the g1 rows [ybeg, yend) are WRITTEN
     if (yend <= ybeg) { ybeg = 0; yend = H; }
     const int rows = yend - ybeg;
     // one workgroup of three waves per (strip, segment); segments as short as still fill ~2 workgroups per SIMD-quad of the
@@ -241,8 +274,11 @@ void launch_guidance(hipStream_t s, Guidance g, int W, int H, const Guidance *se
     int seg_rows = 8;
     while (seg_rows < 64 && nstrips * ((rows + seg_rows - 1) / seg_rows) > wgs) ++seg_rows;
     const int nsegs = (rows + seg_rows - 1) / seg_rows;
-    hipLaunchKernelGGL(k_guide_march, dim3(nstrips * nsegs, second ? 2 : 1), dim3(192), 0, s, (const float4 *)g.g1, W, H, nstrips, seg_rows, g.g2, g.g3, g.g4,
-                       second ? *second : Guidance{}, ybeg, yend, (const PcPair *)nullptr, fma ? 1 : 0);
+#define PSM_LAUNCH_G(SRC)                                                                                                            \
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_guide_march<SRC>), dim3(nstrips * nsegs, second ? 2 : 1), dim3(192), 0, s, (const float4 *)g.g1, W, H, nstrips, \
+                       seg_rows, g.g2, g.g3, g.g4, second ? *second : Guidance{}, ybeg, yend, (const PcPair *)nullptr, fma ? 1 : 0, raw0, raw1, pitch)
+    if (!raw0) PSM_LAUNCH_G(0); else if (raw_f32) PSM_LAUNCH_G(2); else PSM_LAUNCH_G(1);
+#undef PSM_LAUNCH_G
 }
 
 // ---- the same two kernels for every pair of a batch (psm_compute_batch): one launch each, images indexed through the table ----
@@ -254,8 +290,8 @@ void launch_guidance_batch(hipStream_t s, const PcPair *tab, int npairs, int W, 
     int seg_rows = 8;
     while (seg_rows < 64 && nstrips * ((H + seg_rows - 1) / seg_rows) > wgs) ++seg_rows;
     const int nsegs = (H + seg_rows - 1) / seg_rows;
-    hipLaunchKernelGGL(k_guide_march, dim3(nstrips * nsegs, 2 * npairs), dim3(192), 0, s, (const float4 *)nullptr, W, H, nstrips, seg_rows,
-                       (float4 *)nullptr, (float4 *)nullptr, (float2 *)nullptr, Guidance{}, 0, H, tab, 0);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_guide_march<0>), dim3(nstrips * nsegs, 2 * npairs), dim3(192), 0, s, (const float4 *)nullptr, W, H, nstrips, seg_rows,
+                       (float4 *)nullptr, (float4 *)nullptr, (float2 *)nullptr, Guidance{}, 0, H, tab, 0, (const void *)nullptr, (const void *)nullptr, (size_t)0);
 }
 
 // ------------------------------------------------------------------------------------------
