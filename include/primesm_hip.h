@@ -81,7 +81,7 @@ enum psm_flag {
     PSM_FLAG_STORE_FILTERED = 8192,     /* psm_cost_filter always writes the filtered volumes (storing form of the fused
                                            kernel + a separate WTA; default: select forms, packed per-pixel minima) */
     PSM_FLAG_TWO_PHASE_ON = 1048576,    /* force / disable the two-phase selection of psm_cost_filter (default: on from */
-    PSM_FLAG_TWO_PHASE_OFF = 2097152,   /* 112 local slices - every 5th slice through minima planes, the rest against
+    PSM_FLAG_TWO_PHASE_OFF = 2097152,   /* 112 local slices - every 8th (short stripes, large 8-bit images: 5th) slice through minima planes, the rest against
                                            the seeded key plane) */
     PSM_FLAG_WMF_DATAFLOW = 4194304,    /* psm_wgt_median runs its row-dataflow form only */
     PSM_FLAG_WMF_TWO_SWEEPS = 8388608,  /* ... at most 2 sweeps of its parallel form (test hook for the fall-back) */
@@ -164,7 +164,10 @@ int psm_upload_pair(psm_ctx *ctx, const void *l, const void *r, int channels, si
 
 /* DispEst::CostConst_GPU (src/DispEst.cpp:272-276) == CVC_cl::buildCV: gray + x-gradient
  * of both images (CVC::preprocess arithmetic, src/CVC.cpp:41-46 - no +0.5) and both cost
- * volumes (CVC::buildCV_left/right arithmetic, src/CVC.cpp:122-179). */
+ * volumes (CVC::buildCV_left/right arithmetic, src/CVC.cpp:122-179).  In the default float path all of it is lazy: the cost
+ * volumes stay virtual (the fused filter builds the costs on the fly) and - since round 6 - so does the image preparation (the
+ * guidance launch of psm_cost_filter forms gray and gradient itself); the call then only adopts the pair and resets the frame's
+ * state.  Whatever reads the image planes or a volume earlier gets them prepared / materialised on demand. */
 int psm_cost_construct(psm_ctx *ctx);
 
 /* DispEst::CostFilter_GPU (src/DispEst.cpp:299-308) == CVF_cl::preprocess + filterCV for
@@ -296,7 +299,7 @@ int psm_gather_staged_legs(const psm_ctx *root);
  * behind four launches at their latency floor ----
  * psm_compute_batch runs DispEst::CostConst_GPU + CostFilter_GPU + DispSelect_GPU (src/DispEst.cpp:272-276,299-308,323-328) for
  * the n contexts ctxs[0..n) - same width, height, max_disp, slice range, dtype, device and options, each holding its own pair
- * (psm_upload_pair / psm_upload_pair_async) - in SHARED launches: one image preparation, one guidance kernel, one fused
+ * (psm_upload_pair / psm_upload_pair_async) - in SHARED launches: one guidance kernel (which also prepares the images; 8-bit mode: a preparation launch before it), one fused
  * CVC + CVF + WTA grid over all pairs (two in the two-phase form), one reduction.  Afterwards every context is exactly where
  * psm_cost_construct + psm_cost_filter + psm_disp_select(ctx, NULL, NULL, 0) would have left it - same maps bit for bit
  * (psm_download_maps, psm_download_maps_async), same packed minima on a disparity shard, post-processing and volume readers

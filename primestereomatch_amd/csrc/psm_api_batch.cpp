@@ -118,8 +118,8 @@ extern "C" int psm_compute_batch(psm_ctx *const *ctxs, int n)
     const bool whole = Dloc == c0->D;        // every slice here: the maps are final (else: packed minima for psm_disp_merge)
     double t1 = t0;
     auto enqueue = [&]() -> int {
-        // ---- CostConst: CVC::preprocess of every image (the cost volumes stay virtual) ----
-        {
+        // ---- CostConst: CVC::preprocess of every image (the cost volumes stay virtual) - float mode: inside the guidance launch ----
+        if (u8) {
             Prof p(c0, PSM_K_PREP);
             launch_prep_batch(s, dt, n, row, depth == PSM_IMG_F32, W, H, u8);
         }
@@ -127,7 +127,7 @@ extern "C" int psm_compute_batch(psm_ctx *const *ctxs, int n)
         // ---- CostFilter: guidance of every image, the fused select kernel over every pair, the reduction ----
         {
             Prof p(c0, PSM_K_GUIDE);
-            launch_guidance_batch(s, dt, n, W, H);
+            launch_guidance_batch(s, dt, n, W, H, row, u8 ? 0 : (depth == PSM_IMG_F32 ? 2 : 1));
         }
         {
             Prof p(c0, PSM_K_CVF_F);

@@ -435,11 +435,13 @@ int psm_cost_construct(psm_ctx *c)
     // planes of rows y0 - 8 .. y1 + 7 only (costs of the model rows y0 - 4 .. y1 + 2, +- 4 for their box sums, and the guidance)
     if (!lazy) PSM_NOT_STRIDED(c, "psm_cost_construct with materialised costs");
     const bool striped = c->march.yend > c->march.ybeg;
-    if (lazy && c->dtype == PSM_F32) {
+    if (lazy && c->dtype == PSM_F32 && c->march.inflight <= 1) {
         // CVC::preprocess is lazy too (round 6): with the cost volume virtual, the first thing that needs the image planes is the
         // guidance precompute of psm_cost_filter - and k_guide_march forms them itself from the staged images (one launch instead of
         // k_prep + k_guide_march; launch_guidance with raw images).  Everything else that reads g1 finds have_g1 false and runs
-        // run_prep first, as after a striped frame.
+        // run_prep first, as after a striped frame.  (Not with frames in flight on other streams - PSM_OPT_FRAMES_IN_FLIGHT: the merged
+        // launch carries the conversions in all three waves of its workgroups and stretches beside another frame's VALU-bound fused
+        // kernel - 450 x 375 x 64, two frames in flight: 0.226 ms against 0.211 with k_prep + k_guide_march; alone it is 0.270 vs 0.279.)
         c->have_g1 = false;
         c->g1_y0 = c->g1_y1 = 0;
         c->have_guid[0] = c->have_guid[1] = false;

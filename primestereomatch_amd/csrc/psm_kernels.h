@@ -42,7 +42,7 @@ struct PcPair {                  // one pair of the batch: an entry of a device 
     uint8_t *maps;               // [2][H][W]
 };
 void launch_prep_batch(hipStream_t s, const PcPair *tab, int npairs, size_t pitch, int depth_f32, int W, int H, bool u8_planes);
-void launch_guidance_batch(hipStream_t s, const PcPair *tab, int npairs, int W, int H);
+void launch_guidance_batch(hipStream_t s, const PcPair *tab, int npairs, int W, int H, size_t pitch = 0, int src = 0);   // src 1 / 2: + image preparation (8-bit / float staged images)
 void launch_merge_batch(hipStream_t s, const PcPair *tab, int npairs, int W, int H);   // keys -> maps of every pair
 
 // device <-> page-locked host copy as a kernel (both pointers 16-byte aligned)

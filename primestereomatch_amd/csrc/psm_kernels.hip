@@ -184,8 +184,11 @@ __global__ __launch_bounds__(192) void k_guide_march(const float4 *g1, int W, in
     __shared__ float ms[2][4][9][64];            // [batch parity][row of the batch][channel][lane]
     const void *raw = raw0;
     float4 *g1w = const_cast<float4 *>(g1);      // SRC != 0: g1 is an OUTPUT
-    if (tab) { const Guidance gg = tab[blockIdx.y >> 1].g[blockIdx.y & 1]; g1 = gg.g1; g2 = gg.g2; g3 = gg.g3; g4 = gg.g4; }   // batch: image y & 1 of pair y >> 1
-    else if (blockIdx.y == 1) { g1 = second.g1; g1w = second.g1; g2 = second.g2; g3 = second.g3; g4 = second.g4; raw = raw1; }   // second image of a two-image launch
+    if (tab) {   // batch: image y & 1 of pair y >> 1
+        const Guidance gg = tab[blockIdx.y >> 1].g[blockIdx.y & 1];
+        g1 = gg.g1; g1w = gg.g1; g2 = gg.g2; g3 = gg.g3; g4 = gg.g4;
+        raw = tab[blockIdx.y >> 1].raw[blockIdx.y & 1];
+    } else if (blockIdx.y == 1) { g1 = second.g1; g1w = second.g1; g2 = second.g2; g3 = second.g3; g4 = second.g4; raw = raw1; }   // second image of a two-image launch
     const int strip = blockIdx.x % nstrips, seg = blockIdx.x / nstrips;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int x0 = strip * 56;
@@ -282,16 +285,20 @@ void launch_guidance(hipStream_t s, Guidance g, int W, int H, const Guidance *se
 }
 
 // ---- the same two kernels for every pair of a batch (psm_compute_batch): one launch each, images indexed through the table ----
-void launch_guidance_batch(hipStream_t s, const PcPair *tab, int npairs, int W, int H)
-{
+void launch_guidance_batch(hipStream_t s, const PcPair *tab, int npairs, int W, int H, size_t pitch, int src)
+{   // src 0: g1 of every image exists (launch_prep_batch); 1 / 2: image preparation in the same launch, from the table's staged 8-bit /
+    // float images (row pitch `pitch`), as launch_guidance does for one pair
     const int nstrips = (W + 55) / 56;
     const PcDev dev = pc_dev();
     const int wgs = 6 * dev.nxcd * dev.cus_per_xcd / (2 * npairs) > 0 ? 6 * dev.nxcd * dev.cus_per_xcd / (2 * npairs) : 1;
     int seg_rows = 8;
     while (seg_rows < 64 && nstrips * ((H + seg_rows - 1) / seg_rows) > wgs) ++seg_rows;
     const int nsegs = (H + seg_rows - 1) / seg_rows;
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_guide_march<0>), dim3(nstrips * nsegs, 2 * npairs), dim3(192), 0, s, (const float4 *)nullptr, W, H, nstrips, seg_rows,
-                       (float4 *)nullptr, (float4 *)nullptr, (float2 *)nullptr, Guidance{}, 0, H, tab, 0, (const void *)nullptr, (const void *)nullptr, (size_t)0);
+#define PSM_LAUNCH_GB(SRC)                                                                                                          \
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_guide_march<SRC>), dim3(nstrips * nsegs, 2 * npairs), dim3(192), 0, s, (const float4 *)nullptr, W, H, nstrips, seg_rows, \
+                       (float4 *)nullptr, (float4 *)nullptr, (float2 *)nullptr, Guidance{}, 0, H, tab, 0, (const void *)nullptr, (const void *)nullptr, pitch)
+    if (src == 1) PSM_LAUNCH_GB(1); else if (src == 2) PSM_LAUNCH_GB(2); else PSM_LAUNCH_GB(0);
+#undef PSM_LAUNCH_GB
 }
 
 // ------------------------------------------------------------------------------------------

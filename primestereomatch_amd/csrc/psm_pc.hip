@@ -610,28 +610,23 @@ __global__ __launch_bounds__(256) void k_chunk_min(const float4 *kcost, const un
     const int y0 = ybeg + seg * seg_rows, y1 = min(yend, y0 + seg_rows);
     const int ya = y0 + 4 * c - 7;                                  // output row of the record's first entry
     if (ya + 3 < y0 || ya >= y1) return;
-    // (eight chunks' records in flight per thread: at Middlebury size the launch is a handful of workgroups per CU and a load per
-    // loop iteration made it one dependent chain of nchunks memory round trips - 17.8 us for 60 MB)
-    long long best[4] = {0x7fffffffffffffffLL, 0x7fffffffffffffffLL, 0x7fffffffffffffffLL, 0x7fffffffffffffffLL};
-    constexpr int U = 8;        // (16: no better - 15.5 vs 13.7 us at 450 x 375 x 64)
-    for (int c0 = 0; c0 < nchunks; c0 += U) {
-        float4 kc[U];
-        unsigned kd[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int ch = c0 + u < nchunks ? c0 + u : nchunks - 1;      // (past the end: the last chunk again - a minimum does not mind)
-            kc[u] = kcost[(size_t)ch * nrec + idx];
-            kd[u] = kdisp[(size_t)ch * nrec + idx];
-        }
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const long long k0 = pack_key_f32(kc[u].x, kd[u] & 0xff), k1 = pack_key_f32(kc[u].y, (kd[u] >> 8) & 0xff),
-                            k2 = pack_key_f32(kc[u].z, (kd[u] >> 16) & 0xff), k3 = pack_key_f32(kc[u].w, kd[u] >> 24);
-            best[0] = k0 < best[0] ? k0 : best[0];
-            best[1] = k1 < best[1] ? k1 : best[1];
-            best[2] = k2 < best[2] ? k2 : best[2];
-            best[3] = k3 < best[3] ? k3 : best[3];
-        }
+    // (One chunk's record per loop iteration, on purpose.  Round 6 kept 2 / 4 / 8 / 16 chunks' records in flight per thread: alone the
+    // kernel got faster - 17.8 -> 13.7 us at 450 x 375 x 64 -, but with two frames in flight the frame rose from 0.211 to 0.229 ms:
+    // beside three resident workgroups of the fused kernel a SIMD has 32 vector registers left, and only this small form still fits
+    // there; the wider ones wait for a fused workgroup to leave.  profiles/r06/exp_chunk_min_unroll.txt)
+    float4 kc = kcost[idx];
+    unsigned kd = kdisp[idx];
+    long long best[4] = {pack_key_f32(kc.x, kd & 0xff), pack_key_f32(kc.y, (kd >> 8) & 0xff), pack_key_f32(kc.z, (kd >> 16) & 0xff),
+                         pack_key_f32(kc.w, kd >> 24)};
+    for (int ch = 1; ch < nchunks; ++ch) {
+        kc = kcost[(size_t)ch * nrec + idx];
+        kd = kdisp[(size_t)ch * nrec + idx];
+        const long long k0 = pack_key_f32(kc.x, kd & 0xff), k1 = pack_key_f32(kc.y, (kd >> 8) & 0xff),
+                        k2 = pack_key_f32(kc.z, (kd >> 16) & 0xff), k3 = pack_key_f32(kc.w, kd >> 24);
+        best[0] = k0 < best[0] ? k0 : best[0];
+        best[1] = k1 < best[1] ? k1 : best[1];
+        best[2] = k2 < best[2] ? k2 : best[2];
+        best[3] = k3 < best[3] ? k3 : best[3];
     }
 #pragma unroll
     for (int k = 0; k < 4; ++k) {

@@ -140,7 +140,13 @@ def one(rng, idx):
         flags &= FMA_SOLVE    # stripes need the default select form (either arithmetic reading)
     outl, outr = np.zeros_like(ref["ldisp"]), np.zeros_like(ref["rdisp"])
     for y0, y1 in zip(ycuts[:-1], ycuts[1:]):
-        shards = [P.DispEst(l, r, D, dtype=dtype, d_range=(d0, d1)) for d0, d1 in zip(dcuts[:-1], dcuts[1:])]
+        # (round 6) sometimes the same number of shards dealt the other way: shard g of G holds d = g (mod G) - strided ownership needs
+        # the select path, so not with the storing / materialising flags
+        G = len(dcuts) - 1
+        if G > 1 and G <= D and not (flags & (8192 | 128)) and rng.random() < 0.4:
+            shards = [P.DispEst(l, r, D, dtype=dtype, d_stride=(g, G)) for g in range(G)]
+        else:
+            shards = [P.DispEst(l, r, D, dtype=dtype, d_range=(d0, d1)) for d0, d1 in zip(dcuts[:-1], dcuts[1:])]
         try:
             for s in shards:
                 s.set_option(capi.PSM_OPT_FLAGS, flags)
