@@ -253,11 +253,19 @@ void k_cvf_pc(
     const size_t HW = (size_t)H * W;
 
     PC_TRACE_BEGIN()
-    const int nds = MODE == 1 ? DC : 1;               // MODE 0 / 2 always run with DC == 1 (one slice per workgroup)
+    // Slices of this chunk (MODE 0 / 2 always run with DC == 1: one slice per workgroup).  Round 6: consecutive slices of a chunk
+    // OVERLAP - the producers start slice s + 1 (its eight warm-up steps and first two batches) while the consumers finish the last
+    // two batches of slice s, instead of idling through them and making the consumers idle through the next warm-up.  Barriers per
+    // slice: nbB (was nbB + 3); the consumers' two leading barriers are executed once per chunk, the producers' three trailing ones
+    // after the last slice.  The ring keeps counting batches across slices (rb): the producers are never more than two batches ahead
+    // of what the consumers still read, within a slice as before and across the seam (slots rb+nbA, rb+nbA+1 are written while
+    // rb+nbA-2, rb+nbA-1 are read).
+    const int nds = MODE == 1 ? min(DC, Dloc - ch * DC) : 1;
     bool first = true;                                // no slice processed yet: the plane holds nothing
-    for (int ds = 0; ds < nds; ++ds) {                // the slices of this chunk, ascending d
+    int rb = 0;                                       // ring slot of this slice's model batch 0
+    for (int ds = 0; ds < nds; ++ds) {                // ascending d
     const int d = ch * DC + ds;
-    if (MODE == 1 && d >= Dloc) break;                // uniform over the workgroup
+    const bool last_slice = ds == nds - 1;
     if (is_a) {
         // ---------------- producer: stage A ----------------
         // step s reads input row mstart-5+s; from step 8 on it yields model row mstart+(s-8)
@@ -378,7 +386,7 @@ void k_cvf_pc(
 #define PSM_BATCH_PA(B)                                                                            \
         {                                                                                          \
             const int s0 = 8 + (B) * 4;                                                            \
-            float4 *dst = &ring[(B) & (PC_RING - 1)][0][wave * PC_OUT_A + lane];                   \
+            float4 *dst = &ring[((B) + rb) & (PC_RING - 1)][0][wave * PC_OUT_A + lane];            \
             PSM_STEP_PA(0, s0, dst) PSM_STEP_PA(1, s0 + 1, dst) PSM_STEP_PA(2, s0 + 2, dst) PSM_STEP_PA(3, s0 + 3, dst) \
             PC_SYNC();                                                                             \
         }
@@ -389,7 +397,7 @@ void k_cvf_pc(
             if (__builtin_expect(b + 1 < nbA, 1)) PSM_BATCH_PA(b + 1)
         }
 #undef PSM_BATCH_PA
-        for (int b = nbA; b < iters; ++b) PC_SYNC();
+        for (int b = nbA; b < (last_slice ? iters : nbB); ++b) PC_SYNC();      // (the three trailing barriers: after the chunk's last slice only)
 #undef PSM_STEP_PA
 #undef PSM_ISSUE_PA
 #undef PSM_ISSUE_PIX
@@ -451,7 +459,7 @@ void k_cvf_pc(
         auto model_of = [&](int J) -> const float4 * {
             int a = r101(y0 - 4 + J, H) - mstart;
             a = a < 0 ? 0 : (a > amax ? amax : a);
-            return &ring[(a >> 2) & (PC_RING - 1)][a & 3][mc];
+            return &ring[((a >> 2) + rb) & (PC_RING - 1)][a & 3][mc];
         };
         // MODE 0: merged store of output batch `c` (rows parked in qbuf[c & 1] one iteration earlier)
         auto store_batch = [&](int c) {
@@ -487,8 +495,10 @@ void k_cvf_pc(
             }
         }
         if constexpr (MODE == 2) { PSM_KEY_LOAD1(0, 0) PSM_KEY_LOAD1(1, 1) }
-        PC_SYNC();                               // iteration 0
-        PC_SYNC();                               // iteration 1
+        if (ds == 0) {                           // (two batches behind the producers: once per chunk - later slices stay in step)
+            PC_SYNC();                           // iteration 0
+            PC_SYNC();                           // iteration 1
+        }
         // (two batches per loop iteration, as in the producer: no register moves of the s4 slots at the latch)
         auto batch_b = [&](const int c) __attribute__((always_inline)) {   // consume feed batch c
             if (c >= 1) store_batch(c - 1);
@@ -559,13 +569,14 @@ void k_cvf_pc(
             if (__builtin_expect(c + 1 < nbB, 1)) batch_b(c + 1);
         }
         store_batch(nbB - 1);                          // iteration nbB+2
-        PC_SYNC();
+        if (last_slice) PC_SYNC();
 #undef PSM_ISSUE_PB
 #undef PSM_KEY_LOAD1
 #undef PSM_K_LOAD
     }
     if (MODE == 1) __builtin_amdgcn_s_waitcnt(0);      // the chunk planes of this slice are in the L2 before the next slice reads them
     first = false;
+    rb = (rb + nbA) & (PC_RING - 1);
     }   // slices of the chunk
 #undef PSM_BOX
     if (ts != nullptr && threadIdx.x == 0)            // ... and when did the last one end (all waves have passed the last barrier)
