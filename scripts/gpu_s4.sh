@@ -1,4 +1,6 @@
 #!/bin/bash
+# (round 6 experiment session: strided shards; the libprimesm_hip_kaux{0,1}.so variants were built with -DPSM_KEY_AUX=0/1 - the
+# macro is gone now that the policy is settled, profiles/r06/exp_key_load_policy.txt)
 # experiments: strided disparity shards (two-phase on a 32-slice shard), key-load cache policy at 4K / 1080p; tests of the strided path
 TAG=${1:-r6d}
 OUT=$GRAFT_REPO_ROOT/gpurun_out/$TAG

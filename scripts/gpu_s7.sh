@@ -1,4 +1,5 @@
 #!/bin/bash
+# (libprimesm_hip_prev.so = the library of the commit before, built into lib/ for the same-box A/B: git stash; make OUT=../lib/libprimesm_hip_prev.so OBJDIR=../lib/obj_prev)
 # overlap of consecutive slices of a chunk (plane form): correctness + same-box A/B against the library before it
 TAG=${1:-r6s}
 OUT=$GRAFT_REPO_ROOT/gpurun_out/$TAG
