@@ -49,7 +49,7 @@ cp profiles/traffic.json $OUT/traffic.json
 echo "== bench (default: c4, N=1) - the headline line"
 timeout 900 python bench.py --box-bench --verify --pp > $OUT/bench_c4_n1.json 2> $OUT/bench_c4.err; cat $OUT/bench_c4_n1.json; tail -2 $OUT/bench_c4.err
 B="timeout 600 python bench.py"
-$B --config c3 --verify --pp > $OUT/bench_c3_n1.json 2>> $OUT/bench_var.err
+$B --config c3 --steps 30 --warmup 5 --verify --pp > $OUT/bench_c3_n1.json 2>> $OUT/bench_var.err
 $B --config c2 --steps 30 --verify --pp > $OUT/bench_c2_n1.json 2>> $OUT/bench_var.err
 $B --config c5 --steps 4 --warmup 1 --verify --no-cpu-wide > $OUT/bench_c5_n1.json 2>> $OUT/bench_var.err
 $B --config c1 --steps 30 --verify > $OUT/bench_c1_u8_n1.json 2>> $OUT/bench_var.err
