@@ -89,24 +89,32 @@ int psm_wgt_median(psm_ctx *c, uint8_t *lmap, uint8_t *rmap, size_t stride)
     if (!dataflow_only) {
         // parallel form: sweeps to the fixed point of the in-place recursion (psm_pp.hip), both maps side by side
         const size_t nb = (HW + 255) / 256 * 256, ncnt = 2 * (size_t)(96 + 2);
-        const size_t per_side = 4 * nb + (6 * nb + ncnt) * sizeof(int);
-        if (!c->wm_par) PSM_HIP(c, hipMalloc((void **)&c->wm_par, 2 * per_side));
-        uint8_t *orig[2], *newv[2], *chgb[2], *rowany[2];
-        int *stamp[2], *list[2][2], *chg[2], *cnt[2], *slot_of[2], *inv[2];
+        const size_t per_side = 4 * nb + 6 * nb * sizeof(int);       // (the counters of both maps follow the two sides: one fill, one snapshot)
+        if (!c->wm_par) PSM_HIP(c, hipMalloc((void **)&c->wm_par, 2 * per_side + 2 * ncnt * sizeof(int)));
+        int *const cnt0 = reinterpret_cast<int *>(c->wm_par + 2 * per_side);
+        WmPair pr;
+        int *cnt[2], *inv[2], *slot_of[2];
         for (int s = 0; s < 2; ++s) {
             uint8_t *b = c->wm_par + s * per_side;
-            orig[s] = b; newv[s] = b + nb; chgb[s] = b + 2 * nb; rowany[s] = b + 3 * nb;
             int *ip = reinterpret_cast<int *>(b + 4 * nb);
-            stamp[s] = ip; list[s][0] = ip + nb; list[s][1] = ip + 2 * nb; chg[s] = ip + 3 * nb; slot_of[s] = ip + 4 * nb; inv[s] = ip + 5 * nb; cnt[s] = ip + 6 * nb;
-            PSM_HIP(c, hipMemcpyAsync(orig[s], c->maps + s * HW, HW, hipMemcpyDeviceToDevice, c->stream));
-            PSM_HIP(c, hipMemsetAsync(chgb[s], 0, 2 * nb + nb * sizeof(int), c->stream));      // chgb, rowany, stamp (contiguous)
-            PSM_HIP(c, hipMemsetAsync(cnt[s], 0, ncnt * sizeof(int), c->stream));
-            launch_wm_seed(c->stream, c->valid + s * HW, c->W, c->H, inv[s], cnt[s]);     // all invalid pixels = the first sweep's list
+            WmSide &a = pr.s[s];
+            a.cur = c->maps + s * HW; a.valid = c->valid + s * HW; a.g1 = c->g[s].g1;
+            a.orig = b; a.newv = b + nb; a.chgb = b + 2 * nb; a.rowany = b + 3 * nb;
+            a.stamp = ip; a.list[0] = ip + nb; a.list[1] = ip + 2 * nb; a.chg = ip + 3 * nb; a.slot_of = ip + 4 * nb; a.inv = ip + 5 * nb;
+            a.cnt = cnt0 + s * ncnt; a.wts = nullptr;
+            cnt[s] = a.cnt; inv[s] = a.inv; slot_of[s] = a.slot_of;
         }
+        const size_t snap = 2 * ncnt;                      // ints per counter snapshot (both maps)
+        if (!c->wm_pin) PSM_HIP(c, hipHostMalloc((void **)&c->wm_pin, 2 * snap * sizeof(int), hipHostMallocDefault));
+        for (hipEvent_t *e : {&c->ev_wm[0], &c->ev_wm[1]})
+            if (!*e) PSM_HIP(c, hipEventCreateWithFlags(e, hipEventDisableTiming));
+        PSM_HIP(c, hipMemsetAsync(cnt0, 0, 2 * ncnt * sizeof(int), c->stream));
+        launch_wm_seed(c->stream, pr, c->W, c->H);     // all invalid pixels = the first sweep's lists; input copies; per-pixel state zeroed
         // Weight cache: the 19 x 19 weights of an invalid pixel depend on the image only, and the sweeps evaluate it ~5 times.
         // For sides with at least WM_LANE_MIN invalid pixels one pass forms them all (1.5 KB per invalid pixel; beyond
         // WM_CACHE_MAX bytes for the pair the evaluations form their weights themselves, as they do for short lists).
         float *wts[2] = {nullptr, nullptr};
+        bool cached = false;
         {
             // at most 12 GB, and never more than half of what the device has free right now: the volumes, the spare volume and
             // the FGF scratch of this or another context on the device are allocated on first use and must still fit
@@ -115,14 +123,16 @@ int psm_wgt_median(psm_ctx *c, uint8_t *lmap, uint8_t *rmap, size_t stride)
                 const size_t avail = mem_free + c->wm_wts_n * sizeof(float);     // (what we hold already counts as available to us)
                 if (avail / 2 < WM_CACHE_MAX) WM_CACHE_MAX = avail / 2;
             } else (void)hipGetLastError();
-            int n0[2];
-            for (int s = 0; s < 2; ++s) PSM_HIP(c, hipMemcpyAsync(&n0[s], cnt[s], sizeof(int), hipMemcpyDeviceToHost, c->stream));
+            // (the counts of invalid pixels through the same page-locked snapshot the sweeps use: one small kernel, no copy engine)
+            launch_copy_bytes(c->stream, c->wm_pin, cnt0, snap * sizeof(int));
             PSM_HIP(c, hipStreamSynchronize(c->stream));
+            const int n0[2] = {c->wm_pin[0], c->wm_pin[ncnt]};
             size_t need[2], tot = 0;
             for (int s = 0; s < 2; ++s) {      // (whole blocks of 64 pixels: the cache is laid out in such blocks)
-                need[s] = n0[s] >= WM_LANE_MIN ? (size_t)((n0[s] + 63) / 64 * 64) * WM_WPIX : 0;
+                need[s] = (size_t)((n0[s] + 63) / 64 * 64) * WM_WPIX;
                 tot += need[s];
             }
+            if (n0[0] < WM_LANE_MIN && n0[1] < WM_LANE_MIN) tot = 0;      // (short lists form their weights themselves; a launch takes both maps one way)
             if (tot && tot * sizeof(float) <= WM_CACHE_MAX && !(c->march.flags & PSM_FLAG_WMF_NO_CACHE)) {
                 if (c->wm_wts_n < tot) {
                     (void)hipFree(c->wm_wts);
@@ -132,11 +142,14 @@ int psm_wgt_median(psm_ctx *c, uint8_t *lmap, uint8_t *rmap, size_t stride)
                     else (void)hipGetLastError();           // no memory for it: recompute, as without the cache
                 }
                 if (c->wm_wts_n >= tot) {
-                    if (need[0]) wts[0] = c->wm_wts;
-                    if (need[1]) wts[1] = c->wm_wts + need[0];
+                    wts[0] = c->wm_wts;
+                    wts[1] = c->wm_wts + need[0];
+                    cached = true;
                     Prof p(c, PSM_K_WMF);
-                    for (int s = 0; s < 2; ++s)
-                        if (wts[s]) launch_wm_weights(c->stream, c->g[s].g1, c->W, c->H, s, inv[s], cnt[s], n0[s], wts[s], slot_of[s]);
+                    for (int s = 0; s < 2; ++s) {
+                        pr.s[s].wts = wts[s];
+                        if (n0[s]) launch_wm_weights(c->stream, c->g[s].g1, c->W, c->H, s, inv[s], cnt[s], n0[s], wts[s], slot_of[s]);
+                    }
                 }
             }
         }
@@ -144,28 +157,21 @@ int psm_wgt_median(psm_ctx *c, uint8_t *lmap, uint8_t *rmap, size_t stride)
         // next list?) while the NEXT group is already queued - the device never idles behind a host round trip (round 3: ~65 us
         // of idle per check, 0.7 ms of the 4.0 on the 1080p bench pair).  A group launched for a map that had already reached
         // its fixed point is a handful of launches over empty lists.
-        const size_t snap = 2 * ncnt;                      // ints per counter snapshot (both maps)
-        if (!c->wm_pin) PSM_HIP(c, hipHostMalloc((void **)&c->wm_pin, 2 * snap * sizeof(int), hipHostMallocDefault));
-        for (hipEvent_t *e : {&c->ev_wm[0], &c->ev_wm[1]})
-            if (!*e) PSM_HIP(c, hipEventCreateWithFlags(e, hipEventDisableTiming));
         int sw = 0;                        // sweeps launched
         bool tail[2] = {false, false};     // the list going into the next sweep is short: two launches per sweep, more sweeps per check
         int upto[2] = {0, 0};              // sweeps covered by the snapshot in slot g & 1
         auto launch_group = [&](int slot) -> int {
-            const int chk = ((tail[0] || done[0]) && (tail[1] || done[1])) ? 2 * CHK : CHK;
+            const bool short_lists = (tail[0] || done[0]) && (tail[1] || done[1]);
+            const int chk = short_lists ? 2 * CHK : CHK;
             const int end = sw + chk < CAP ? sw + chk : CAP;
             {
                 Prof p(c, PSM_K_WMF);
-                for (; sw < end; ++sw)
-                    for (int s = 0; s < 2; ++s)
-                        if (!done[s])
-                            launch_wm_sweep(c->stream, c->maps + s * HW, orig[s], c->valid + s * HW, c->g[s].g1, c->W, c->H, c->D, s,
-                                            sw == 0 ? inv[s] : list[s][(sw + 1) & 1], cnt[s] + 2 * sw, newv[s], chg[s], cnt[s] + 2 * sw + 1, stamp[s], sw + 1,
-                                            list[s][sw & 1], cnt[s] + 2 * (sw + 1), wts[s], slot_of[s], inv[s], cnt[s], chgb[s], rowany[s], tail[s]);
+                // (a map that has reached its fixed point has empty lists from then on: its half of a launch returns at once)
+                for (; sw < end; ++sw) launch_wm_sweep(c->stream, pr, c->W, c->H, c->D, sw, cached, short_lists);
             }
             if (check_launch(c, "wgt_median (sweeps)")) return 1;
-            for (int s = 0; s < 2; ++s)      // (a kernel writing the page-locked snapshot: a copy-engine transfer in the stream stalls it for ~60 us)
-                launch_copy_bytes(c->stream, c->wm_pin + slot * snap + s * ncnt, cnt[s], ncnt * sizeof(int));
+            // (a kernel writing the page-locked snapshot: a copy-engine transfer in the stream stalls it for ~60 us)
+            launch_copy_bytes(c->stream, c->wm_pin + slot * snap, cnt0, snap * sizeof(int));
             PSM_HIP(c, hipEventRecord(c->ev_wm[slot], c->stream));
             upto[slot] = sw;
             return 0;
@@ -189,14 +195,25 @@ int psm_wgt_median(psm_ctx *c, uint8_t *lmap, uint8_t *rmap, size_t stride)
                         break;
                     }
                 }
-                tail[s] = seen < CAP && h[s * ncnt + 2 * seen] <= 2048;      // (the count the last sweep of the group left for the next one)
+                tail[s] = seen < CAP && h[s * ncnt + 2 * seen] < WM_LANE_MIN;      // (the count the last sweep of the group left for the next one: wave form)
             }
             if ((done[0] && done[1]) || !more) break;
         }
+#ifdef PSM_EXPERIMENTS
+        if (getenv("PSM_WM_TRACE")) {      // per sweep: pixels evaluated / changed (both maps)
+            std::vector<int> hc(ncnt);
+            for (int s = 0; s < 2; ++s) {
+                PSM_HIP(c, hipMemcpy(hc.data(), cnt[s], ncnt * sizeof(int), hipMemcpyDeviceToHost));
+                fprintf(stderr, "[wm] side %d:", s);
+                for (int k = 0; k < sw && k < 96; ++k) fprintf(stderr, " %d/%d", hc[2 * k], hc[2 * k + 1]);
+                fprintf(stderr, "\n");
+            }
+        }
+#endif
         // no fixed point within CAP sweeps (long chains of pixels that keep flipping each other): start over from the input
         // with the dataflow form, which is exact for any input
         for (int s = 0; s < 2; ++s)
-            if (!done[s]) PSM_HIP(c, hipMemcpyAsync(c->maps + s * HW, orig[s], HW, hipMemcpyDeviceToDevice, c->stream));
+            if (!done[s]) PSM_HIP(c, hipMemcpyAsync(c->maps + s * HW, pr.s[s].orig, HW, hipMemcpyDeviceToDevice, c->stream));
     }
     for (int s = 0; s < 2; ++s)
         if (!done[s] && wgt_median_dataflow(c, s)) return 1;

@@ -132,10 +132,21 @@ void launch_wgt_median(hipStream_t s, uint8_t *dis, const uint8_t *valid, const 
 constexpr int WM_LANE_MIN = 8192;       // active pixels from which a sweep evaluates one pixel per LANE (k_wm_eval) instead of per wave
 constexpr int WM_WROW = 20;             // floats per window row of the weight cache (19 weights + 1 pad: five float4)
 constexpr int WM_WPIX = 19 * WM_WROW;   // floats per cached pixel
-void launch_wm_seed(hipStream_t s, const uint8_t *valid, int W, int H, int *list, int *cnt);
-void launch_wm_sweep(hipStream_t s, uint8_t *cur, const uint8_t *orig, const uint8_t *valid, const float4 *g1, int W, int H, int maxDis,
-                     int right, const int *act, const int *n_act, uint8_t *newv, int *chg, int *n_chg, int *stamp, int mark,
-                     int *next, int *n_next, const float *wts, const int *slot_of, const int *inv, const int *n_inv, uint8_t *chgb, uint8_t *rowany, bool tail);
+// One map's share of the sweep state.  Sweep k (0-based) evaluates the list act = k ? list[(k + 1) & 1] : inv, whose length is
+// cnt[2k]; it leaves the number of changed pixels in cnt[2k + 1], the changed pixels in chg, and the next sweep's list in
+// list[k & 1] / cnt[2k + 2]; cnt[0] is the number of invalid pixels (inv).  Both maps go through every launch side by side
+// (blockIdx.y): below the first sweeps a kernel is a few hundred waves, and the two maps are independent.
+struct WmSide {
+    uint8_t *cur;                 // the map, filtered in place
+    const uint8_t *valid;
+    const float4 *g1;
+    uint8_t *orig, *newv, *chgb, *rowany;      // input copy, new values of changed pixels, byte maps of the gather form
+    int *stamp, *list[2], *chg, *slot_of, *inv, *cnt;
+    const float *wts;             // weight cache of this map (null: none, or an empty map)
+};
+struct WmPair { WmSide s[2]; };
+void launch_wm_seed(hipStream_t s, const WmPair &p, int W, int H);
+void launch_wm_sweep(hipStream_t s, const WmPair &p, int W, int H, int maxDis, int sw, bool cached, bool tail);
 void launch_wm_weights(hipStream_t s, const float4 *g1, int W, int H, int right, const int *inv, const int *n_inv, int n, float *wts, int *slot_of);
 
 // ---- Fast Guided Filter variant (psm_fgf.hip); sub = subsample rate, small planes are (H/sub) x (W/sub) ----

@@ -252,16 +252,43 @@ __device__ __forceinline__ int wm_append(int *cnt, bool want)
     return base + before;
 }
 
-// the invalid pixels of a map as a list (any order): 16 pixels per thread, one atomic per wave
+// Start of a call, both maps per launch: the invalid pixels of a map as a list (any order; 16 pixels per thread, one atomic per
+// wave), the input copy `orig` the later taps of a window are read from, and the per-pixel sweep state (stamp, the gather form's
+// byte maps) zeroed - round 6: one launch where seeds, copies and fills were eight.
 constexpr int WM_SEED_PER = 16;
-__global__ __launch_bounds__(256) void k_wm_seed(const uint8_t *__restrict__ valid, int HW, int *__restrict__ list, int *cnt)
-{
+__global__ __launch_bounds__(256) void k_wm_seed(WmPair pr, int HW, int nb)
+{   // nb: length of the scratch planes (HW rounded up to whole blocks of 256 pixels)
+    const WmSide &a = pr.s[blockIdx.y];
     const int lane = threadIdx.x & 63;
     const int base = (blockIdx.x * blockDim.x + threadIdx.x) * WM_SEED_PER;
+    typedef unsigned wm_u32 __attribute__((aligned(1)));
     unsigned m = 0;                                   // bit k: pixel base + k is invalid
+    uint4 dv = make_uint4(0u, 0u, 0u, 0u);
+    if (base + WM_SEED_PER <= HW) {
+        const wm_u32 *pv = reinterpret_cast<const wm_u32 *>(a.valid + base), *pd = reinterpret_cast<const wm_u32 *>(a.cur + base);
+        unsigned v[4] = {pv[0], pv[1], pv[2], pv[3]};
+        dv = make_uint4(pd[0], pd[1], pd[2], pd[3]);
 #pragma unroll
-    for (int k = 0; k < WM_SEED_PER; ++k)
-        if (base + k < HW && valid[base + k] == 0) m |= 1u << k;
+        for (int k = 0; k < WM_SEED_PER; ++k)
+            if (((v[k >> 2] >> (8 * (k & 3))) & 0xffu) == 0u) m |= 1u << k;
+    } else {
+        unsigned d[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int k = 0; k < WM_SEED_PER; ++k)
+            if (base + k < HW) {
+                if (a.valid[base + k] == 0) m |= 1u << k;
+                d[k >> 2] |= (unsigned)a.cur[base + k] << (8 * (k & 3));
+            }
+        dv = make_uint4(d[0], d[1], d[2], d[3]);
+    }
+    if (base < nb) {
+        const uint4 z = make_uint4(0u, 0u, 0u, 0u);
+        *reinterpret_cast<uint4 *>(a.orig + base) = dv;
+        *reinterpret_cast<uint4 *>(a.chgb + base) = z;
+        *reinterpret_cast<uint4 *>(a.rowany + base) = z;
+#pragma unroll
+        for (int k = 0; k < WM_SEED_PER / 4; ++k) reinterpret_cast<uint4 *>(a.stamp + base)[k] = z;
+    }
     const int c = __builtin_popcount(m);
     int incl = c;                                     // inclusive prefix sum over the wave
 #pragma unroll
@@ -272,13 +299,13 @@ __global__ __launch_bounds__(256) void k_wm_seed(const uint8_t *__restrict__ val
     const int total = __shfl(incl, 63);
     if (total == 0) return;
     int wbase = 0;
-    if (lane == 63) wbase = atomicAdd(cnt, total);
+    if (lane == 63) wbase = atomicAdd(a.cnt, total);
     wbase = __shfl(wbase, 63);
     int slot = wbase + incl - c;
     while (m) {
         const int k = __builtin_ctz(m);
         m &= m - 1;
-        list[slot++] = base + k;
+        a.inv[slot++] = base + k;
     }
 }
 
@@ -345,12 +372,11 @@ __global__ __launch_bounds__(256) void k_wm_weights(const float4 *__restrict__ g
 }
 
 template <bool RIGHT, bool CACHED>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2))) void k_wm_eval(const uint8_t *__restrict__ cur, const uint8_t *__restrict__ orig,
-                                               const float4 *__restrict__ g1, const int *__restrict__ list, const int *n_act,
-                                               uint8_t *__restrict__ newv, int *__restrict__ chg, int *n_chg, int W, int H, int maxDis,
-                                               const float4 *__restrict__ wts, const int *__restrict__ slot_of)
-{
-    extern __shared__ float hist[];          // [maxDis][64], all zero between two evaluations
+__device__ __forceinline__ void wm_eval_lanes(float *hist, const uint8_t *__restrict__ cur, const uint8_t *__restrict__ orig,
+                                              const float4 *__restrict__ g1, const int *__restrict__ list, const int *n_act,
+                                              uint8_t *__restrict__ newv, int *__restrict__ chg, int *n_chg, int W, int H, int maxDis,
+                                              const float4 *__restrict__ wts, const int *__restrict__ slot_of)
+{   // hist: [maxDis][64] floats of LDS, all zero between two evaluations
     const int lane = threadIdx.x;
     const int n = *n_act;
     if (n < WM_LANE_MIN) return;               // short lists: k_wm_eval_w (latency of one evaluation instead of a batch's)
@@ -368,13 +394,17 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2))) void
         // One window row at a time: its loads (five dwords of disparities and five float4 of cached weights, or the 19 g1 values
         // the weights are formed from; every lane its own pixel: uncoalesced) are all issued before the row is accumulated, and
         // the next row's are in flight meanwhile.
-        float4 gq[2][CACHED ? WM_WROW / 4 : WM_K];     // CACHED: the row's weights instead of its g1 values
+        // P - 1 rows' loads are in flight ahead of the row being accumulated.  (Round 6 tried P = 4 with the cache - 25 registers a
+        // row - on the theory that two waves per CU cannot hide a load: 6 % SLOWER at 1080p, 19 % at 450 x 375.  The kernel is
+        // bound by the ~30 instructions a tap costs at one wave per SIMD, not by the loads' latency.)
+        constexpr int P = 2;
+        float4 gq[P][CACHED ? WM_WROW / 4 : WM_K];     // CACHED: the row's weights instead of its g1 values
         // the 19 disparities of a window row, packed four to a dword.  A row is 19 consecutive bytes of one plane (the current
         // iterate for an earlier row, the input for a later one; the pixel's own row: left of it / from it on) unless the window
         // wraps around the image's left or right edge: five unaligned dword loads instead of 19 byte loads - every lane reads
         // its own pixel's window, so each load instruction walks 64 cache lines whatever its width.
         typedef unsigned wm_u32 __attribute__((aligned(1)));
-        unsigned dq[2][5];
+        unsigned dq[P][5];
         const bool inner = x - WM_R >= 0 && x + WM_R + 1 < W;     // (the fifth dword's last byte is still inside the row)
         auto issue_row = [&](int slot, int wy) __attribute__((always_inline)) {
             int qy = y + wy;
@@ -428,28 +458,57 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2))) void
             // equal neighbours among them) was 2/3 of its instruction stream (PMC: 39 VALU + 39 scalar + 10 branch instructions per
             // tap).  A tap that does not vote (dep == 0, or dep >= maxDis: cannot come out of a WTA over maxDis slices) adds its
             // weight to bin 0, which nothing reads; adding +0.0f to the non-negative total is the identity.
+            // Round 6: the taps of a dword of disparities (four; the row's last: three) read their bins TOGETHER and are then
+            // added in tap order in registers - a tap whose bin an earlier tap of the group also hit continues from that tap's
+            // result instead of what it read, and the results are stored in tap order (the last store to a bin is its sum).  Every
+            // bin still sees its taps in raster order, one addition each: the same bits.  95 LDS round trips per pixel instead of
+            // 361: -10 % at D = 64 (450 x 375, 43 % invalid: 1.51 -> 1.35 ms), nothing at D = 256, where a SIMD holds one wave and
+            // the instruction count per tap binds (the compares cost what the waits did).
 #pragma unroll
-            for (int k = 0; k < WM_K; ++k) {
-                const unsigned dep = (dq[slot][k >> 2] >> (8 * (k & 3))) & 0xffu;
-                const float w = wk[k];
-                tot = __fadd_rn(tot, dep != 0u ? w : 0.0f);
-                const unsigned bin = dep < (unsigned)maxDis ? dep : 0u;
-                // (ds_add_f32 gives the same bits and needs no read, but measured 40 % slower: the LDS processes a 64-lane float
-                // atomic far below the rate of a read and a write)
-                float *hp = &hist[bin * 64u + lane];
-                *hp = __fadd_rn(*hp, w);
-                dlo = min(dlo, bin - 1u);              // (bin 0: 0xffffffff, no effect)
-                dhi = max(dhi, bin);
+            for (int g = 0; g < (WM_K + 3) / 4; ++g) {
+                constexpr int G = 4;
+                float *hp[G];
+                unsigned bin[G];
+                float h[G], r[G];
+#pragma unroll
+                for (int j = 0; j < G; ++j) {
+                    const int k = 4 * g + j;
+                    if (k >= WM_K) continue;
+                    const unsigned dep = (dq[slot][g] >> (8 * j)) & 0xffu;
+                    tot = __fadd_rn(tot, dep != 0u ? wk[k] : 0.0f);
+                    bin[j] = dep < (unsigned)maxDis ? dep : 0u;
+                    // (ds_add_f32 gives the same bits and needs no read, but measured 40 % slower: the LDS processes a 64-lane float
+                    // atomic far below the rate of a read and a write)
+                    hp[j] = &hist[bin[j] * 64u + lane];
+                    h[j] = *hp[j];
+                    dlo = min(dlo, bin[j] - 1u);           // (bin 0: 0xffffffff, no effect)
+                    dhi = max(dhi, bin[j]);
+                }
+#pragma unroll
+                for (int j = 0; j < G; ++j) {
+                    if (4 * g + j >= WM_K) continue;
+                    float v = h[j];
+#pragma unroll
+                    for (int i = 0; i < j; ++i) v = bin[i] == bin[j] ? r[i] : v;      // (ascending: the latest earlier tap of the bin wins)
+                    r[j] = __fadd_rn(v, wk[4 * g + j]);
+                }
+#pragma unroll
+                for (int j = 0; j < G; ++j)
+                    if (4 * g + j < WM_K) *hp[j] = r[j];
             }
         };
-        issue_row(0, -WM_R);
-        for (int wy = -WM_R; wy < WM_R; wy += 2) {     // rows wy (slot 0) and wy + 1 (slot 1); the last row after the loop
-            issue_row(1, wy + 1);
-            take_row(0, wy);
-            issue_row(0, wy + 2);
-            take_row(1, wy + 1);
+        // (19 rows = 9 P + P - 1)
+#pragma unroll
+        for (int j = 0; j < P - 1; ++j) issue_row(j, -WM_R + j);
+        for (int wy = -WM_R; wy + 2 * P - 2 <= WM_R; wy += P) {
+#pragma unroll
+            for (int j = 0; j < P; ++j) {
+                issue_row((j + P - 1) % P, wy + j + P - 1);
+                take_row(j, wy + j);
+            }
         }
-        take_row(0, WM_R);
+#pragma unroll
+        for (int j = 0; j < P - 1; ++j) take_row(j, WM_R - (P - 2) + j);
         // ---- threshold scan over the non-empty bins, ascending d (src/PP.cpp:184-192) ----
         const float half = __fdiv_rn(tot, 2.0f);
         float run = 0.0f;
@@ -484,17 +543,30 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2))) void
     }
 }
 
+// sweep `sw` of both maps (blockIdx.y); the cached form does not depend on the map (the weights kernel did)
+template <bool CACHED>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2))) void k_wm_eval(WmPair pr, int sw, int W, int H, int maxDis)
+{
+    extern __shared__ float hist[];
+    const WmSide &a = pr.s[blockIdx.y];
+    const int *act = sw ? a.list[(sw + 1) & 1] : a.inv;
+    if (CACHED || blockIdx.y == 0)
+        wm_eval_lanes<false, CACHED>(hist, a.cur, a.orig, a.g1, act, a.cnt + 2 * sw, a.newv, a.chg, a.cnt + 2 * sw + 1, W, H, maxDis, (const float4 *)a.wts, a.slot_of);
+    else
+        wm_eval_lanes<true, CACHED>(hist, a.cur, a.orig, a.g1, act, a.cnt + 2 * sw, a.newv, a.chg, a.cnt + 2 * sw + 1, W, H, maxDis, (const float4 *)a.wts, a.slot_of);
+}
+
 // Short active lists (the tail sweeps: a few hundred pixels whose evaluation latency is what the sweep costs): one WAVE per
 // pixel - the 361 weights of a pixel are evaluated by the 64 lanes in parallel, the histogram bins and the total are then
 // accumulated in window raster order (lane l owns bins l, l+64, ..: every lane scans the (disparity, weight) pairs from LDS
 // and adds the ones that fall into its bins).  ~10 us per evaluation instead of ~80 us for a batch of 64, at 30x the
 // instructions per evaluation.
 template <bool RIGHT, int NB, bool CACHED>
-__global__ __launch_bounds__(64) void k_wm_eval_w(const uint8_t *__restrict__ cur, const uint8_t *__restrict__ orig,
-                                               const float4 *__restrict__ g1, const int *__restrict__ list, const int *n_act,
-                                               uint8_t *__restrict__ newv, int *__restrict__ chg, int *n_chg, int W, int H, int maxDis,
-                                               const float *__restrict__ wts, const int *__restrict__ slot_of, int force)
-{
+__device__ __forceinline__ void wm_eval_wave(const uint8_t *__restrict__ cur, const uint8_t *__restrict__ orig,
+                                             const float4 *__restrict__ g1, const int *__restrict__ list, const int *n_act,
+                                             uint8_t *__restrict__ newv, int *__restrict__ chg, int *n_chg, int W, int H, int maxDis,
+                                             const float *__restrict__ wts, const int *__restrict__ slot_of, int force, int wg, int nwg)
+{   // wg of nwg: this wave's place among the waves that share the list
     // NB == 1: taps in window raster order.  NB > 1: the voting taps stably partitioned by dep / 64 (bucket j holds, in raster
     // order, the taps of the bins lane + 64 j, buckets back to back), so a lane walks every tap once instead of NB times;
     // wsum[] keeps the raster order for the total.
@@ -506,10 +578,11 @@ __global__ __launch_bounds__(64) void k_wm_eval_w(const uint8_t *__restrict__ cu
     if (!force && n >= WM_LANE_MIN) return;    // long lists: k_wm_eval (force: a tail sweep, launched without it)
     constexpr int WM_ROUNDS = (WM_TAPS + 63) / 64;
     const unsigned long long below = (1ull << lane) - 1ull;
-    for (int i = blockIdx.x; i < n; i += gridDim.x) {
+    for (int i = wg; i < n; i += nwg) {
         const int pix = list[i];
         const int y = pix / W, x = pix - y * W;
         const float4 p = g1[pix];
+        const int before = cur[pix];        // (read with the taps: nothing changes the map during an evaluation pass)
         int cntj[NB], basej[NB];
 #pragma unroll
         for (int j = 0; j < NB; ++j) cntj[j] = 0;
@@ -601,12 +674,23 @@ __global__ __launch_bounds__(64) void k_wm_eval_w(const uint8_t *__restrict__ cu
                 if (run >= half) { filterDep = b + 64 * j; found = true; }
             }
         }
-        if (lane == 0 && filterDep != (int)cur[pix]) {
+        if (lane == 0 && filterDep != before) {
             newv[pix] = (uint8_t)filterDep;
             chg[atomicAdd(n_chg, 1)] = pix;
         }
         __syncthreads();
     }
+}
+
+template <int NB, bool CACHED>
+__global__ __launch_bounds__(64) void k_wm_eval_w(WmPair pr, int sw, int W, int H, int maxDis, int force)
+{
+    const WmSide &a = pr.s[blockIdx.y];
+    const int *act = sw ? a.list[(sw + 1) & 1] : a.inv;
+    if (CACHED || blockIdx.y == 0)
+        wm_eval_wave<false, NB, CACHED>(a.cur, a.orig, a.g1, act, a.cnt + 2 * sw, a.newv, a.chg, a.cnt + 2 * sw + 1, W, H, maxDis, a.wts, a.slot_of, force, blockIdx.x, gridDim.x);
+    else
+        wm_eval_wave<true, NB, CACHED>(a.cur, a.orig, a.g1, act, a.cnt + 2 * sw, a.newv, a.chg, a.cnt + 2 * sw + 1, W, H, maxDis, a.wts, a.slot_of, force, blockIdx.x, gridDim.x);
 }
 
 // Which pixels does the next sweep evaluate?  Every invalid pixel that has a pixel changed by this sweep among the EARLIER taps
@@ -617,13 +701,16 @@ __global__ __launch_bounds__(64) void k_wm_eval_w(const uint8_t *__restrict__ cu
 //     7.7 of 19 ms at 1080p / 20 % invalid): the changed pixels mark themselves and the 19 columns around them in their own
 //     row (rowany[y][x] = "row y changed within x +- 9", plain byte stores of the sweep's mark), then every invalid pixel looks
 //     at rowany of the earlier rows of its window at its own column and at the earlier taps of its own row: <= 36 byte loads.
-// (measured at 1080p: the gather pass costs ~0.09 ms whatever changed, the scatter pass ~3 ns per changed pixel)
-__device__ __forceinline__ bool wm_gather_form(int n_chg, int n_inv) { return n_inv >= 4096 && (long long)n_chg * 16 >= n_inv; }
+// (measured at 1080p, both maps per launch: marks + gather pass ~0.07 ms whatever changed, the scatter pass ~12 ns per changed pixel)
+__device__ __forceinline__ bool wm_gather_form(int n_chg, int n_inv) { return n_inv >= 4096 && (long long)n_chg * 80 >= n_inv; }
 
-__global__ __launch_bounds__(256) void k_wm_gather(const int *__restrict__ inv, const int *n_inv, const int *n_chg,
-                                                  const uint8_t *__restrict__ chgb, const uint8_t *__restrict__ rowany, int mark,
-                                                  int *__restrict__ next, int *n_next, int W, int H)
+__global__ __launch_bounds__(256) void k_wm_gather(WmPair pr, int sw, int W, int H)
 {
+    const WmSide &a = pr.s[blockIdx.y];
+    const int *__restrict__ inv = a.inv, *n_inv = a.cnt, *n_chg = a.cnt + 2 * sw + 1;
+    const uint8_t *__restrict__ chgb = a.chgb, *__restrict__ rowany = a.rowany;
+    const int mark = sw + 1;
+    int *__restrict__ next = a.list[sw & 1], *n_next = a.cnt + 2 * (sw + 1);
     const int ninv = *n_inv;
     if (!wm_gather_form(*n_chg, ninv)) return;
     const int lane = threadIdx.x & 63;
@@ -647,14 +734,15 @@ __global__ __launch_bounds__(256) void k_wm_gather(const int *__restrict__ inv, 
 
 // the changed pixels take their new value; every invalid pixel LATER in raster order that has one of them in its window
 // is evaluated again in the next sweep (stamp: once)
-__global__ __launch_bounds__(64) void k_wm_apply(uint8_t *__restrict__ cur, const uint8_t *__restrict__ newv, const uint8_t *__restrict__ valid,
-                                                const int *__restrict__ chg, const int *n_chg, const int *n_inv, int *__restrict__ stamp, int mark,
-                                                int *__restrict__ next, int *n_next, int W, int H, uint8_t *__restrict__ chgb, uint8_t *__restrict__ rowany, int force)
+__device__ __forceinline__ void wm_apply(uint8_t *__restrict__ cur, const uint8_t *__restrict__ newv, const uint8_t *__restrict__ valid,
+                                         const int *__restrict__ chg, const int *n_chg, const int *n_inv, int *__restrict__ stamp, int mark,
+                                         int *__restrict__ next, int *n_next, int W, int H, uint8_t *__restrict__ chgb, uint8_t *__restrict__ rowany, int force,
+                                         int wg, int nwg)
 {
     const int lane = threadIdx.x;
     const int n = *n_chg;
     if (!force && wm_gather_form(n, *n_inv)) {   // gather form: only mark (one thread per changed pixel); k_wm_gather builds the next list
-        for (int i = blockIdx.x * 64 + lane; i < n; i += gridDim.x * 64) {
+        for (int i = wg * 64 + lane; i < n; i += nwg * 64) {
             const int pix = chg[i];
             const int y = pix / W, x = pix - y * W;
             cur[pix] = newv[pix];
@@ -665,7 +753,7 @@ __global__ __launch_bounds__(64) void k_wm_apply(uint8_t *__restrict__ cur, cons
         return;
     }
     constexpr int WM_ROUNDS = (WM_TAPS + 63) / 64;
-    for (int i = blockIdx.x; i < n; i += gridDim.x) {
+    for (int i = wg; i < n; i += nwg) {
         const int pix = chg[i];
         const int y = pix / W, x = pix - y * W;
         if (lane == 0) cur[pix] = newv[pix];
@@ -687,6 +775,13 @@ __global__ __launch_bounds__(64) void k_wm_apply(uint8_t *__restrict__ cur, cons
     }
 }
 
+__global__ __launch_bounds__(64) void k_wm_apply(WmPair pr, int sw, int W, int H, int force)
+{
+    const WmSide &a = pr.s[blockIdx.y];
+    wm_apply(a.cur, a.newv, a.valid, a.chg, a.cnt + 2 * sw + 1, a.cnt, a.stamp, sw + 1, a.list[sw & 1], a.cnt + 2 * (sw + 1), W, H, a.chgb, a.rowany, force,
+             blockIdx.x, gridDim.x);
+}
+
 // the 19 x 19 weights of the n_inv invalid pixels of `inv` (n = an upper bound of *n_inv, for the grid) -> wts, slot_of
 void launch_wm_weights(hipStream_t s, const float4 *g1, int W, int H, int right, const int *inv, const int *n_inv, int n, float *wts, int *slot_of)
 {
@@ -696,49 +791,38 @@ void launch_wm_weights(hipStream_t s, const float4 *g1, int W, int H, int right,
     else hipLaunchKernelGGL(k_wm_weights<false>, dim3(blocks), dim3(256), 0, s, g1, inv, n_inv, (float4 *)wts, slot_of, W, H);
 }
 
-void launch_wm_seed(hipStream_t s, const uint8_t *valid, int W, int H, int *list, int *cnt)
-{
+void launch_wm_seed(hipStream_t s, const WmPair &p, int W, int H)
+{   // (the counters of both maps are zero: the caller's memset)
     const int HW = W * H, per_block = 256 * WM_SEED_PER;
-    hipLaunchKernelGGL(k_wm_seed, dim3((HW + per_block - 1) / per_block), dim3(256), 0, s, valid, HW, list, cnt);
+    hipLaunchKernelGGL(k_wm_seed, dim3((HW + per_block - 1) / per_block, 2), dim3(256), 0, s, p, HW, (HW + 255) / 256 * 256);
 }
 
-// one sweep: evaluate list `act` (count *n_act) -> changed pixels (chg, *n_chg) -> applied, dependents -> list `next` (*n_next)
-void launch_wm_sweep(hipStream_t s, uint8_t *cur, const uint8_t *orig, const uint8_t *valid, const float4 *g1, int W, int H, int maxDis,
-                     int right, const int *act, const int *n_act, uint8_t *newv, int *chg, int *n_chg, int *stamp, int mark,
-                     int *next, int *n_next, const float *wts, const int *slot_of, const int *inv, const int *n_inv, uint8_t *chgb, uint8_t *rowany, bool tail)
-{   // tail: the host has seen a short list going into this sweep - only the one-wave-per-pixel evaluation and the scatter form of
-    // the dependents are launched (both made to take whatever the list turns out to be): two launches instead of four
-    // wts / slot_of: the weight cache (launch_wm_weights) or null; inv / n_inv: the list of all invalid pixels (the first sweep's
-    // list); chgb, rowany: byte maps of the gather form (zero at the start)
-    const bool cached = wts != nullptr;
-    const dim3 ga(2048);
+// sweep `sw` of both maps: evaluate the active lists -> changed pixels -> applied, dependents -> the next lists (WmSide)
+void launch_wm_sweep(hipStream_t s, const WmPair &p, int W, int H, int maxDis, int sw, bool cached, bool tail)
+{   // tail: the host has seen short lists going into this sweep on both maps - only the one-wave-per-pixel evaluation and the
+    // scatter form of the dependents are launched (both made to take whatever the lists turn out to be): two launches instead of
+    // four.  cached: both maps have their weight cache (launch_wm_weights).
+    const dim3 ga(2048, 2);
     // two waves per CU at D = 256 (64 KB of LDS each), up to ten at D <= 64; the grid strides over batches of 64 pixels
     const size_t lds = (size_t)maxDis * 64 * sizeof(float);
     const PcDev dev = pc_dev();
     const int per_cu = (int)(160 * 1024 / (lds > 16384 ? lds : 16384));
-    const dim3 ge(dev.nxcd * dev.cus_per_xcd * (per_cu < 1 ? 1 : per_cu));
+    const dim3 ge(dev.nxcd * dev.cus_per_xcd * (per_cu < 1 ? 1 : per_cu), 2);
     const int force = tail ? 1 : 0;
-#define PSM_LAUNCH_WL(R, CA) \
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_wm_eval<R, CA>), ge, dim3(64), lds, s, (const uint8_t *)cur, orig, g1, act, n_act, newv, chg, n_chg, W, H, maxDis, (const float4 *)wts, slot_of)
-    if (tail) {}
-    else if (right) { if (cached) PSM_LAUNCH_WL(true, true); else PSM_LAUNCH_WL(true, false); }
-    else { if (cached) PSM_LAUNCH_WL(false, true); else PSM_LAUNCH_WL(false, false); }
-#undef PSM_LAUNCH_WL
-    // ... and the one-wave-per-pixel form for short lists (either kernel returns at once when the list is not its size)
-    const int nb = (maxDis + 63) / 64;
-    const dim3 gw(8192);
-#define PSM_LAUNCH_WE(R, NBV, CA) \
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_wm_eval_w<R, NBV, CA>), gw, dim3(64), 0, s, (const uint8_t *)cur, orig, g1, act, n_act, newv, chg, n_chg, W, H, maxDis, wts, slot_of, force)
-#define PSM_LAUNCH_WE2(R, NBV) { if (cached) PSM_LAUNCH_WE(R, NBV, true); else PSM_LAUNCH_WE(R, NBV, false); }
-    if (right) {
-        if (nb <= 1) PSM_LAUNCH_WE2(true, 1) else if (nb == 2) PSM_LAUNCH_WE2(true, 2) else if (nb == 3) PSM_LAUNCH_WE2(true, 3) else PSM_LAUNCH_WE2(true, 4)
-    } else {
-        if (nb <= 1) PSM_LAUNCH_WE2(false, 1) else if (nb == 2) PSM_LAUNCH_WE2(false, 2) else if (nb == 3) PSM_LAUNCH_WE2(false, 3) else PSM_LAUNCH_WE2(false, 4)
+    if (!tail) {
+        if (cached) hipLaunchKernelGGL(k_wm_eval<true>, ge, dim3(64), lds, s, p, sw, W, H, maxDis);
+        else hipLaunchKernelGGL(k_wm_eval<false>, ge, dim3(64), lds, s, p, sw, W, H, maxDis);
     }
+    // ... and the one-wave-per-pixel form for short lists (either kernel returns at once when a list is not its size)
+    const int nb = (maxDis + 63) / 64;
+    const dim3 gw(8192, 2);
+#define PSM_LAUNCH_WE(NBV, CA) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_wm_eval_w<NBV, CA>), gw, dim3(64), 0, s, p, sw, W, H, maxDis, force)
+#define PSM_LAUNCH_WE2(NBV) { if (cached) PSM_LAUNCH_WE(NBV, true); else PSM_LAUNCH_WE(NBV, false); }
+    if (nb <= 1) PSM_LAUNCH_WE2(1) else if (nb == 2) PSM_LAUNCH_WE2(2) else if (nb == 3) PSM_LAUNCH_WE2(3) else PSM_LAUNCH_WE2(4)
 #undef PSM_LAUNCH_WE2
 #undef PSM_LAUNCH_WE
-    hipLaunchKernelGGL(k_wm_apply, ga, dim3(64), 0, s, cur, (const uint8_t *)newv, valid, (const int *)chg, (const int *)n_chg, n_inv, stamp, mark, next, n_next, W, H, chgb, rowany, force);
-    if (!tail) hipLaunchKernelGGL(k_wm_gather, dim3(2048), dim3(256), 0, s, inv, n_inv, (const int *)n_chg, (const uint8_t *)chgb, (const uint8_t *)rowany, mark, next, n_next, W, H);
+    hipLaunchKernelGGL(k_wm_apply, ga, dim3(64), 0, s, p, sw, W, H, force);
+    if (!tail) hipLaunchKernelGGL(k_wm_gather, dim3(2048, 2), dim3(256), 0, s, p, sw, W, H);
 }
 
 void launch_wgt_median(hipStream_t s, uint8_t *dis, const uint8_t *valid, const float4 *g1, int W, int H, int maxDis, int right,
