@@ -172,7 +172,7 @@ def parse_args():
                     help="c1 / c1x / c2: 'fixture' times the Middlebury pair BASELINE.json names instead of a synthetic pair of its size - Cones "
                          "(c1; c1x: its 384 x 288 crop) and Teddy (c2) from tests/golden/*_pair.npz, the images the reference ships")
     ap.add_argument("--frames-in-flight", type=int, default=0,
-                    help="(0 = default: 1 at N = 1, 2 per rank at N > 1)  F contexts of the configuration, each on its own stream, take the steps in turn - frame i + 1 is queued while "
+                    help="(0 = default: 1 at N = 1; 2 per rank for row stripes from N = 4 and for disparity shards from N = 2)  F contexts of the configuration, each on its own stream, take the steps in turn - frame i + 1 is queued while "
                          "frame i runs, so a frame's short kernels (prep, guidance, reduction) and the half-empty last round of its fused "
                          "launch run beside the next frame's fused kernel.  The reference's use is a frame loop (src/main.cpp:64-73); this is "
                          "that loop with two frames in the device's queues.  Measured: -9 % at 720p x 128, -19 % at 450 x 375 x 64, nothing at "
@@ -336,10 +336,11 @@ def main():
         if args.fgf:
             de.setSubsampleRate(args.fgf)
         # --frames-in-flight F: F - 1 more contexts with the same pair, geometry and options, each on its own stream; step i runs on
-        # context i % F.  Default (0): one frame at a time at N = 1 (the headline configuration does not gain), TWO per rank for
-        # N > 1 - a rank's share of the job is a short launch chain whose tails and small kernels hide under the next frame's
-        # fused kernel (1/8 row stripe of 1080p x 256: 1.015 -> 0.95 ms rank-local).
-        FIF = args.frames_in_flight if args.frames_in_flight > 0 else (2 if use_dist else 1)
+        # context i % F.  Default (0): one frame at a time at N = 1 (the headline configuration does not gain), TWO per rank where a
+        # rank's share of the job is a short launch chain whose tails and small kernels hide under the next frame's fused kernel:
+        # row stripes from N = 4 (rank-local, one GPU, 1080p x 256: 1/2 stripe 3.40 -> 3.51 ms, 1/4 1.84 -> 1.78, 1/8 1.01 -> 0.92),
+        # disparity shards from N = 2 (1/2: 3.74 -> 3.57, 1/4: 2.09 -> 2.06); profiles/r06/exp_frames_in_flight_by_share.txt, DESIGN.md 6.
+        FIF = args.frames_in_flight if args.frames_in_flight > 0 else (2 if use_dist and (world >= 4 or not rows_mode) else 1)
         if use_batch or args.fgf:
             FIF = 1
         ring = [de]

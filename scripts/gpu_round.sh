@@ -88,13 +88,13 @@ $B --config c5 --shard-sim 8 --steps 6 --warmup 2 > $OUT/bench_c5_shardsim_1of8.
 echo "== weighted median timing (hybrid sweeps form / dataflow form)"
 timeout 300 python scripts/dbg_wmf.py big > $OUT/wmf_timing.txt 2>&1; WM_FLAGS=4194304 timeout 300 python scripts/dbg_wmf.py >> $OUT/wmf_timing.txt 2>&1; tail -22 $OUT/wmf_timing.txt
 echo "== torch.distributed path on 1 GPU (RCCL, world_size 1): both sharding axes per invocation"
-D="timeout 600 python bench.py --gpus 1 --force-dist --steps 10 --warmup 3 --no-cpu-baseline"
+D="timeout 600 python bench.py --gpus 1 --force-dist --frames-in-flight 2 --steps 10 --warmup 3 --no-cpu-baseline"   # (two frames in flight per rank: what --gpus N runs from N = 4)
 $D > $OUT/bench_c4_dist_world1.json 2> $OUT/bench_dist1.err
 $D --shard disp > $OUT/bench_c4_dist_world1_disp.json 2>> $OUT/bench_dist1.err
 $D --no-frame-pipeline > $OUT/bench_c4_dist_world1_nopipeline.json 2>> $OUT/bench_dist1.err
-$D --frames-in-flight 1 > $OUT/bench_c4_dist_world1_fif1.json 2>> $OUT/bench_dist1.err
+${D/--frames-in-flight 2/--frames-in-flight 1} > $OUT/bench_c4_dist_world1_fif1.json 2>> $OUT/bench_dist1.err
 echo "== the N > 1 protocol with TWO ranks on this one GPU (RCCL first; gloo-staged exchange when RCCL refuses the duplicate device)"
-W2="timeout 900 python bench.py --gpus 2 --same-device --steps 10 --warmup 3"
+W2="timeout 900 python bench.py --gpus 2 --same-device --frames-in-flight 2 --steps 10 --warmup 3"
 $W2 > $OUT/bench_c4_world2_same_device.json 2> $OUT/bench_world2.err
 $W2 --shard disp > $OUT/bench_c4_world2_same_device_disp.json 2>> $OUT/bench_world2.err
 $W2 --no-frame-pipeline > $OUT/bench_c4_world2_same_device_nopipeline.json 2>> $OUT/bench_world2.err

@@ -69,7 +69,7 @@ def test_distributed_path_world2(shard, extra):
     DispSelect_merge(world = 2) on a real all-gather result, set_map_buffer(whole) / set_key_buffer alternation."""
     from primestereomatch_amd import capi
     same = () if capi.device_count() >= 2 else ("--same-device",)
-    j = _bench("--gpus", "2", "--shard", shard, "--config", "c3", "--steps", "4", "--warmup", "2", *same, *extra, timeout=900)   # bare command: self-launch
+    j = _bench("--gpus", "2", "--shard", shard, "--config", "c3", "--steps", "4", "--warmup", "2", "--frames-in-flight", "2", *same, *extra, timeout=900)   # bare command: self-launch
     assert j["n_gpus"] == 2 and j["config"]["ranks"] == 2 and j["config"]["shard"] == shard
     assert j["verified_vs_single_gpu"] is True and j["oracle_maps_equal"] is True
     a = j["alt_shard"]
@@ -122,8 +122,11 @@ def test_n_gt_1_line_explains_itself():
     """Round 5: ranks, backend, shard, exchange, frame pipeline and per-rank compute / collective ms for both axes."""
     j = _bench("--gpus", "1", "--force-dist", "--config", "c3", "--steps", "3", "--warmup", "1", "--no-cpu-baseline")
     assert j["ranks"] == 1 and j["exchange_backend"] == "nccl" and j["shard"] == "rows" and j["frame_pipeline"] is True
-    # round 6: two frames in flight per rank are the default of the distributed path, on both axes; every context of the ring
-    # ends with the same (verified) maps
+    # round 6: two frames in flight per rank are the distributed path's default where a rank's share is short enough to gain -
+    # row stripes from 4 ranks, disparity shards from 2 (measured per share, DESIGN.md 6) - so at world 1 only the other axis ...
+    assert j["config"]["frames_in_flight"] == 1 and j["alt_shard"]["frames_in_flight"] == 2
+    # ... and on request on both; every context of the ring ends with the same (verified) maps
+    j = _bench("--gpus", "1", "--force-dist", "--frames-in-flight", "2", "--config", "c3", "--steps", "3", "--warmup", "1", "--no-cpu-baseline")
     assert j["config"]["frames_in_flight"] == 2 and j["alt_shard"]["frames_in_flight"] == 2 and j["frames_in_flight_maps_equal"] is True
     assert j["verified_vs_single_gpu"] is True and j["alt_shard"]["verified_vs_single_gpu"] is True
     for rec in (j, j["alt_shard"]):
