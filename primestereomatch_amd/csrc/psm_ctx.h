@@ -85,7 +85,8 @@ struct psm_ctx {
     uint8_t *pinned2 = nullptr;         // second bounce buffer: psm_download_maps_async of frame i while frame i-1 is being read
     int *wm = nullptr;                  // psm_wgt_median scratch: nxt[H][W+1], prog[H], err[1]; allocated on first use
     uint8_t *wm_par = nullptr;          // scratch of its parallel (sweep) form, per side: orig, newv, chgb, rowany (bytes), stamp, 2 active lists, changed list,
-                                        // slot_of, the list of all invalid pixels, counters
+                                        // slot_of, the list of all invalid pixels; behind the two sides the per-sweep counters of both maps (one block:
+                                        // one fill, one snapshot) - the layout WmPair points into (psm_kernels.h)
     float *wm_wts = nullptr;            // ... the 19 x 19 window weights of every invalid pixel (formed once per call, read by every evaluation)
     size_t wm_wts_n = 0;
     int *wm_pin = nullptr;              // page-locked snapshots of the sweep counters (two slots: a group's counters are read while the next group runs)
