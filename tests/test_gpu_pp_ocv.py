@@ -96,6 +96,35 @@ def test_wgt_median_long_lists_with_and_without_the_weight_cache(psm, oracle, fl
     assert np.array_equal(gl, el) and np.array_equal(gr, er)
 
 
+@pytest.mark.parametrize("fl,fr", [(0.0, 0.5), (0.5, 0.0), (0.55, 0.02), (0.01, 0.6), (0.0, 0.0)])
+@pytest.mark.parametrize("flags", [0, 16777216])
+def test_wgt_median_unequal_maps_share_their_launches(psm, oracle, fl, fr, flags):
+    """Round 6: both maps go through every sweep launch side by side (WmPair) and one decision - weight cache or not, wave
+    form only or all four launches - holds for the pair.  Maps that differ in everything the decision looks at: one without a
+    single invalid pixel beside one with a long list, a short list (below WM_LANE_MIN: wave form, weights formed in place when
+    alone) beside a long one, nothing to do at all; 111 x 233 pixels is no multiple of the 16 pixels a thread of the seed launch
+    takes, so its tail path and the odd offset of the right map's planes run as well."""
+    from primestereomatch_amd import capi
+    H, W, D = 111, 233, 80
+    l, lm, rm, _, _ = _wm_inputs(H, W, D, seed=int(1000 * fl + 10 * fr) + 5, frac_invalid=0.5)
+    rng = np.random.default_rng(9)
+    lv = (rng.random((H, W)) >= fl).astype(np.uint8)
+    rv = (rng.random((H, W)) >= fr).astype(np.uint8)
+    r = np.roll(l, 4, axis=1)
+    with psm.DispEst(l, r, D) as de:
+        de.set_option(capi.PSM_OPT_FLAGS, flags)
+        for rep in range(2):              # (the second call reuses the sweep state, the cache and the counters of the first)
+            de.upload_maps(lm, rm, lv, rv)
+            de.WgtMedian_GPU()
+        gl, gr = de.lDisMap.copy(), de.rDisMap.copy()
+        sweeps, evals = de.wgt_median_stats()
+    el = oracle.wgt_median(oracle.u8_to_f32(l), lm, lv, D, right=False)
+    er = oracle.wgt_median(oracle.u8_to_f32(r), rm, rv, D, right=True)
+    print(f"[wmf] invalid {int((lv == 0).sum())} / {int((rv == 0).sum())}, flags {flags}: sweeps {sweeps}, evaluations {evals}")
+    assert np.array_equal(gl, el) and np.array_equal(gr, er)
+    assert min(sweeps) >= 1 and (fl > 0 or evals[0] == 0) and (fr > 0 or evals[1] == 0)
+
+
 @pytest.mark.parametrize("form", ["sweeps", "dataflow"])
 @pytest.mark.parametrize("name", ["cones", "teddy"])
 def test_wgt_median_after_lr_check_middlebury(psm, oracle, golden, name, form):
