@@ -34,8 +34,7 @@ int psm_fill_invalid(psm_ctx *c, uint8_t *lmap, uint8_t *rmap, size_t stride)
     const size_t HW = (size_t)c->W * c->H;
     {
         Prof p(c, PSM_K_LRC);
-        launch_fill_inv(c->stream, c->maps, c->valid, c->W, c->H);
-        launch_fill_inv(c->stream, c->maps + HW, c->valid + HW, c->W, c->H);
+        launch_fill_inv(c->stream, c->maps, c->valid, HW, c->W, c->H);
     }
     if (check_launch(c, "fill_inv")) return 1;
     // have_valid stays set: the mask still says which pixels the L-R check rejected, which is what the next stage of

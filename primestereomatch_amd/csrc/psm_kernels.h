@@ -122,7 +122,7 @@ void launch_lr_check(hipStream_t s, const uint8_t *l, const uint8_t *r, int W, i
                      uint8_t *rv);
 
 // fill invalid pixels of one map in place (valid: 0/1 per pixel)
-void launch_fill_inv(hipStream_t s, uint8_t *dis, const uint8_t *valid, int W, int H);
+void launch_fill_inv(hipStream_t s, uint8_t *dis, const uint8_t *valid, size_t side, int W, int H);   // both maps: the right one `side` bytes behind
 
 // weighted-median post-filter of one map, in place, with the reference's raster-order semantics (psm_pp.hip).
 // nxt: scratch of H*(W+1) ints, prog: H ints, err: 1 int (set to 1 if the dataflow watchdog fired)

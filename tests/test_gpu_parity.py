@@ -569,6 +569,33 @@ def test_fill_invalid_synthetic_width(psm, oracle):
         assert np.array_equal(de.lDisMap, filled)   # same pixels, src/PP.cpp:405-410); filling twice is idempotent
 
 
+@pytest.mark.parametrize("W", [9, 63, 64, 65, 127, 128, 129, 200, 450])
+def test_fill_invalid_validity_patterns(psm, oracle, W):
+    """Round 6: fillInv takes the nearest valid neighbours from a wave's ballot, chunk by chunk of 64 pixels with a carry - rows
+    without a valid pixel, with one at either end only, with valid runs that start or end on a chunk boundary, random rows; both
+    maps in one launch (different patterns left and right)."""
+    H, D = 24, 8
+    rng = np.random.default_rng(W)
+    l = rng.integers(0, 256, (H, W, 3), dtype=np.uint8)
+    lm = rng.integers(0, D, (H, W)).astype(np.uint8)
+    rm = rng.integers(0, D, (H, W)).astype(np.uint8)
+    lv = (rng.random((H, W)) > 0.6).astype(np.uint8)
+    rv = (rng.random((H, W)) > 0.95).astype(np.uint8)
+    lv[0] = 0                                   # nothing valid
+    lv[1] = 0; lv[1, 0] = 1                     # only the first pixel
+    lv[2] = 0; lv[2, W - 1] = 1                 # only the last
+    lv[3] = 1                                   # nothing to fill
+    lv[4] = 0; lv[4, min(63, W - 1)] = 1        # a single valid pixel on a chunk's last lane ...
+    lv[5] = 0; lv[5, min(64, W - 1)] = 1        # ... and on the next chunk's first
+    lv[6] = 1; lv[6, max(W - 70, 0):] = 0       # a long invalid tail across chunks
+    rv[7] = 1; rv[7, :min(70, W - 1)] = 0       # a long invalid head (right map)
+    with psm.DispEst(l, np.roll(l, 2, axis=1), D) as de:
+        de.upload_maps(lm, rm, lv, rv)
+        de.FillInv_GPU()
+        gl, gr = de.lDisMap.copy(), de.rDisMap.copy()
+    assert np.array_equal(gl, oracle.fill_inv(lm, lv)) and np.array_equal(gr, oracle.fill_inv(rm, rv))
+
+
 @pytest.mark.parametrize("W,H,D", [(96, 40, 9), (200, 33, 20), (100, 22, 5), (61, 21, 4), (450, 60, 70)])
 def test_lazy_cost_volume_equals_materialised(psm, oracle, W, H, D):
     """Default path: CostConst leaves the volumes virtual and the fused filter builds the costs on the fly
