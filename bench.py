@@ -185,6 +185,9 @@ def parse_args():
 
 def main():
     args = parse_args()
+    # (ranks launched by a driver's own torch.distributed.run come here directly: the host driver only supports dmabuf IPC, and
+    # RCCL's device-memory sharing fails with the legacy mode - hipIpcGetMemHandle: invalid argument)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     N = args.gpus
     if N < 1:
         raise SystemExit("bench.py: --gpus must be >= 1")
