@@ -562,11 +562,18 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2))) void
 // and adds the ones that fall into its bins).  ~10 us per evaluation instead of ~80 us for a batch of 64, at 30x the
 // instructions per evaluation.
 template <bool RIGHT, int NB, bool CACHED>
-__device__ __forceinline__ void wm_eval_wave(const uint8_t *__restrict__ cur, const uint8_t *__restrict__ orig,
+__device__ __forceinline__ void wm_eval_wave(const uint8_t *cur, const uint8_t *__restrict__ orig,
                                              const float4 *__restrict__ g1, const int *__restrict__ list, const int *n_act,
                                              uint8_t *__restrict__ newv, int *__restrict__ chg, int *n_chg, int W, int H, int maxDis,
-                                             const float *__restrict__ wts, const int *__restrict__ slot_of, int force, int wg, int nwg)
+                                             const float *__restrict__ wts, const int *__restrict__ slot_of, int force, int wg, int nwg,
+                                             uint8_t *curw, const uint8_t *__restrict__ valid, int *__restrict__ stamp, int mark,
+                                             int *__restrict__ next, int *n_next)
 {   // wg of nwg: this wave's place among the waves that share the list
+    // curw != null (the tail sweeps, round 6): a pixel that changes takes its new value AT ONCE and its wave queues the later
+    // invalid pixels of its window for the next sweep itself (what k_wm_apply does after the evaluations otherwise) - one launch a
+    // sweep.  Waves still evaluating may see the old value or the new one: either way the pixels that read it are evaluated again
+    // in the next sweep (they are exactly the ones queued here), and a sweep that changes nothing has read a map nobody wrote -
+    // the fixed point, which is unique (psm_api_pp.cpp).  Only the NUMBER of evaluations can differ from run to run.
     // NB == 1: taps in window raster order.  NB > 1: the voting taps stably partitioned by dep / 64 (bucket j holds, in raster
     // order, the taps of the bins lane + 64 j, buckets back to back), so a lane walks every tap once instead of NB times;
     // wsum[] keeps the raster order for the total.
@@ -674,7 +681,29 @@ __device__ __forceinline__ void wm_eval_wave(const uint8_t *__restrict__ cur, co
                 if (run >= half) { filterDep = b + 64 * j; found = true; }
             }
         }
-        if (lane == 0 && filterDep != before) {
+        if (curw) {
+            if (filterDep != before) {                 // (wave-uniform: every lane ran the same scan)
+                if (lane == 0) {
+                    curw[pix] = (uint8_t)filterDep;
+                    atomicAdd(n_chg, 1);
+                }
+#pragma unroll
+                for (int k = 0; k < WM_ROUNDS; ++k) {
+                    const int t = lane + 64 * k;
+                    bool want = false;
+                    int pp = 0;
+                    if (t < WM_TAPS) {
+                        const int wy = t / WM_K - WM_R, wx = t % WM_K - WM_R;
+                        // the pixel whose tap (wy, wx) is this one: (py + wy + H) % H == y, (px + wx + W) % W == x
+                        const int py = ((y - wy) % H + H) % H, px = ((x - wx) % W + W) % W;
+                        pp = py * W + px;
+                        want = pp > pix && valid[pp] == 0 && atomicExch(&stamp[pp], mark) != mark;
+                    }
+                    const int slot = wm_append(n_next, want);
+                    if (want) next[slot] = pp;
+                }
+            }
+        } else if (lane == 0 && filterDep != before) {
             newv[pix] = (uint8_t)filterDep;
             chg[atomicAdd(n_chg, 1)] = pix;
         }
@@ -687,10 +716,13 @@ __global__ __launch_bounds__(64) void k_wm_eval_w(WmPair pr, int sw, int W, int 
 {
     const WmSide &a = pr.s[blockIdx.y];
     const int *act = sw ? a.list[(sw + 1) & 1] : a.inv;
+    uint8_t *const curw = force ? a.cur : nullptr;       // (force = the tail sweeps: evaluation and dependents in this one launch)
     if (CACHED || blockIdx.y == 0)
-        wm_eval_wave<false, NB, CACHED>(a.cur, a.orig, a.g1, act, a.cnt + 2 * sw, a.newv, a.chg, a.cnt + 2 * sw + 1, W, H, maxDis, a.wts, a.slot_of, force, blockIdx.x, gridDim.x);
+        wm_eval_wave<false, NB, CACHED>(a.cur, a.orig, a.g1, act, a.cnt + 2 * sw, a.newv, a.chg, a.cnt + 2 * sw + 1, W, H, maxDis, a.wts, a.slot_of, force, blockIdx.x, gridDim.x,
+                                        curw, a.valid, a.stamp, sw + 1, a.list[sw & 1], a.cnt + 2 * (sw + 1));
     else
-        wm_eval_wave<true, NB, CACHED>(a.cur, a.orig, a.g1, act, a.cnt + 2 * sw, a.newv, a.chg, a.cnt + 2 * sw + 1, W, H, maxDis, a.wts, a.slot_of, force, blockIdx.x, gridDim.x);
+        wm_eval_wave<true, NB, CACHED>(a.cur, a.orig, a.g1, act, a.cnt + 2 * sw, a.newv, a.chg, a.cnt + 2 * sw + 1, W, H, maxDis, a.wts, a.slot_of, force, blockIdx.x, gridDim.x,
+                                       curw, a.valid, a.stamp, sw + 1, a.list[sw & 1], a.cnt + 2 * (sw + 1));
 }
 
 // Which pixels does the next sweep evaluate?  Every invalid pixel that has a pixel changed by this sweep among the EARLIER taps
@@ -799,9 +831,9 @@ void launch_wm_seed(hipStream_t s, const WmPair &p, int W, int H)
 
 // sweep `sw` of both maps: evaluate the active lists -> changed pixels -> applied, dependents -> the next lists (WmSide)
 void launch_wm_sweep(hipStream_t s, const WmPair &p, int W, int H, int maxDis, int sw, bool cached, bool tail)
-{   // tail: the host has seen short lists going into this sweep on both maps - only the one-wave-per-pixel evaluation and the
-    // scatter form of the dependents are launched (both made to take whatever the lists turn out to be): two launches instead of
-    // four.  cached: both maps have their weight cache (launch_wm_weights).
+{   // tail: the host has seen short lists going into this sweep on both maps - only the one-wave-per-pixel evaluation is launched
+    // (made to take whatever the lists turn out to be), and it applies its changes and queues their dependents itself: one launch
+    // instead of four.  cached: both maps have their weight cache (launch_wm_weights).
     const dim3 ga(2048, 2);
     // two waves per CU at D = 256 (64 KB of LDS each), up to ten at D <= 64; the grid strides over batches of 64 pixels
     const size_t lds = (size_t)maxDis * 64 * sizeof(float);
@@ -821,8 +853,9 @@ void launch_wm_sweep(hipStream_t s, const WmPair &p, int W, int H, int maxDis, i
     if (nb <= 1) PSM_LAUNCH_WE2(1) else if (nb == 2) PSM_LAUNCH_WE2(2) else if (nb == 3) PSM_LAUNCH_WE2(3) else PSM_LAUNCH_WE2(4)
 #undef PSM_LAUNCH_WE2
 #undef PSM_LAUNCH_WE
+    if (tail) return;               // (the forced wave form applied its changes and queued their dependents itself)
     hipLaunchKernelGGL(k_wm_apply, ga, dim3(64), 0, s, p, sw, W, H, force);
-    if (!tail) hipLaunchKernelGGL(k_wm_gather, dim3(2048, 2), dim3(256), 0, s, p, sw, W, H);
+    hipLaunchKernelGGL(k_wm_gather, dim3(2048, 2), dim3(256), 0, s, p, sw, W, H);
 }
 
 void launch_wgt_median(hipStream_t s, uint8_t *dis, const uint8_t *valid, const float4 *g1, int W, int H, int maxDis, int right,
