@@ -83,7 +83,7 @@ int psm_wgt_median(psm_ctx *c, uint8_t *lmap, uint8_t *rmap, size_t stride)
     const size_t HW = (size_t)c->W * c->H;
     // PSM_FLAG_WMF_DATAFLOW: dataflow form only; PSM_FLAG_WMF_TWO_SWEEPS: at most 2 sweeps (test hook for the fall-back)
     const bool dataflow_only = (c->march.flags & PSM_FLAG_WMF_DATAFLOW) != 0;
-    const int CAP = (c->march.flags & PSM_FLAG_WMF_TWO_SWEEPS) ? 2 : 96, CHK = 4;
+    const int CAP = (c->march.flags & PSM_FLAG_WMF_TWO_SWEEPS) ? 2 : 96;
     bool done[2] = {false, false};
     if (!dataflow_only) {
         // parallel form: sweeps to the fixed point of the in-place recursion (psm_pp.hip), both maps side by side
@@ -161,7 +161,9 @@ int psm_wgt_median(psm_ctx *c, uint8_t *lmap, uint8_t *rmap, size_t stride)
         int upto[2] = {0, 0};              // sweeps covered by the snapshot in slot g & 1
         auto launch_group = [&](int slot) -> int {
             const bool short_lists = (tail[0] || done[0]) && (tail[1] || done[1]);
-            const int chk = short_lists ? 2 * CHK : CHK;
+            // two sweeps per group while the lists are long (the host learns two groups late that they have become short, and a
+            // sweep launched the long way costs three launches more than it needs then), eight once they are short
+            const int chk = short_lists ? 8 : 2;
             const int end = sw + chk < CAP ? sw + chk : CAP;
             {
                 Prof p(c, PSM_K_WMF);
