@@ -372,10 +372,11 @@ __global__ __launch_bounds__(256) void k_wm_weights(const float4 *__restrict__ g
 }
 
 template <bool RIGHT, bool CACHED>
-__device__ __forceinline__ void wm_eval_lanes(float *hist, const uint8_t *__restrict__ cur, const uint8_t *__restrict__ orig,
+__device__ __forceinline__ void wm_eval_lanes(float *hist, const uint8_t *cur, const uint8_t *__restrict__ orig,
                                               const float4 *__restrict__ g1, const int *__restrict__ list, const int *n_act,
                                               uint8_t *__restrict__ newv, int *__restrict__ chg, int *n_chg, int W, int H, int maxDis,
-                                              const float4 *__restrict__ wts, const int *__restrict__ slot_of)
+                                              const float4 *__restrict__ wts, const int *__restrict__ slot_of,
+                                              uint8_t *curw, uint8_t *__restrict__ chgb, uint8_t *__restrict__ rowany, int mark)
 {   // hist: [maxDis][64] floats of LDS, all zero between two evaluations
     const int lane = threadIdx.x;
     const int n = *n_act;
@@ -537,8 +538,16 @@ __device__ __forceinline__ void wm_eval_lanes(float *hist, const uint8_t *__rest
         const bool changed = live && filterDep != (int)cur[pix];
         const int slot = wm_append(n_chg, changed);
         if (changed) {
+            // (round 6) the pixel takes its value at once - as in the wave form's tail sweeps, a lane still evaluating may read
+            // either value, and whoever reads it is evaluated again next sweep - and leaves the marks of the gather form (itself
+            // and the 19 columns around it in its row) here, where rounds 3 - 5 had k_wm_apply walk the list of changes for it
+            // (66 us for the first sweep's 38 000 changes of the 1080p bench pair).  The scatter form still finds its list in chg.
             newv[pix] = (uint8_t)filterDep;
             chg[slot] = pix;
+            curw[pix] = (uint8_t)filterDep;
+            chgb[pix] = (uint8_t)mark;
+#pragma unroll
+            for (int wx = -WM_R; wx <= WM_R; ++wx) rowany[y * W + ((x + wx) % W + W) % W] = (uint8_t)mark;
         }
     }
 }
@@ -551,9 +560,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2))) void
     const WmSide &a = pr.s[blockIdx.y];
     const int *act = sw ? a.list[(sw + 1) & 1] : a.inv;
     if (CACHED || blockIdx.y == 0)
-        wm_eval_lanes<false, CACHED>(hist, a.cur, a.orig, a.g1, act, a.cnt + 2 * sw, a.newv, a.chg, a.cnt + 2 * sw + 1, W, H, maxDis, (const float4 *)a.wts, a.slot_of);
+        wm_eval_lanes<false, CACHED>(hist, a.cur, a.orig, a.g1, act, a.cnt + 2 * sw, a.newv, a.chg, a.cnt + 2 * sw + 1, W, H, maxDis, (const float4 *)a.wts, a.slot_of,
+                                     a.cur, a.chgb, a.rowany, sw + 1);
     else
-        wm_eval_lanes<true, CACHED>(hist, a.cur, a.orig, a.g1, act, a.cnt + 2 * sw, a.newv, a.chg, a.cnt + 2 * sw + 1, W, H, maxDis, (const float4 *)a.wts, a.slot_of);
+        wm_eval_lanes<true, CACHED>(hist, a.cur, a.orig, a.g1, act, a.cnt + 2 * sw, a.newv, a.chg, a.cnt + 2 * sw + 1, W, H, maxDis, (const float4 *)a.wts, a.slot_of,
+                                    a.cur, a.chgb, a.rowany, sw + 1);
 }
 
 // Short active lists (the tail sweeps: a few hundred pixels whose evaluation latency is what the sweep costs): one WAVE per
@@ -769,12 +780,13 @@ __global__ __launch_bounds__(256) void k_wm_gather(WmPair pr, int sw, int W, int
 __device__ __forceinline__ void wm_apply(uint8_t *__restrict__ cur, const uint8_t *__restrict__ newv, const uint8_t *__restrict__ valid,
                                          const int *__restrict__ chg, const int *n_chg, const int *n_inv, int *__restrict__ stamp, int mark,
                                          int *__restrict__ next, int *n_next, int W, int H, uint8_t *__restrict__ chgb, uint8_t *__restrict__ rowany, int force,
-                                         int wg, int nwg)
+                                         int wg, int nwg, const int *n_act)
 {
     const int lane = threadIdx.x;
     const int n = *n_chg;
-    if (!force && wm_gather_form(n, *n_inv)) {   // gather form: only mark (one thread per changed pixel); k_wm_gather builds the next list
-        for (int i = wg * 64 + lane; i < n; i += nwg * 64) {
+    if (!force && wm_gather_form(n, *n_inv)) {   // gather form: k_wm_gather builds the next list from the marks the evaluations left
+        if (*n_act >= WM_LANE_MIN) return;       // (k_wm_eval applied and marked its changes itself)
+        for (int i = wg * 64 + lane; i < n; i += nwg * 64) {      // changes found by the wave form (a short list of a long map)
             const int pix = chg[i];
             const int y = pix / W, x = pix - y * W;
             cur[pix] = newv[pix];
@@ -811,7 +823,7 @@ __global__ __launch_bounds__(64) void k_wm_apply(WmPair pr, int sw, int W, int H
 {
     const WmSide &a = pr.s[blockIdx.y];
     wm_apply(a.cur, a.newv, a.valid, a.chg, a.cnt + 2 * sw + 1, a.cnt, a.stamp, sw + 1, a.list[sw & 1], a.cnt + 2 * (sw + 1), W, H, a.chgb, a.rowany, force,
-             blockIdx.x, gridDim.x);
+             blockIdx.x, gridDim.x, a.cnt + 2 * sw);
 }
 
 // the 19 x 19 weights of the n_inv invalid pixels of `inv` (n = an upper bound of *n_inv, for the grid) -> wts, slot_of
