@@ -61,22 +61,30 @@ def spawn_ranks(n, args):
     import subprocess
 
     def run(extra, timeout=None):
-        with socket.socket() as so:
-            so.bind(("127.0.0.1", 0))
-            port = so.getsockname()[1]
         env = dict(os.environ)
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # the host driver only supports dmabuf IPC (RCCL needs it)
         env.setdefault("OMP_NUM_THREADS", "8")
-        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
-               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:] + extra
-        p = subprocess.Popen(cmd, env=env, start_new_session=True, stderr=subprocess.PIPE if timeout else None, text=True)
-        try:
-            _, err = p.communicate(timeout=timeout)
-        except subprocess.TimeoutExpired:
-            os.killpg(p.pid, signal.SIGKILL)           # (our own process group: the launcher and its ranks)
-            p.wait()
-            return 124, "no communicator within %d s" % timeout
-        return p.returncode, err
+        for attempt in range(3):
+            with socket.socket() as so:
+                so.bind(("127.0.0.1", 0))
+                port = so.getsockname()[1]
+            cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+                   "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:] + extra
+            p = subprocess.Popen(cmd, env=env, start_new_session=True, stderr=subprocess.PIPE, text=True)
+            try:
+                _, err = p.communicate(timeout=timeout)
+            except subprocess.TimeoutExpired:
+                os.killpg(p.pid, signal.SIGKILL)           # (our own process group: the launcher and its ranks)
+                p.wait()
+                return 124, "no communicator within %d s" % timeout
+            # the port was free when we asked and taken when the rendezvous store tried to listen (seen once in a round's sessions:
+            # the line of that run was lost): nothing has run yet - ask for another port
+            if p.returncode != 0 and "EADDRINUSE" in (err or "") and attempt < 2:
+                print("bench.py: rendezvous port %d was taken before the launcher could listen on it; retrying with another" % port, file=sys.stderr)
+                continue
+            if not timeout and err:
+                sys.stderr.write(err)                      # (a measurement run: its ranks' messages belong on our stderr)
+            return p.returncode, err
 
     if not args.same_device:
         # one rank per GPU: more ranks than devices cannot work - say so before anything is launched
@@ -834,6 +842,13 @@ def main():
         roofline["achieved"], roofline["frac"] = roofline["pipeline_alg_GBs"], roofline["pipeline_frac"]
         roofline["frac_basis"] = f"whole step: pipeline algorithmic bytes / ms_per_step ({len(ring)} frames in flight: launches of consecutive frames overlap)"
         roofline.pop("valu", None); roofline["binding_frac"] = None
+    if roofline["frac"] > 1.0:
+        # even the whole step outruns what the staged pipeline's bytes would need at the HBM peak (the opt-in tolerance form on the
+        # round's fastest boxes: 1.00x): the figure stays what was measured - it is an algorithmic-equivalent rate, not a
+        # utilisation - and the line says so instead of clamping it
+        roofline["exceeds_hbm_peak"] = True
+        roofline["exceeds_hbm_peak_note"] = ("frac > 1: the fused step finishes sooner than the staged pipeline's algorithmic bytes (48 B / voxel) could cross "
+                                             "HBM at its peak; the kernel's physical HBM rate is traffic_frac of the peak and VALU issue binds it")
     for nm, v in kern.items():
         if nm in algb:
             v["alg_GBs"] = round(algb[nm] * vox_per_launch / (v["avg_ms"] * 1e-3) / 1e9, 1)

@@ -269,7 +269,9 @@ int psm_fill_invalid(psm_ctx *ctx, uint8_t *lmap, uint8_t *rmap, size_t stride);
  * device's per-sweep counters), so the call returns with the filtered maps complete. */
 int psm_wgt_median(psm_ctx *ctx, uint8_t *lmap, uint8_t *rmap, size_t stride);
 /* What the last psm_wgt_median did, per map {left, right}: sweeps until the fixed point (-1: dataflow form) and pixel
- * evaluations in total.  Either pointer may be NULL. */
+ * evaluations in total.  Either pointer may be NULL.  The maps are a function of the input alone (the unique fixed point of the
+ * in-place recursion); these two numbers are not - a changed pixel is visible to evaluations still running in its sweep, so how
+ * many evaluations (and, on dense maps, sweeps) a call needs can differ from run to run. */
 int psm_wgt_median_stats(psm_ctx *ctx, int sweeps[2], long long evals[2]);
 
 /* ---- second sharding axis: row stripes (SURVEY.md 8e asks for shards of the path; the filter's vertical support is
