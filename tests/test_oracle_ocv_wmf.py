@@ -243,3 +243,48 @@ def test_wgt_median_is_the_fixed_point_of_parallel_sweeps(oracle, seed, frac, tw
     assert np.array_equal(cur, seq)
     assert sweep <= len(inv) + 1                               # (worst case: one pixel of the dependency chain per sweep)
     print(f"[wmf-fixed-point] {len(inv)} invalid pixels, {sweep} sweeps")
+
+
+@pytest.mark.parametrize("seed,frac,two_camps,geo", [(31, 0.5, False, (14, 16, 12)), (32, 0.7, True, (14, 16, 12)), (33, 1.0, True, (14, 16, 12)),
+                                                     (34, 0.9, False, (30, 46, 24)), (35, 1.0, True, (26, 40, 16))])
+def test_wgt_median_sweeps_with_changes_visible_at_once(oracle, seed, frac, two_camps, geo):
+    """Round 6's form of the sweeps: a change is written the moment it is found, so an evaluation of the same sweep
+    sees the old value or the new one depending on timing, and only the pixels a change can reach - the later invalid pixels with
+    the changed one in their window - are evaluated in the next sweep.  Modelled here with a random order of the evaluations
+    inside a sweep and a coin per evaluation for "reads the values of this sweep's earlier writers or the sweep's starting map":
+    whatever the timing, the sweeps end (a sweep without a change) in the sequential map."""
+    H, W, D0 = geo
+    R = 9
+    img, dis, valid, D = _wm_case(seed, H=H, W=W, D=D0, frac_invalid=frac)
+    if two_camps:
+        img[:] = np.float32(0.5)
+        dis = np.where(np.random.default_rng(seed).random(dis.shape) < 0.5, 2, 9).astype(np.uint8)
+    seq = oracle.wgt_median(img, dis, valid, D)
+    idx = np.arange(H * W).reshape(H, W)
+    rng = np.random.default_rng(seed + 100)
+    cur = dis.copy()
+    active = [tuple(p) for p in zip(*np.nonzero(valid == 0))]
+    sweeps = evals = 0
+    while active:
+        sweeps += 1
+        assert sweeps < 400
+        start = cur.copy()
+        nxt = set()
+        for k in rng.permutation(len(active)):
+            y, x = active[k]
+            view = cur if rng.random() < 0.5 else start            # (timing: this sweep's writes seen, or not)
+            seen = np.where(idx < idx[y, x], view, dis)
+            one = np.ones_like(valid)
+            one[y, x] = 0
+            v = oracle.wgt_median(img, seen, one, D)[y, x]
+            evals += 1
+            if v != cur[y, x]:
+                cur[y, x] = v                                      # written at once ...
+                for wy in range(-R, R + 1):                        # ... and its later invalid window neighbours queued
+                    for wx in range(-R, R + 1):
+                        py, px = (y - wy) % H, (x - wx) % W
+                        if idx[py, px] > idx[y, x] and valid[py, px] == 0:
+                            nxt.add((py, px))
+        active = sorted(nxt)
+    assert np.array_equal(cur, seq)
+    print(f"[wmf-in-sweep] {int((valid == 0).sum())} invalid pixels, {sweeps} sweeps, {evals} evaluations")
