@@ -96,6 +96,41 @@ def test_wgt_median_long_lists_with_and_without_the_weight_cache(psm, oracle, fl
     assert np.array_equal(gl, el) and np.array_equal(gr, er)
 
 
+def test_wgt_median_repeats_give_one_map(psm, oracle):
+    """Round 6: a changed pixel is written the moment it is found, so which evaluations of a sweep see it depends on timing - the
+    number of evaluations may differ between runs, the maps may not (the fixed point is unique).  The same dense input twelve times,
+    from the fifth on with a second context filtering another map on its own stream and host thread to stir the timing: one map, the oracle's."""
+    H, W, D = 110, 230, 96
+    l, lm, rm, lv, rv = _wm_inputs(H, W, D, seed=123, frac_invalid=0.6)
+    r = np.roll(l, 5, axis=1)
+    el = oracle.wgt_median(oracle.u8_to_f32(l), lm, lv, D, right=False)
+    er = oracle.wgt_median(oracle.u8_to_f32(r), rm, rv, D, right=True)
+    import threading
+    seen = set()
+    with psm.DispEst(l, r, D) as de, psm.DispEst(r, l, D) as other:
+        stop = threading.Event()
+
+        def stir():                        # (its own context and stream; the C calls release the interpreter lock)
+            while not stop.is_set():
+                other.upload_maps(rm, lm, rv, lv)
+                other.WgtMedian_GPU()
+
+        th = threading.Thread(target=stir)
+        try:
+            for rep in range(12):
+                if rep == 4:
+                    th.start()
+                de.upload_maps(lm, rm, lv, rv)
+                de.WgtMedian_GPU()
+                assert np.array_equal(de.lDisMap, el) and np.array_equal(de.rDisMap, er), rep
+                seen.add(tuple(de.wgt_median_stats()[1]))
+        finally:
+            stop.set()
+            if th.is_alive():
+                th.join()
+    print(f"[wmf] 12 repeats: {len(seen)} different evaluation counts {sorted(seen)[:3]} ...")
+
+
 @pytest.mark.parametrize("fl,fr", [(0.0, 0.5), (0.5, 0.0), (0.55, 0.02), (0.01, 0.6), (0.0, 0.0)])
 @pytest.mark.parametrize("flags", [0, 16777216])
 def test_wgt_median_unequal_maps_share_their_launches(psm, oracle, fl, fr, flags):
