@@ -286,8 +286,15 @@ __global__ __launch_bounds__(256) void k_wm_seed(WmPair pr, int HW, int nb)
         *reinterpret_cast<uint4 *>(a.orig + base) = dv;
         *reinterpret_cast<uint4 *>(a.chgb + base) = z;
         *reinterpret_cast<uint4 *>(a.rowany + base) = z;
+    }
+    {   // the wave's 1 024 stamps, a contiguous kilobyte per store (16 bytes a lane at a 64-byte stride reach the L2 as partial lines)
+        const int wbase = base - lane * WM_SEED_PER;
+        const uint4 z = make_uint4(0u, 0u, 0u, 0u);
 #pragma unroll
-        for (int k = 0; k < WM_SEED_PER / 4; ++k) reinterpret_cast<uint4 *>(a.stamp + base)[k] = z;
+        for (int k = 0; k < WM_SEED_PER / 4; ++k) {
+            const int i0 = wbase + 4 * (k * 64 + lane);
+            if (i0 < nb) *reinterpret_cast<uint4 *>(a.stamp + i0) = z;
+        }
     }
     const int c = __builtin_popcount(m);
     int incl = c;                                     // inclusive prefix sum over the wave
