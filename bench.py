@@ -842,7 +842,7 @@ def main():
         roofline["achieved"], roofline["frac"] = roofline["pipeline_alg_GBs"], roofline["pipeline_frac"]
         roofline["frac_basis"] = f"whole step: pipeline algorithmic bytes / ms_per_step ({len(ring)} frames in flight: launches of consecutive frames overlap)"
         roofline.pop("valu", None); roofline["binding_frac"] = None
-    if roofline["frac"] > 1.0:
+    if roofline["frac"] is not None and roofline["frac"] > 1.0:
         # even the whole step outruns what the staged pipeline's bytes would need at the HBM peak (the opt-in tolerance form on the
         # round's fastest boxes: 1.00x): the figure stays what was measured - it is an algorithmic-equivalent rate, not a
         # utilisation - and the line says so instead of clamping it

@@ -84,6 +84,9 @@ def test_shard_sim_lines_are_verified():
     for shard in ("rows", "disp"):
         j = _bench("--shard-sim", "4", "--shard", shard, "--config", "c3", "--steps", "3", "--warmup", "1")
         assert j["verified_vs_single_gpu"] is True and j["oracle_maps_equal"] is True, shard
+    # ... and with two frames in flight on the share (the line has no per-launch roofline then: frac is null, not an error)
+    j = _bench("--shard-sim", "4", "--shard", "rows", "--frames-in-flight", "2", "--config", "c3", "--steps", "4", "--warmup", "2", "--no-cpu-baseline")
+    assert j["verified_vs_single_gpu"] is True and j["config"]["frames_in_flight"] == 2 and j["roofline"]["frac"] is None
 
 
 @pytest.mark.parametrize("parts", [2, 8])
