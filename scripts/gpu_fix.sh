@@ -1,4 +1,5 @@
 #!/bin/bash
+# short session: the two --shard-sim 8 --frames-in-flight 2 lines of scripts/gpu_round.sh + tests/test_gpu_bench.py (after the None comparison fix in bench.py)
 TAG=${1:-fix}
 OUT=gpurun_out/$TAG
 mkdir -p $OUT

@@ -1,4 +1,5 @@
 #!/bin/bash
+# short session: the tests that touch the post-processing rows (fillInv, weighted median) + bench.py --pp twice
 TAG=${1:-s8}
 O=gpurun_out/$TAG
 mkdir -p $O
